@@ -1,0 +1,397 @@
+#!/usr/bin/env python3
+"""Generate the constant tables of the single static CELT mode (48 kHz, 960-sample frame,
+120-sample overlap, FIXED_POINT) from their defining formulas.
+
+The reference ships these as pre-dumped arrays (opus-fix/celt/static_modes_fixed.h:14-866,
+opus-fix/celt/cwrs.c:213); they were produced by the CUSTOM_MODES initialisers, whose published
+algorithms are restated here:
+
+  window120          celt/modes.c  (power-complementary "Vorbis" window, Q15, clamped to 32767)
+  fft twiddles       celt/kiss_fft.c:425-440 compute_twiddles (fixed branch: celt_cos_norm)
+  fft bitrev tables  celt/kiss_fft.c:328-359 compute_bitrev_table + kf_factor :365-420
+  mdct trig          celt/mdct.c:86-96 clt_mdct_init (double-precision branch, clamped)
+  logN400            celt/modes.c  (log2_frac(width, BITRES))
+  pulse cache        celt/rate.c:70-245 compute_pulse_cache, celt/cwrs.c:45-72 log2_frac
+  PVQ U(n,k) table   celt/cwrs.c:195-215 (recurrence U(n,k)=U(n-1,k)+U(n,k-1)+U(n-1,k-1))
+
+Small hand-tuned tables of the Opus specification (band edges, allocation matrix, probability
+models ...) cannot be derived and are listed literally.
+
+tests/test_tables.py checks every generated array against the compiled reference
+(oracle/_ref/libopus_ref.so) when that library is present.
+
+Usage: python tools/gen_tables.py   -> writes concentus_amd/csrc/celt_tables.h and oracle/oracle_tables.h
+"""
+import math
+import os
+
+BITRES = 3
+NB_EBANDS = 21
+EBAND5MS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14, 16, 20, 24, 28, 34, 40, 48, 60, 78, 100]
+
+# ---------------------------------------------------------------- fixed-point helpers
+
+
+def _s16(x):
+    x &= 0xFFFF
+    return x - 0x10000 if x & 0x8000 else x
+
+
+def _mult16_16_p15(a, b):
+    return (16384 + a * b) >> 15
+
+
+def _cos_pi_2(x):
+    """celt/mathops.c:142-150 _celt_cos_pi_2 (x Q15 in [0,1))."""
+    l1, l2, l3, l4 = 32767, -7651, 8277, -626
+    x2 = _mult16_16_p15(x, x)
+    inner = l3 + _mult16_16_p15(l4, x2)
+    inner = l2 + _mult16_16_p15(x2, inner)
+    v = (l1 - x2) + _mult16_16_p15(x2, inner)
+    return _s16(1 + min(32766, v))
+
+
+def cos_norm(x):
+    """celt/mathops.c:156-177 celt_cos_norm: cos(pi/2 * x / 32768 ... ) with period 2^17."""
+    x &= 0x1FFFF
+    if x > (1 << 16):
+        x = (1 << 17) - x
+    if x & 0x7FFF:
+        if x < (1 << 15):
+            return _cos_pi_2(_s16(x))
+        return -_cos_pi_2(_s16(65536 - x))
+    if x & 0xFFFF:
+        return 0
+    if x & 0x1FFFF:
+        return -32767
+    return 32767
+
+
+def _cdiv(a, b):
+    """C division (truncate toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a < 0) == (b < 0) else -q
+
+
+# ---------------------------------------------------------------- tables
+
+
+def window(overlap=120):
+    out = []
+    for i in range(overlap):
+        s = math.sin(0.5 * math.pi * (i + 0.5) / overlap)
+        out.append(min(32767, int(math.floor(0.5 + 32768.0 * math.sin(0.5 * math.pi * s * s)))))
+    return out
+
+
+def fft_twiddles(nfft=480):
+    out = []
+    for i in range(nfft):
+        phase = _cdiv((-i) << 17, nfft) if i else 0
+        out.append((cos_norm(phase), cos_norm(phase - 32768)))
+    return out
+
+
+def fft_factors(n):
+    """kf_factor: radix list as (p, m) pairs, radix-4 stages last."""
+    p = 4
+    ps = []
+    nn = n
+    while nn > 1:
+        while nn % p:
+            p = {4: 2, 2: 3}.get(p, p + 2)
+            if p > 32000 or p * p > nn:
+                p = nn
+        nn //= p
+        assert p <= 5
+        ps.append(p)
+        if p == 2 and len(ps) > 2:
+            ps[-1] = 4
+            ps[1] = 2
+    ps = ps[::-1]
+    fac = []
+    nn = n
+    for p in ps:
+        nn //= p
+        fac.append((p, nn))
+    return fac
+
+
+def fft_bitrev(nfft):
+    fac = fft_factors(nfft)
+    table = [0] * nfft
+
+    def rec(fout, f, fstride, level):
+        p, m = fac[level]
+        if m == 1:
+            for j in range(p):
+                table[f] = fout + j
+                f += fstride
+        else:
+            for j in range(p):
+                rec(fout, f, fstride * p, level + 1)
+                f += fstride
+                fout += m
+
+    rec(0, 0, 1, 0)
+    return table
+
+
+def mdct_trig(n=1920, maxshift=3):
+    """celt/mdct.c:86-96: the shipped table follows the double-precision branch
+    (round(32768*cos(2*pi*(i+1/8)/N)) clamped to +-32767), not the celt_cos_norm one."""
+    out = []
+    nn = n
+    for _ in range(maxshift + 1):
+        n2 = nn >> 1
+        for i in range(n2):
+            v = math.floor(0.5 + 32768.0 * math.cos(2.0 * math.pi * (i + 0.125) / nn))
+            out.append(int(max(-32767, min(32767, v))))
+        nn >>= 1
+    return out
+
+
+def ec_ilog(v):
+    return v.bit_length()
+
+
+def log2_frac(val, frac):
+    l = ec_ilog(val)
+    if val & (val - 1):
+        if l > 16:
+            val = ((val - 1) >> (l - 16)) + 1
+        else:
+            val <<= 16 - l
+        l = (l - 1) << frac
+        while True:
+            b = val >> 16
+            l += b << frac
+            val = (val + b) >> b
+            val = (val * val + 0x7FFF) >> 15
+            frac -= 1
+            if frac < 0:
+                break
+        return l + (1 if val > 0x8000 else 0)
+    return (l - 1) << frac
+
+
+def logn():
+    return [log2_frac(EBAND5MS[i + 1] - EBAND5MS[i], BITRES) for i in range(NB_EBANDS)]
+
+
+_U = {}
+
+
+def pvq_u(n, k):
+    """U(n,k): codewords of dimension n with k pulses whose first... (cwrs.c:195)."""
+    if n == 0:
+        return 1 if k == 0 else 0
+    if k == 0:
+        return 0
+    n, k = min(n, k), max(n, k)
+    key = (n, k)
+    if key not in _U:
+        # iterative fill to avoid deep recursion
+        for kk in range(1, k + 1):
+            for nn in range(1, min(n, kk) + 1):
+                if (nn, kk) in _U:
+                    continue
+                _U[(nn, kk)] = pvq_u(nn - 1, kk) + pvq_u(nn, kk - 1) + pvq_u(nn - 1, kk - 1)
+    return _U[key]
+
+
+def pvq_v(n, k):
+    return pvq_u(n, k) + pvq_u(n, k + 1)
+
+
+# row r of the packed U table holds U(r, k) for k = r .. PVQ_ROW_LAST[r]   (cwrs.c:421-427)
+PVQ_ROW_OFFSET = [0, 176, 351, 525, 698, 870, 1041, 1131, 1178, 1207, 1226, 1240, 1248, 1254, 1257]
+PVQ_TABLE_LEN = 1272
+
+
+def pvq_u_table():
+    data = [0] * PVQ_TABLE_LEN
+    for r in range(15):
+        start = PVQ_ROW_OFFSET[r] + r
+        end = (PVQ_ROW_OFFSET[r + 1] + r + 1) if r < 14 else PVQ_TABLE_LEN
+        for idx in range(start, end):
+            k = idx - PVQ_ROW_OFFSET[r]
+            v = pvq_u(r, k)
+            assert v < (1 << 32), (r, k)
+            data[idx] = v
+    return data
+
+
+def get_pulses(i):
+    return i if i < 8 else (8 + (i & 7)) << ((i >> 3) - 1)
+
+
+def _fits_in32(n, k):
+    max_n = [32767, 32767, 32767, 1476, 283, 109, 60, 40, 29, 24, 20, 18, 16, 14, 13]
+    max_k = [32767, 32767, 32767, 32767, 1172, 238, 95, 53, 36, 27, 22, 18, 16, 15, 13]
+    if n >= 14:
+        return False if k >= 14 else n <= max_n[k]
+    return k <= max_k[n]
+
+
+def pulse_cache(max_lm=3):
+    """celt/rate.c:70-245 compute_pulse_cache for the standard mode. Returns (index, bits, caps)."""
+    max_pseudo = 40
+    qtheta_offset, qtheta_offset_twophase, fine_offset, max_fine_bits = 4, 16, 21, 8
+    eb = EBAND5MS
+    nb = NB_EBANDS
+    ln = logn()
+    cindex = [-1] * (nb * (max_lm + 2))
+    entries = []
+    curr = 0
+    for i in range(max_lm + 2):
+        for j in range(nb):
+            n = ((eb[j + 1] - eb[j]) << i) >> 1
+            found = False
+            for k in range(i + 1):
+                for t in range(nb):
+                    if k == i and t >= j:
+                        break
+                    if n == ((eb[t + 1] - eb[t]) << k) >> 1:
+                        cindex[i * nb + j] = cindex[k * nb + t]
+                        found = True
+                        break
+                if found:
+                    break
+            if cindex[i * nb + j] == -1 and n != 0:
+                kk = 0
+                while _fits_in32(n, get_pulses(kk + 1)) and kk < max_pseudo:
+                    kk += 1
+                entries.append((n, kk, curr))
+                cindex[i * nb + j] = curr
+                curr += kk + 1
+    bits = [0] * curr
+    for n, kk, at in entries:
+        bits[at] = kk
+        for j in range(1, kk + 1):
+            p = get_pulses(j)
+            req = (1 << BITRES) if n == 1 else log2_frac(pvq_v(n, p), BITRES)
+            bits[at + j] = req - 1
+    caps = []
+    for i in range(max_lm + 1):
+        for c in (1, 2):
+            for j in range(nb):
+                n0 = eb[j + 1] - eb[j]
+                if (n0 << i) == 1:
+                    max_bits = (c * (1 + max_fine_bits)) << BITRES
+                else:
+                    lm0 = 0
+                    if n0 > 2:
+                        n0 >>= 1
+                        lm0 -= 1
+                    elif n0 <= 1:
+                        lm0 = min(i, 1)
+                        n0 <<= lm0
+                    pc = cindex[(lm0 + 1) * nb + j]
+                    max_bits = bits[pc + bits[pc]] + 1
+                    n = n0
+                    for k in range(i - lm0):
+                        max_bits <<= 1
+                        offset = ((ln[j] + ((lm0 + k) << BITRES)) >> 1) - qtheta_offset
+                        num = 459 * ((2 * n - 1) * offset + max_bits)
+                        den = ((2 * n - 1) << 9) - 459
+                        max_bits += min(_cdiv(num + (den >> 1), den), 57)
+                        n <<= 1
+                    if c == 2:
+                        max_bits <<= 1
+                        offset = ((ln[j] + (i << BITRES)) >> 1) - (qtheta_offset_twophase if n == 2 else qtheta_offset)
+                        ndof = 2 * n - 1 - (1 if n == 2 else 0)
+                        mul = 512 if n == 2 else 487
+                        num = mul * (max_bits + ndof * offset)
+                        den = (ndof << 9) - mul
+                        max_bits += min(_cdiv(num + (den >> 1), den), 64 if n == 2 else 61)
+                    ndof = c * n + (1 if (c == 2 and n > 2) else 0)
+                    offset = ((ln[j] + (i << BITRES)) >> 1) - fine_offset
+                    if n == 2:
+                        offset += (1 << BITRES) >> 2
+                    num = max_bits + ndof * offset
+                    den = (ndof - 1) << BITRES
+                    qb = min(_cdiv(num + (den >> 1), den), max_fine_bits)
+                    max_bits += (c * qb) << BITRES
+                max_bits = _cdiv(4 * max_bits, c * ((eb[j + 1] - eb[j]) << i)) - 64
+                assert 0 <= max_bits < 256
+                caps.append(max_bits)
+    return cindex, bits, caps
+
+
+# ---------------------------------------------------------------- literal spec tables
+
+# celt/modes.c:50-63: bit allocation matrix, 1/32 bit per sample, 11 quality rows x 21 bands
+BAND_ALLOCATION = [
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    90, 80, 75, 69, 63, 56, 49, 40, 34, 29, 20, 18, 10, 0, 0, 0, 0, 0, 0, 0, 0,
+    110, 100, 90, 84, 78, 71, 65, 58, 51, 45, 39, 32, 26, 20, 12, 0, 0, 0, 0, 0, 0,
+    118, 110, 103, 93, 86, 80, 75, 70, 65, 59, 53, 47, 40, 31, 23, 15, 4, 0, 0, 0, 0,
+    126, 119, 112, 104, 95, 89, 83, 78, 72, 66, 60, 54, 47, 39, 32, 25, 17, 12, 1, 0, 0,
+    134, 127, 120, 114, 103, 97, 91, 85, 78, 72, 66, 60, 54, 47, 41, 35, 29, 23, 16, 10, 1,
+    144, 137, 130, 124, 113, 107, 101, 95, 88, 82, 76, 70, 64, 57, 51, 45, 39, 33, 26, 15, 1,
+    152, 145, 138, 132, 123, 117, 111, 105, 98, 92, 86, 80, 74, 67, 61, 55, 49, 43, 36, 20, 1,
+    162, 155, 148, 142, 133, 127, 121, 115, 108, 102, 96, 90, 84, 77, 71, 65, 59, 53, 46, 30, 1,
+    172, 165, 158, 152, 143, 137, 131, 125, 118, 112, 106, 100, 94, 87, 81, 75, 69, 63, 56, 45, 20,
+    200, 200, 200, 200, 200, 200, 200, 200, 198, 193, 188, 183, 178, 173, 168, 163, 158, 153, 148, 129, 104,
+]
+
+
+def all_tables():
+    idx, bits, caps = pulse_cache()
+    tw = fft_twiddles(480)
+    t = {
+        "window120": ("int16_t", window(120)),
+        "fft_twiddles480": ("int16_t", [v for pair in tw for v in pair]),
+        "fft_bitrev480": ("int16_t", fft_bitrev(480)),
+        "fft_bitrev240": ("int16_t", fft_bitrev(240)),
+        "fft_bitrev120": ("int16_t", fft_bitrev(120)),
+        "fft_bitrev60": ("int16_t", fft_bitrev(60)),
+        "mdct_trig960": ("int16_t", mdct_trig()),
+        "eband5ms": ("int16_t", EBAND5MS),
+        "logN400": ("int16_t", logn()),
+        "band_allocation": ("uint8_t", BAND_ALLOCATION),
+        "cache_index50": ("int16_t", idx),
+        "cache_bits50": ("uint8_t", bits),
+        "cache_caps50": ("uint8_t", caps),
+        "pvq_u_data": ("uint32_t", pvq_u_table()),
+        "pvq_u_row": ("uint16_t", PVQ_ROW_OFFSET),
+    }
+    return t
+
+
+def emit(path, prefix="CLT_"):
+    t = all_tables()
+    lines = [
+        "/* GENERATED by tools/gen_tables.py -- do not edit.",
+        " * Constant tables of the static CELT mode 48000/960/120 (FIXED_POINT), derived from",
+        " * their defining formulas; verified against the compiled reference in tests/test_tables.py. */",
+        "#ifndef CONCENTUS_AMD_CELT_TABLES_H",
+        "#define CONCENTUS_AMD_CELT_TABLES_H",
+        "#include <stdint.h>",
+        "#ifndef CLT_TABLE_QUAL",
+        "#define CLT_TABLE_QUAL static const",
+        "#endif",
+        "",
+    ]
+    for name, (ctype, vals) in t.items():
+        lines.append("CLT_TABLE_QUAL %s %s%s[%d] = {" % (ctype, prefix, name, len(vals)))
+        row = []
+        for i, v in enumerate(vals):
+            row.append(("%du" % v) if ctype == "uint32_t" else str(v))
+            if len(row) == 12 or i == len(vals) - 1:
+                lines.append("  " + ", ".join(row) + ",")
+                row = []
+        lines.append("};")
+        lines.append("")
+    lines.append("#endif")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emit(os.path.join(root, "concentus_amd", "csrc", "celt_tables.h"))
+    # the oracle keeps its own copy so that nothing under oracle/ depends on the product tree
+    emit(os.path.join(root, "oracle", "oracle_tables.h"))
+    print("wrote celt_tables.h, oracle_tables.h")
