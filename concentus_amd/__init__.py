@@ -1,0 +1,11 @@
+"""concentus_amd -- MI355X (gfx950) batched Opus frame path behind a C-ABI (libopusgpu.so).
+
+Host-side mirror of the reference's operator interface for the hot path only
+(opus-fix: CELT MDCT, PVQ band quantiser, range coder, SILK Burg/NSQ). PyTorch is used for device
+memory and streams; every computation happens in hand-written HIP kernels reached through
+`include/opusgpu.h`. There is no CPU fallback: a missing library raises.
+"""
+from . import lib  # noqa: F401
+from .mdct import clt_mdct_forward, clt_mdct_backward, mdct_forward_batch, mdct_backward_batch  # noqa: F401
+
+__all__ = ["lib", "clt_mdct_forward", "clt_mdct_backward", "mdct_forward_batch", "mdct_backward_batch"]

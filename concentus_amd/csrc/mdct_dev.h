@@ -1,0 +1,323 @@
+// mdct_dev.h -- wave-cooperative CELT MDCT / FFT for gfx950 (one 64-lane wavefront per transform).
+//
+// Device-side building blocks shared by the MDCT-only kernels (mdct_kernels.hip) and the full CELT
+// frame kernels. All working arrays live in LDS and belong to ONE wavefront; `wave_sync()` orders the
+// LDS traffic between its lanes. The arithmetic per element follows the reference bit for bit
+// (opus-fix/celt/kiss_fft.c:51-322,532-578 and celt/mdct.c:121-363); what is new is the mapping:
+// every butterfly stage is one flat index space of 480/p butterflies spread over the 64 lanes, and
+// the 8 short blocks of a transient frame run side by side in the same index space.
+#pragma once
+#include "fixmath.h"
+#include "device_tables.h"
+
+namespace ca {
+
+// ---- LDS-resident constant tables (staged once per workgroup) ------------------------------------
+// "A" holds the tables of the long transform in use (shift 0 in the frame kernels), "B" those of the
+// short one (shift 3); trig entries are packed (trig[i] & 0xffff) | (trig[N4+i] << 16).
+struct MdctLds {
+    u32 tw[480];        // fft twiddles, packed (r & 0xffff) | (i << 16)   static_modes_fixed.h:104
+    u32 trigA[480];
+    u32 trigB[60];
+    u16 bitrevA[480];
+    u16 bitrevB[64];
+    i16 window[120];    // window120
+};
+
+template <int SHIFT>
+CA_DEV void mdct_stage_shift(u32 *trig, u16 *bitrev, int tid, int nthreads)
+{
+    constexpr int N4 = 480 >> SHIFT;
+    constexpr int OFF = SHIFT == 0 ? 0 : SHIFT == 1 ? 960 : SHIFT == 2 ? 1440 : 1680;   // mdct.c:141-146
+    const i16 *br = SHIFT == 0 ? CLT_fft_bitrev480 : SHIFT == 1 ? CLT_fft_bitrev240
+                  : SHIFT == 2 ? CLT_fft_bitrev120 : CLT_fft_bitrev60;
+    const i16 *t = CLT_mdct_trig960 + OFF;
+    for (int i = tid; i < N4; i += nthreads) {
+        trig[i] = (u32)(uint16_t)t[i] | ((u32)(uint16_t)t[N4 + i] << 16);
+        bitrev[i] = (u16)br[i];
+    }
+}
+
+CA_DEV void mdct_stage_common(MdctLds &L, int tid, int nthreads)
+{
+    for (int i = tid; i < 480; i += nthreads)
+        L.tw[i] = (u32)(uint16_t)CLT_fft_twiddles480[2 * i] | ((u32)(uint16_t)CLT_fft_twiddles480[2 * i + 1] << 16);
+    for (int i = tid; i < 120; i += nthreads) L.window[i] = CLT_window120[i];
+}
+
+// ---- complex helpers ------------------------------------------------------------------------------
+struct cpx { i32 r, i; };
+CA_DEV cpx ld(const int2 *p) { int2 v = *p; return cpx{v.x, v.y}; }
+CA_DEV void st(int2 *p, cpx v) { *p = make_int2(v.r, v.i); }
+CA_DEV i32 lo16(u32 p) { return (i32)(i16)(p & 0xffff); }
+CA_DEV i32 hi16(u32 p) { return (i32)p >> 16; }
+#define CA_SMUL(x, t) mul16_32_q15((t), (x))       // S_MUL(a,b) = MULT16_32_Q15(b,a)
+
+CA_DEV cpx c_mul(cpx a, u32 tw)                     // _kiss_fft_guts.h:59 C_MUL
+{
+    i32 tr = lo16(tw), ti = hi16(tw);
+    cpx m;
+    m.r = sub32(CA_SMUL(a.r, tr), CA_SMUL(a.i, ti));
+    m.i = add32(CA_SMUL(a.r, ti), CA_SMUL(a.i, tr));
+    return m;
+}
+CA_DEV cpx c_add(cpx a, cpx b) { return cpx{add32(a.r, b.r), add32(a.i, b.i)}; }
+CA_DEV cpx c_sub(cpx a, cpx b) { return cpx{sub32(a.r, b.r), sub32(a.i, b.i)}; }
+
+// ---- butterfly stages: B blocks of NFFT points laid out back to back in x[] ----------------------
+template <int NFFT, int B>
+CA_DEV void fft_radix4_first(int2 *x, int lane)     // kiss_fft.c:123-145, m == 1
+{
+    constexpr int CNT = B * NFFT / 4;
+    for (int idx = lane; idx < CNT; idx += 64) {
+        int2 *f = x + 4 * idx;
+        cpx x0 = ld(f), x1 = ld(f + 1), x2 = ld(f + 2), x3 = ld(f + 3);
+        cpx s0 = c_sub(x0, x2);
+        x0 = c_add(x0, x2);
+        cpx s1 = c_add(x1, x3);
+        x2 = c_sub(x0, s1);
+        x0 = c_add(x0, s1);
+        s1 = c_sub(x1, x3);
+        st(f, x0);
+        st(f + 2, x2);
+        st(f + 1, cpx{add32(s0.r, s1.i), sub32(s0.i, s1.r)});
+        st(f + 3, cpx{sub32(s0.r, s1.i), add32(s0.i, s1.r)});
+    }
+}
+
+template <int NFFT, int B>
+CA_DEV void fft_radix2_m4(int2 *x, int lane)        // kiss_fft.c:72-107, m == 4
+{
+    // one lane per (group, k) pair: k selects which of the four fixed rotations applies
+    constexpr int CNT = B * NFFT / 2;
+    constexpr i32 TW = 23170;
+    for (int idx = lane; idx < CNT; idx += 64) {
+        int g = idx >> 2, k = idx & 3;
+        int2 *f = x + 8 * g + k;
+        cpx a = ld(f), b = ld(f + 4), t;
+        if (k == 0) {
+            t = b;
+        } else if (k == 1) {
+            t.r = CA_SMUL(add32(b.r, b.i), TW);
+            t.i = CA_SMUL(sub32(b.i, b.r), TW);
+        } else if (k == 2) {
+            t.r = b.i;
+            t.i = neg32(b.r);
+        } else {
+            t.r = CA_SMUL(sub32(b.i, b.r), TW);
+            t.i = CA_SMUL(sub32(neg32(b.i), b.r), TW);
+        }
+        st(f + 4, c_sub(a, t));
+        st(f, c_add(a, t));
+    }
+}
+
+template <int NFFT, int B, int M>
+CA_DEV void fft_radix4(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:146-176
+{
+    constexpr int G = NFFT / (4 * M);
+    constexpr int TWS = G * (480 / NFFT);
+    constexpr int CNT = B * NFFT / 4;
+    for (int idx = lane; idx < CNT; idx += 64) {
+        int blk = idx / (G * M), r = idx % (G * M);
+        int g = r / M, j = r % M;
+        int2 *f = x + blk * NFFT + g * 4 * M + j;
+        cpx f0 = ld(f);
+        cpx a = c_mul(ld(f + M), tw[j * TWS]);
+        cpx b = c_mul(ld(f + 2 * M), tw[2 * j * TWS]);
+        cpx c = c_mul(ld(f + 3 * M), tw[3 * j * TWS]);
+        cpx d5 = c_sub(f0, b);
+        f0 = c_add(f0, b);
+        cpx s3 = c_add(a, c);
+        cpx s4 = c_sub(a, c);
+        st(f + 2 * M, c_sub(f0, s3));
+        st(f, c_add(f0, s3));
+        st(f + M, cpx{add32(d5.r, s4.i), sub32(d5.i, s4.r)});
+        st(f + 3 * M, cpx{sub32(d5.r, s4.i), add32(d5.i, s4.r)});
+    }
+}
+
+template <int NFFT, int B, int M>
+CA_DEV void fft_radix3(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:185-241
+{
+    constexpr int G = NFFT / (3 * M);
+    constexpr int TWS = G * (480 / NFFT);
+    constexpr int CNT = B * NFFT / 3;
+    constexpr i32 EPI3 = -28378;
+    for (int idx = lane; idx < CNT; idx += 64) {
+        int blk = idx / (G * M), r = idx % (G * M);
+        int g = r / M, j = r % M;
+        int2 *f = x + blk * NFFT + g * 3 * M + j;
+        cpx f0 = ld(f);
+        cpx a = c_mul(ld(f + M), tw[j * TWS]);
+        cpx b = c_mul(ld(f + 2 * M), tw[2 * j * TWS]);
+        cpx s3 = c_add(a, b);
+        cpx s0 = c_sub(a, b);
+        cpx f1{sub32(f0.r, s3.r >> 1), sub32(f0.i, s3.i >> 1)};
+        s0.r = CA_SMUL(s0.r, EPI3);
+        s0.i = CA_SMUL(s0.i, EPI3);
+        st(f, c_add(f0, s3));
+        st(f + 2 * M, cpx{add32(f1.r, s0.i), sub32(f1.i, s0.r)});
+        st(f + M, cpx{sub32(f1.r, s0.i), add32(f1.i, s0.r)});
+    }
+}
+
+template <int NFFT, int B, int M>
+CA_DEV void fft_radix5(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:245-322
+{
+    constexpr int G = NFFT / (5 * M);
+    constexpr int TWS = G * (480 / NFFT);
+    constexpr int CNT = B * NFFT / 5;
+    constexpr i32 YAR = 10126, YAI = -31164, YBR = -26510, YBI = -19261;
+    for (int idx = lane; idx < CNT; idx += 64) {
+        int blk = idx / (G * M), r = idx % (G * M);
+        int g = r / M, u = r % M;
+        int2 *f = x + blk * NFFT + g * 5 * M + u;
+        cpx s0 = ld(f);
+        cpx s1 = c_mul(ld(f + M), tw[u * TWS]);
+        cpx s2 = c_mul(ld(f + 2 * M), tw[2 * u * TWS]);
+        cpx s3 = c_mul(ld(f + 3 * M), tw[3 * u * TWS]);
+        cpx s4 = c_mul(ld(f + 4 * M), tw[4 * u * TWS]);
+        cpx s7 = c_add(s1, s4), s10 = c_sub(s1, s4);
+        cpx s8 = c_add(s2, s3), s9 = c_sub(s2, s3);
+        st(f, cpx{add32(s0.r, add32(s7.r, s8.r)), add32(s0.i, add32(s7.i, s8.i))});
+        cpx s5, s6, s11, s12;
+        s5.r = add32(add32(s0.r, CA_SMUL(s7.r, YAR)), CA_SMUL(s8.r, YBR));
+        s5.i = add32(add32(s0.i, CA_SMUL(s7.i, YAR)), CA_SMUL(s8.i, YBR));
+        s6.r = add32(CA_SMUL(s10.i, YAI), CA_SMUL(s9.i, YBI));
+        s6.i = sub32(neg32(CA_SMUL(s10.r, YAI)), CA_SMUL(s9.r, YBI));
+        st(f + M, c_sub(s5, s6));
+        st(f + 4 * M, c_add(s5, s6));
+        s11.r = add32(add32(s0.r, CA_SMUL(s7.r, YBR)), CA_SMUL(s8.r, YAR));
+        s11.i = add32(add32(s0.i, CA_SMUL(s7.i, YBR)), CA_SMUL(s8.i, YAR));
+        s12.r = add32(neg32(CA_SMUL(s10.i, YBI)), CA_SMUL(s9.i, YAI));
+        s12.i = sub32(CA_SMUL(s10.r, YBI), CA_SMUL(s9.r, YAI));
+        st(f + 2 * M, c_add(s11, s12));
+        st(f + 3 * M, c_sub(s11, s12));
+    }
+}
+
+// In-place FFT of B blocks of (480 >> SHIFT) bit-reversed points (opus_fft_impl, kiss_fft.c:532-578).
+template <int SHIFT, int B>
+CA_DEV void fft_wave(int2 *x, const u32 *tw, int lane)
+{
+    constexpr int NFFT = 480 >> SHIFT;
+    fft_radix4_first<NFFT, B>(x, lane);
+    wave_sync();
+    if constexpr (SHIFT == 0) {
+        fft_radix2_m4<NFFT, B>(x, lane);        wave_sync();
+        fft_radix4<NFFT, B, 8>(x, tw, lane);    wave_sync();
+        fft_radix3<NFFT, B, 32>(x, tw, lane);   wave_sync();
+        fft_radix5<NFFT, B, 96>(x, tw, lane);   wave_sync();
+    } else if constexpr (SHIFT == 1) {
+        fft_radix4<NFFT, B, 4>(x, tw, lane);    wave_sync();
+        fft_radix3<NFFT, B, 16>(x, tw, lane);   wave_sync();
+        fft_radix5<NFFT, B, 48>(x, tw, lane);   wave_sync();
+    } else if constexpr (SHIFT == 2) {
+        fft_radix2_m4<NFFT, B>(x, lane);        wave_sync();
+        fft_radix3<NFFT, B, 8>(x, tw, lane);    wave_sync();
+        fft_radix5<NFFT, B, 24>(x, tw, lane);   wave_sync();
+    } else {
+        fft_radix3<NFFT, B, 4>(x, tw, lane);    wave_sync();
+        fft_radix5<NFFT, B, 12>(x, tw, lane);   wave_sync();
+    }
+}
+
+// ---- MDCT ------------------------------------------------------------------------------------------
+// Forward MDCT of B blocks (hop N2, block b reads sin[b*N2 .. b*N2+N2+120)); coefficient k of block b
+// goes to dst[(k*B + b) * dstride] -- the interleaved layout of compute_mdcts (celt_encoder.c:441).
+// trig/bitrev are the packed LDS tables for this SHIFT. dst may be LDS or global; it may alias sin
+// (all reads of sin complete before the first write to dst).      Reference: mdct.c:121-259.
+template <int SHIFT, int B>
+CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, const MdctLds &L,
+                              const u32 *trig, const u16 *bitrev, int lane)
+{
+    constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
+    constexpr int OV = 120, OV2 = 60, Q = 30;
+    constexpr int SCALE_SHIFT = (8 - SHIFT) - 1;                     // st->scale_shift - 1
+    for (int idx = lane; idx < B * N4; idx += 64) {
+        int blk = idx / N4, i = idx % N4;
+        const i32 *in = sin + blk * N2;
+        int a = OV2 + 2 * i, b = N2 - 1 + OV2 - 2 * i;
+        i32 re, im;
+        if (i < Q) {                                                  // mdct.c:162-175
+            i32 w1 = L.window[OV2 + 2 * i], w2 = L.window[OV2 - 1 - 2 * i];
+            re = add32(mul16_32_q15(w2, in[a + N2]), mul16_32_q15(w1, in[b]));
+            im = sub32(mul16_32_q15(w1, in[a]), mul16_32_q15(w2, in[b - N2]));
+        } else if (i < N4 - Q) {                                      // mdct.c:178-189
+            re = in[b];
+            im = in[a];
+        } else {                                                      // mdct.c:190-203
+            int k = i - (N4 - Q);
+            i32 w1 = L.window[2 * k], w2 = L.window[OV - 1 - 2 * k];
+            re = add32(neg32(mul16_32_q15(w1, in[a - N2])), mul16_32_q15(w2, in[b]));
+            im = add32(mul16_32_q15(w2, in[a]), mul16_32_q15(w1, in[b + N2]));
+        }
+        u32 t = trig[i];                                              // mdct.c:206-231
+        i32 t0 = lo16(t), t1 = hi16(t);
+        i32 yr = sub32(CA_SMUL(re, t0), CA_SMUL(im, t1));
+        i32 yi = add32(CA_SMUL(im, t0), CA_SMUL(re, t1));
+        yr = pshr32(mul16_32_q16(17476, yr), SCALE_SHIFT);
+        yi = pshr32(mul16_32_q16(17476, yi), SCALE_SHIFT);
+        f2[blk * NFFT + bitrev[i]] = make_int2(yr, yi);
+    }
+    wave_sync();
+    fft_wave<SHIFT, B>(f2, L.tw, lane);
+    for (int idx = lane; idx < B * N4; idx += 64) {                  // mdct.c:237-257
+        int blk = idx / N4, i = idx % N4;
+        cpx f = ld(f2 + blk * NFFT + i);
+        u32 t = trig[i];
+        i32 t0 = lo16(t), t1 = hi16(t);
+        dst[((2 * i) * B + blk) * dstride] = sub32(CA_SMUL(f.i, t1), CA_SMUL(f.r, t0));
+        dst[((N2 - 1 - 2 * i) * B + blk) * dstride] = add32(CA_SMUL(f.r, t1), CA_SMUL(f.i, t0));
+    }
+    wave_sync();
+}
+
+// Inverse MDCT of B blocks. Coefficient k of block b is src[(k*B + b) * sstride]; block b produces
+// out[b*N2 + 60 .. b*N2 + 60 + N2) and TDAC-mixes out[b*N2 .. b*N2+120) (the first 60 samples of
+// block 0 are the previous frame's tail). src must not alias out.    Reference: mdct.c:263-363.
+template <int SHIFT, int B>
+CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, const MdctLds &L,
+                               const u32 *trig, const u16 *bitrev, int lane)
+{
+    constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
+    constexpr int OV = 120, OV2 = 60;
+    for (int idx = lane; idx < B * N4; idx += 64) {                  // mdct.c:283-304
+        int blk = idx / N4, i = idx % N4;
+        i32 x1 = src[((2 * i) * B + blk) * sstride];
+        i32 x2 = src[((N2 - 1 - 2 * i) * B + blk) * sstride];
+        u32 t = trig[i];
+        i32 t0 = lo16(t), t1 = hi16(t);
+        i32 yr = add32(CA_SMUL(x2, t0), CA_SMUL(x1, t1));
+        i32 yi = sub32(CA_SMUL(x1, t0), CA_SMUL(x2, t1));
+        f2[blk * NFFT + bitrev[i]] = make_int2(yi, yr);              // re/im swapped: FFT as IFFT
+    }
+    wave_sync();
+    fft_wave<SHIFT, B>(f2, L.tw, lane);
+    // post-rotate + de-shuffle (mdct.c:310-342). The reference walks the buffer from both ends in
+    // place; element k always lands as y[2k] = yr(k), y[2(N4-1-k)+1] = yi(k) with twiddles
+    // trig[k], trig[N4+k], which is what each lane computes here.
+    for (int idx = lane; idx < B * N4; idx += 64) {
+        int blk = idx / N4, k = idx % N4;
+        cpx f = ld(f2 + blk * NFFT + k);
+        i32 re = f.i, im = f.r;
+        u32 t = trig[k];
+        i32 t0 = lo16(t), t1 = hi16(t);
+        i32 *y = out + blk * N2 + OV2;
+        y[2 * k] = add32(CA_SMUL(re, t0), CA_SMUL(im, t1));
+        y[2 * (N4 - 1 - k) + 1] = sub32(CA_SMUL(re, t1), CA_SMUL(im, t0));
+    }
+    wave_sync();
+    for (int idx = lane; idx < B * OV2; idx += 64) {                 // mdct.c:345-361 TDAC mirror
+        int blk = idx / OV2, i = idx % OV2;
+        i32 *o = out + blk * N2;
+        i32 x1 = o[OV - 1 - i], x2 = o[i];
+        i32 w1 = L.window[i], w2 = L.window[OV - 1 - i];
+        o[i] = sub32(mul16_32_q15(w2, x2), mul16_32_q15(w1, x1));
+        o[OV - 1 - i] = add32(mul16_32_q15(w1, x2), mul16_32_q15(w2, x1));
+    }
+    wave_sync();
+}
+
+}  // namespace ca

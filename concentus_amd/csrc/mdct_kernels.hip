@@ -1,0 +1,206 @@
+// mdct_kernels.hip -- batched CELT MDCT forward / backward for gfx950 (BASELINE config #2).
+//
+// One 64-lane wavefront per (frame, channel) transform; workgroup = one wave; the grid is persistent
+// (grid-stride over transforms) so the LDS table staging is paid once per workgroup.
+// Data path per transform:  HBM --16 B/lane coalesced--> LDS --fold/rotate/FFT in LDS--> LDS --16 B/lane--> HBM.
+//
+// Replaces clt_mdct_forward_c / clt_mdct_backward_c (opus-fix/celt/mdct.c:121,263) as driven by
+// compute_mdcts (celt/celt_encoder.c:418-461) and celt_synthesis (celt/celt_decoder.c:323-346).
+#include "mdct_dev.h"
+#include "opusgpu_internal.h"
+
+namespace ca {
+
+struct __align__(16) MdctFwdLds {
+    MdctLds tab;
+    __align__(16) i32 buf[1080];      // input samples; re-used as the 960 output coefficients
+    __align__(16) int2 f2[480];
+};
+
+template <int SHIFT>
+__global__ __launch_bounds__(64) void mdct_forward_kernel(const i32 *__restrict__ sig, i32 *__restrict__ freq,
+                                                          int ntransforms)
+{
+    constexpr int B = 1 << SHIFT;
+    __shared__ MdctFwdLds S;
+    const int lane = threadIdx.x;
+    mdct_stage_common(S.tab, lane, 64);
+    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    wave_sync();
+    for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
+        const int4 *src = reinterpret_cast<const int4 *>(sig + (size_t)t * 1080);
+        int4 *b4 = reinterpret_cast<int4 *>(S.buf);
+        for (int i = lane; i < 270; i += 64) b4[i] = src[i];
+        wave_sync();
+        mdct_forward_wave<SHIFT, B>(S.buf, S.f2, S.buf, 1, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+        int4 *dst = reinterpret_cast<int4 *>(freq + (size_t)t * 960);
+        for (int i = lane; i < 240; i += 64) dst[i] = b4[i];
+        wave_sync();
+    }
+}
+
+struct __align__(16) MdctBwdLds {
+    MdctLds tab;
+    __align__(16) i32 coef[960];
+    __align__(16) i32 out[1080];
+    __align__(16) int2 f2[480];
+};
+
+template <int SHIFT>
+__global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *__restrict__ sig,
+                                                           int ntransforms)
+{
+    constexpr int B = 1 << SHIFT;
+    __shared__ MdctBwdLds S;
+    const int lane = threadIdx.x;
+    mdct_stage_common(S.tab, lane, 64);
+    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    wave_sync();
+    for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
+        const int4 *src = reinterpret_cast<const int4 *>(freq + (size_t)t * 960);
+        int4 *c4 = reinterpret_cast<int4 *>(S.coef);
+        for (int i = lane; i < 240; i += 64) c4[i] = src[i];
+        // only the first 60 samples (previous tail) are live on entry (mdct.c:345-361)
+        int4 *io = reinterpret_cast<int4 *>(sig + (size_t)t * 1080);
+        int4 *o4 = reinterpret_cast<int4 *>(S.out);
+        if (lane < 15) o4[lane] = io[lane];
+        wave_sync();
+        mdct_backward_wave<SHIFT, B>(S.coef, 1, S.f2, S.out, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+        for (int i = lane; i < 255; i += 64) io[i] = o4[i];      // 1020 samples; [1020,1080) untouched
+        wave_sync();
+    }
+}
+
+// Single transform with an arbitrary output/input stride, for the per-call RTCD-style hook.
+template <int SHIFT>
+__global__ __launch_bounds__(64) void mdct_forward_single_kernel(const i32 *in, i32 *out, int stride)
+{
+    __shared__ MdctFwdLds S;
+    const int lane = threadIdx.x;
+    constexpr int N2 = 960 >> SHIFT;
+    mdct_stage_common(S.tab, lane, 64);
+    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    for (int i = lane; i < N2 + 120; i += 64) S.buf[i] = in[i];
+    wave_sync();
+    mdct_forward_wave<SHIFT, 1>(S.buf, S.f2, out, stride, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+}
+
+template <int SHIFT>
+__global__ __launch_bounds__(64) void mdct_backward_single_kernel(const i32 *in, i32 *out, int stride)
+{
+    __shared__ MdctBwdLds S;
+    const int lane = threadIdx.x;
+    constexpr int N2 = 960 >> SHIFT;
+    mdct_stage_common(S.tab, lane, 64);
+    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    for (int i = lane; i < N2; i += 64) S.coef[i] = in[i * stride];
+    for (int i = lane; i < 120; i += 64) S.out[i] = out[i];
+    wave_sync();
+    mdct_backward_wave<SHIFT, 1>(S.coef, 1, S.f2, S.out, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+    for (int i = lane; i < N2 + 60; i += 64) out[i] = S.out[i];
+}
+
+static int grid_for(int ntransforms, int waves_per_cu)
+{
+    int cap = opusgpu_num_cus() * waves_per_cu;
+    return ntransforms < cap ? ntransforms : cap;
+}
+
+}  // namespace ca
+
+using namespace ca;
+
+extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq, int n_frames, int channels,
+                                          int shift, void *stream)
+{
+    if (!d_sig || !d_freq || n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (shift != 0 && shift != 3) return OPUSGPU_UNIMPLEMENTED;    // 20 ms frames: long or 8 short blocks
+    int nt = n_frames * channels;
+    if (nt == 0) return OPUSGPU_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = grid_for(nt, 12);
+    if (shift == 0) hipLaunchKernelGGL(mdct_forward_kernel<0>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    else            hipLaunchKernelGGL(mdct_forward_kernel<3>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    return opusgpu_check_launch();
+}
+
+extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig, int n_frames, int channels,
+                                           int shift, void *stream)
+{
+    if (!d_sig || !d_freq || n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (shift != 0 && shift != 3) return OPUSGPU_UNIMPLEMENTED;
+    int nt = n_frames * channels;
+    if (nt == 0) return OPUSGPU_OK;
+    hipStream_t s = (hipStream_t)stream;
+    int grid = grid_for(nt, 10);
+    if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    else            hipLaunchKernelGGL(mdct_backward_kernel<3>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    return opusgpu_check_launch();
+}
+
+// ---- per-call hooks with the reference's own signature (host pointers) ---------------------------
+// Same argument list as clt_mdct_forward_c / clt_mdct_backward_c (celt/mdct.h:77-110). `l`, `window`
+// and `overlap` must describe the static mode (n = 1920, window120, 120); they are validated, not read
+// on the device. Latency-dominated: for plumbing/parity only, throughput comes from the batch API.
+struct ref_mdct_lookup_head { int n; int maxshift; };
+
+static int hook_args_ok(const void *l, const void *window, int overlap, int shift, int stride)
+{
+    if (!l || !window || overlap != 120 || shift < 0 || shift > 3 || stride < 1) return 0;
+    const ref_mdct_lookup_head *h = (const ref_mdct_lookup_head *)l;
+    return h->n == 1920 && h->maxshift == 3;
+}
+
+extern "C" void opusgpu_clt_mdct_forward(const void *l, int32_t *in, int32_t *out, const int16_t *window,
+                                         int overlap, int shift, int stride, int arch)
+{
+    (void)arch;
+    if (!hook_args_ok(l, window, overlap, shift, stride)) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+    const int n2 = 960 >> shift;
+    const size_t in_bytes = (size_t)(n2 + 120) * 4, out_elems = (size_t)(n2 - 1) * stride + 1;
+    int32_t *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, in_bytes) != hipSuccess || hipMalloc(&d_out, out_elems * 4) != hipSuccess) {
+        opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL);
+        if (d_in) (void)hipFree(d_in);
+        return;
+    }
+    (void)hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_out, out, out_elems * 4, hipMemcpyHostToDevice);   // keep the gaps when stride > 1
+    switch (shift) {
+    case 0: hipLaunchKernelGGL(mdct_forward_single_kernel<0>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    case 1: hipLaunchKernelGGL(mdct_forward_single_kernel<1>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    case 2: hipLaunchKernelGGL(mdct_forward_single_kernel<2>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    default: hipLaunchKernelGGL(mdct_forward_single_kernel<3>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    }
+    opusgpu_set_last_error(opusgpu_check_launch());
+    (void)hipMemcpy(out, d_out, out_elems * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+}
+
+extern "C" void opusgpu_clt_mdct_backward(const void *l, int32_t *in, int32_t *out, const int16_t *window,
+                                          int overlap, int shift, int stride, int arch)
+{
+    (void)arch;
+    if (!hook_args_ok(l, window, overlap, shift, stride)) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+    const int n2 = 960 >> shift;
+    const size_t in_elems = (size_t)(n2 - 1) * stride + 1, out_bytes = (size_t)(n2 + 120) * 4;
+    int32_t *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, in_elems * 4) != hipSuccess || hipMalloc(&d_out, out_bytes) != hipSuccess) {
+        opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL);
+        if (d_in) (void)hipFree(d_in);
+        return;
+    }
+    (void)hipMemcpy(d_in, in, in_elems * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_out, out, out_bytes, hipMemcpyHostToDevice);
+    switch (shift) {
+    case 0: hipLaunchKernelGGL(mdct_backward_single_kernel<0>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    case 1: hipLaunchKernelGGL(mdct_backward_single_kernel<1>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    case 2: hipLaunchKernelGGL(mdct_backward_single_kernel<2>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    default: hipLaunchKernelGGL(mdct_backward_single_kernel<3>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
+    }
+    opusgpu_set_last_error(opusgpu_check_launch());
+    (void)hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+}

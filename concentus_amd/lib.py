@@ -1,0 +1,63 @@
+"""ctypes binding of libopusgpu.so (the C-ABI declared in include/opusgpu.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C concentus_amd/csrc`.
+Loading fails loudly: there is no fallback path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopusgpu.so")
+
+# every symbol include/opusgpu.h declares: (name, restype, argtypes)
+_vp, _i = C.c_void_p, C.c_int
+SYMBOLS = [
+    ("opusgpu_get_version_string", C.c_char_p, []),
+    ("opusgpu_strerror", C.c_char_p, [_i]),
+    ("opusgpu_get_last_error", _i, []),
+    ("opusgpu_num_cus", _i, []),
+    ("opusgpu_mdct_forward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
+    ("opusgpu_mdct_backward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
+    ("opusgpu_clt_mdct_forward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    ("opusgpu_clt_mdct_backward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+]
+
+_lib = None
+
+
+class OpusGpuError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__("%s: %s (%d)" % (where, strerror(code), code))
+
+
+def load():
+    """Return the loaded library, raising if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "concentus_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C concentus_amd/csrc` (no CPU fallback exists)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def strerror(code):
+    return load().opusgpu_strerror(code).decode()
+
+
+def check(code, where):
+    if code < 0:
+        raise OpusGpuError(code, where)
+    return code
+
+
+def current_stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

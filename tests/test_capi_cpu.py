@@ -1,0 +1,55 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/opusgpu.h declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "opusgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(opusgpu_\w+)\s*\(", src)))
+
+
+def _ensure_built():
+    from concentus_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return lib
+
+
+def test_header_symbols_all_exported():
+    lib = _ensure_built()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in _declared() if s not in exported]
+    assert not missing, missing
+
+
+def test_python_binding_covers_header():
+    lib = _ensure_built()
+    bound = {name for name, _, _ in lib.SYMBOLS}
+    assert set(_declared()) == bound
+    lib.load()  # resolves every symbol via ctypes; raises AttributeError if one is absent
+
+
+def test_strerror_and_version_without_gpu():
+    lib = _ensure_built()
+    L = lib.load()
+    assert b"gfx950" in L.opusgpu_get_version_string()
+    assert lib.strerror(0) == "success"
+    assert lib.strerror(-1) == "invalid argument"
+    assert lib.strerror(-99) == "unknown error"
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from concentus_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        lib.load()
