@@ -48,6 +48,7 @@ def cpu_baseline_mdct(seed_sig):
     or, if that library did not travel, our C restatement (kind "port") on a bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)                    # one GPU's share of the host (the box allots 16 per GPU)
     n = 2048                                  # stereo frames per pass
     sig = np.ascontiguousarray(np.tile(seed_sig, (n // seed_sig.shape[0] + 1, 1, 1))[:n])
     freq = np.zeros((n, 2, 960), np.int32)

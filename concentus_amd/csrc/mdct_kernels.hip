@@ -113,10 +113,12 @@ using namespace ca;
 extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq, int n_frames, int channels,
                                           int shift, void *stream)
 {
-    if (!d_sig || !d_freq || n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (shift < 0 || shift > 3) return OPUSGPU_BAD_ARG;
     if (shift != 0 && shift != 3) return OPUSGPU_UNIMPLEMENTED;    // 20 ms frames: long or 8 short blocks
     int nt = n_frames * channels;
     if (nt == 0) return OPUSGPU_OK;
+    if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = grid_for(nt, 12);
     if (shift == 0) hipLaunchKernelGGL(mdct_forward_kernel<0>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
@@ -127,10 +129,12 @@ extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq,
 extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig, int n_frames, int channels,
                                            int shift, void *stream)
 {
-    if (!d_sig || !d_freq || n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (n_frames < 0 || channels < 1 || channels > 2) return OPUSGPU_BAD_ARG;
+    if (shift < 0 || shift > 3) return OPUSGPU_BAD_ARG;
     if (shift != 0 && shift != 3) return OPUSGPU_UNIMPLEMENTED;
     int nt = n_frames * channels;
     if (nt == 0) return OPUSGPU_OK;
+    if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = grid_for(nt, 10);
     if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
