@@ -1,0 +1,522 @@
+// celt_enc.h -- one Opus CELT-only frame, PCM in -> packet out, by one wavefront.
+//
+// Restates the CELT-only slice of opus_encode_native (opus-fix/src/opus_encoder.c:938-1974: rate
+// bookkeeping :1040-1054 / :1440-1453 / :1716-1770, dc_reject :1473, TOC :1925, final range :1927) and
+// celt_encode_with_ec (opus-fix/celt/celt_encoder.c:1379-2273) for 48 kHz, 20 ms, restricted-lowdelay,
+// fullband; the steps are numbered as in SURVEY.md 3.2.
+#pragma once
+#include "celt_enc_back.h"
+
+namespace ca {
+
+struct FrameResult { int bytes; u32 final_range; };
+
+CA_DEV void load_state(FrameCtx &fc, FrameLds &F, const opusgpu_celt_state *st, int C)
+{
+    fc.C = C;
+    if (st) {
+        for (int k = 0; k < 4; k++) fc.hp_mem[k] = st->hp_mem[k];
+        fc.rng = st->rng;
+        fc.spread_decision = st->spread_decision;
+        fc.delayedIntra = st->delayedIntra;
+        fc.tonal_average = st->tonal_average;
+        fc.lastCodedBands = st->lastCodedBands;
+        fc.hf_average = st->hf_average;
+        fc.tapset_decision = st->tapset_decision;
+        fc.prefilter_period = st->prefilter_period;
+        fc.prefilter_gain = st->prefilter_gain;
+        fc.prefilter_tapset = st->prefilter_tapset;
+        fc.consec_transient = st->consec_transient;
+        fc.preemph_memE[0] = st->preemph_memE[0];
+        fc.preemph_memE[1] = st->preemph_memE[1];
+        fc.vbr_reservoir = st->vbr_reservoir;
+        fc.vbr_drift = st->vbr_drift;
+        fc.vbr_offset = st->vbr_offset;
+        fc.vbr_count = st->vbr_count;
+        fc.overlap_max = st->overlap_max;
+        fc.stereo_saving = st->stereo_saving;
+        fc.intensity = st->intensity;
+        fc.spec_avg = st->spec_avg;
+        fc.hist = st->prefilter_mem;
+        for (int k = lane(); k < 2 * NB; k += LANES) {
+            F.oldBandE[k] = st->oldBandE[k];
+            F.oldLogE[k] = st->oldLogE[k];
+            F.oldLogE2[k] = st->oldLogE2[k];
+        }
+    } else {
+        // OPUS_RESET_STATE (celt_encoder.c:2443-2462) on a zeroed encoder
+        for (int k = 0; k < 4; k++) fc.hp_mem[k] = 0;
+        fc.rng = 0;
+        fc.spread_decision = SPREAD_NORMAL;
+        fc.delayedIntra = 1;
+        fc.tonal_average = 256;
+        fc.lastCodedBands = 0;
+        fc.hf_average = 0;
+        fc.tapset_decision = 0;
+        fc.prefilter_period = 0;
+        fc.prefilter_gain = 0;
+        fc.prefilter_tapset = 0;
+        fc.consec_transient = 0;
+        fc.preemph_memE[0] = fc.preemph_memE[1] = 0;
+        fc.vbr_reservoir = fc.vbr_drift = fc.vbr_offset = fc.vbr_count = 0;
+        fc.overlap_max = 0;
+        fc.stereo_saving = 0;
+        fc.intensity = 0;
+        fc.spec_avg = 0;
+        fc.hist = nullptr;
+        for (int k = lane(); k < 2 * NB; k += LANES) {
+            F.oldBandE[k] = 0;
+            F.oldLogE[k] = -28672;
+            F.oldLogE2[k] = -28672;
+        }
+    }
+    wave_sync();
+}
+
+// Writes the stream state back (st_out may equal the input state: everything read from it -- the
+// prefilter history in particular -- has been consumed by the time this runs).
+CA_DEV void store_state(const FrameCtx &fc, FrameLds &F, opusgpu_celt_state *st, const opusgpu_celt_state *st_in)
+{
+    const int C = fc.C;
+    // prefilter_mem <- last 1024 samples of [history | unfiltered new]  (celt_encoder.c:1179-1187):
+    // new[j] = j < 64 ? old[960 + j] : xf_unfiltered[j - 64]. The unfiltered samples were overwritten by the
+    // MDCT output, so the kernel keeps them in HBM: see celt_encode_frame (hist_new).
+    (void)st_in;
+    if (lane() == 0) {
+        for (int k = 0; k < 4; k++) st->hp_mem[k] = fc.hp_mem[k];
+        st->rng = fc.rng;
+        st->spread_decision = fc.spread_decision;
+        st->delayedIntra = fc.delayedIntra;
+        st->tonal_average = fc.tonal_average;
+        st->lastCodedBands = fc.lastCodedBands;
+        st->hf_average = fc.hf_average;
+        st->tapset_decision = fc.tapset_decision;
+        st->prefilter_period = fc.prefilter_period;
+        st->prefilter_gain = fc.prefilter_gain;
+        st->prefilter_tapset = fc.prefilter_tapset;
+        st->consec_transient = fc.consec_transient;
+        st->preemph_memE[0] = fc.preemph_memE[0];
+        st->preemph_memE[1] = fc.preemph_memE[1];
+        st->vbr_reservoir = fc.vbr_reservoir;
+        st->vbr_drift = fc.vbr_drift;
+        st->vbr_offset = fc.vbr_offset;
+        st->vbr_count = fc.vbr_count;
+        st->overlap_max = fc.overlap_max;
+        st->stereo_saving = fc.stereo_saving;
+        st->intensity = fc.intensity;
+        st->spec_avg = fc.spec_avg;
+    }
+    for (int k = lane(); k < C * NB; k += LANES) {
+        st->oldBandE[k] = F.oldBandE[k];
+        st->oldLogE[k] = F.oldLogE[k];
+        st->oldLogE2[k] = F.oldLogE2[k];
+    }
+}
+
+// One frame. pcm: 960*C interleaved int16 (global). out: packet bytes (global, >= max packet size).
+// st_in == nullptr: independent first frame. st_out may be nullptr (state discarded) or == st_in.
+CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
+                                       opusgpu_celt_state *st_out, const i16 *pcm, u8 *out)
+{
+    const int C = cfg.channels, N = FRAME, LM = LM3, M = M8, end = NB;
+    FrameCtx fc;
+    load_state(fc, F, st_in, C);
+
+    // ---- Opus layer: rate bookkeeping (opus_encoder.c:1040-1054, 1440-1453, 1735-1770, 1873-1876) ----
+    int max_data_bytes = imin(1276, cfg.max_data_bytes);
+    i32 bitrate_bps = cfg.bitrate;
+    if (!cfg.vbr) {
+        int cbrBytes = imin((3 * bitrate_bps / 8 + 150 / 2) / 150, max_data_bytes);
+        bitrate_bps = cbrBytes * 150 * 8 / 3;
+        max_data_bytes = cbrBytes;
+    }
+    const int bytes_target = imin(max_data_bytes, bitrate_bps * N / (48000 * 8)) - 1;
+    int nb_compr_bytes = cfg.vbr ? max_data_bytes - 1 : bytes_target;
+    nb_compr_bytes = imin(max_data_bytes - 1, nb_compr_bytes);
+    // CELT ctl: VBR on -> bitrate = bitrate_bps, else OPUS_BITRATE_MAX (-1) with vbr off (opus_encoder.c:1727-1768)
+    const int celt_vbr = cfg.vbr;
+    const i32 celt_bitrate = cfg.vbr ? bitrate_bps : -1;
+    const int constrained_vbr = cfg.constrained_vbr;
+
+    RangeEnc enc;
+    ec_enc_init(enc, F.packet + 1, (u32)(max_data_bytes - 1));
+    ec_enc_shrink(enc, (u32)nb_compr_bytes);
+
+    // ---- stage PCM, dc_reject (opus_encoder.c:1473) ----
+    {
+        const int4 *src = reinterpret_cast<const int4 *>(pcm);
+        int4 *dst = reinterpret_cast<int4 *>(F.s.raw_pcm);
+        for (int k = lane(); k < (N * C * 2) / 16; k += LANES) dst[k] = src[k];
+    }
+    wave_sync();
+    dc_reject_wave(F, fc);
+    CA_TRACE("dc_reject done");
+
+    // ---- celt_encode_with_ec ----
+    i32 tell = ec_tell(enc);                                   // == 1
+    const int nbFilledBytes = (tell + 4) >> 3;                 // == 0
+    int nbCompressedBytes = imin(nb_compr_bytes, 1275);
+    int nbAvailableBytes = nbCompressedBytes - nbFilledBytes;
+    i32 vbr_rate;
+    int effectiveBytes;
+    if (celt_vbr && celt_bitrate != -1) {
+        i32 den = 48000 >> BITRES;
+        vbr_rate = (celt_bitrate * N + (den >> 1)) / den;
+        effectiveBytes = vbr_rate >> (3 + BITRES);
+    } else {
+        vbr_rate = 0;
+        i32 tmp = celt_bitrate * N;
+        if (tell > 1) tmp += tell;
+        if (celt_bitrate != -1) nbCompressedBytes = imax(2, imin(nbCompressedBytes, (tmp + 4 * 48000) / (8 * 48000)));
+        effectiveBytes = nbCompressedBytes;
+    }
+    i32 equiv_rate = 510000;
+    if (celt_bitrate != -1) equiv_rate = celt_bitrate - (40 * C + 20) * ((400 >> LM) - 50);
+    if (vbr_rate > 0 && constrained_vbr) {
+        i32 vbr_bound = vbr_rate;
+        i32 max_allowed = imin(imax(tell == 1 ? 2 : 0, (vbr_rate + vbr_bound - fc.vbr_reservoir) >> (BITRES + 3)), nbAvailableBytes);
+        if (max_allowed < nbAvailableBytes) {
+            nbCompressedBytes = nbFilledBytes + max_allowed;
+            nbAvailableBytes = max_allowed;
+            ec_enc_shrink(enc, (u32)nbCompressedBytes);
+        }
+    }
+    i32 total_bits = nbCompressedBytes * 8;
+
+    // 2. silence
+    i32 sample_max = imax(fc.overlap_max, maxabs_pcm(F, C, 0, N - OVL));
+    fc.overlap_max = maxabs_pcm(F, C, N - OVL, N);
+    sample_max = imax(sample_max, fc.overlap_max);
+    int silence = sample_max == 0;
+    if (tell == 1) ec_enc_bit_logp(enc, silence, 15);
+    else silence = 0;
+    if (silence) {
+        if (vbr_rate > 0) {
+            effectiveBytes = nbCompressedBytes = imin(nbCompressedBytes, nbFilledBytes + 2);
+            total_bits = nbCompressedBytes * 8;
+            nbAvailableBytes = 2;
+            ec_enc_shrink(enc, (u32)nbCompressedBytes);
+        }
+        tell = nbCompressedBytes * 8;
+        enc.nbits_total += tell - ec_tell(enc);
+    }
+
+    // 3. pre-emphasis
+    preemphasis_wave(F, fc);
+    CA_TAP("in_preemph", F.in, sizeof(F.in));
+    CA_TRACE("preemph done");
+
+    // 4. pitch pre-filter
+    int pitch_index, pf_on, prefilter_tapset;
+    i32 gain1;
+    {
+        const int enabled = (nbAvailableBytes > 12 * C) && !silence && cfg.complexity >= 5;
+        prefilter_tapset = fc.tapset_decision;
+        PrefilterOut po = run_prefilter_wave(F, fc, st_in ? st_in->in_mem : nullptr, prefilter_tapset, enabled,
+                                             nbAvailableBytes, cfg.loss_rate);
+        pitch_index = po.pitch_index;
+        gain1 = po.gain1;
+        pf_on = po.pf_on;
+        if (pf_on == 0) {
+            if (tell + 16 <= total_bits) ec_enc_bit_logp(enc, 0, 1);
+        } else {
+            ec_enc_bit_logp(enc, 1, 1);
+            pitch_index += 1;
+            int octave = ec_ilog((u32)pitch_index) - 5;
+            ec_enc_uint(enc, (u32)octave, 6);
+            ec_enc_bits(enc, (u32)(pitch_index - (16 << octave)), (u32)(4 + octave));
+            pitch_index -= 1;
+            ec_enc_bits(enc, (u32)po.qg, 3);
+            ec_enc_icdf(enc, prefilter_tapset, CLT_tapset_icdf, 2);
+        }
+    }
+    // stream state that depends on the (still live) unfiltered / filtered time signal
+    if (st_out) {
+        for (int c = 0; c < C; c++) {
+            for (int i = lane(); i < OVL; i += LANES) st_out->in_mem[c * OVL + i] = F.in[c][N + i];
+            // prefilter_mem <- last 1024 of [history | new]; new[j] = j<64 ? old[960+j] : unfiltered[j-64].
+            // In-place safe: element j (>= 64) no longer depends on the old array, element j < 64 reads old[960+j]
+            // which only lanes handling j' = 960+j >= 64 overwrite -> read everything first.
+            i32 *keep = F.s.pitch.xcorr;                     // pitch scratch is dead by now
+            for (int j = lane(); j < MAXP - FRAME; j += LANES) keep[j] = fc.hist ? fc.hist[c * MAXP + FRAME + j] : 0;
+            wave_sync();
+            for (int j = lane(); j < MAXP; j += LANES)
+                st_out->prefilter_mem[c * MAXP + j] = j < MAXP - FRAME ? keep[j] : F.xf[c][j - (MAXP - FRAME)];
+            wave_sync();
+        }
+    }
+    wave_sync();
+
+    CA_TRACE("prefilter done pitch=%d gain=%d pf_on=%d", pitch_index, gain1, pf_on); CA_TRACE("");
+    CA_TAP("in_filtered", F.in, sizeof(F.in));
+    // 5. transient analysis
+    int isTransient = 0, shortBlocks = 0, tf_chan = 0, transient_got_disabled = 0;
+    i32 tf_estimate = 0;
+    if (cfg.complexity >= 1) {
+        TransientOut to = transient_analysis_wave(F, fc);
+        isTransient = to.is_transient;
+        tf_estimate = to.tf_estimate;
+        tf_chan = to.tf_chan;
+    }
+    if (ec_tell(enc) + 3 <= total_bits) {
+        if (isTransient) shortBlocks = M;
+    } else {
+        isTransient = 0;
+        transient_got_disabled = 1;
+    }
+
+    CA_TRACE("transient done isT=%d tf_est=%d", isTransient, tf_estimate); CA_TRACE("");
+    // 6./7./8. MDCT + band energies
+    const int secondMdct = shortBlocks && cfg.complexity >= 8;
+    if (secondMdct) {
+        compute_mdcts_wave(F, fc, 0);
+        band_energies_wave(F, fc, F.bandLogE2);
+        for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
+        wave_sync();
+    }
+    compute_mdcts_wave(F, fc, shortBlocks);
+    band_energies_wave(F, fc, F.bandLogE);
+
+    CA_TAP("freq", F.xf, sizeof(F.xf)); CA_TAP("bandE", F.bandE, sizeof(F.bandE)); CA_TAP("bandLogE", F.bandLogE, sizeof(F.bandLogE));
+    // 9. temporal VBR, transient patch
+    i32 temporal_vbr;
+    {
+        i32 follow = -10240;
+        i32 frame_avg = 0;
+        i32 offset = shortBlocks ? (shl16(LM, 10) >> 1) : 0;
+        for (int i = 0; i < end; i++) {
+            follow = (i16)imax(follow - 1024, F.bandLogE[i] - offset);
+            if (C == 2) follow = (i16)imax(follow, F.bandLogE[i + NB] - offset);
+            frame_avg += follow;
+        }
+        frame_avg /= end;
+        temporal_vbr = (i16)sub16(frame_avg, fc.spec_avg);
+        temporal_vbr = imin(3072, imax(-1536, temporal_vbr));
+        fc.spec_avg = (i16)(fc.spec_avg + mul16_16_q15(655, temporal_vbr));
+    }
+    if (!secondMdct) {
+        for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = F.bandLogE[k];
+        wave_sync();
+    }
+    if (ec_tell(enc) + 3 <= total_bits && !isTransient && cfg.complexity >= 5) {
+        // patch_transient_decision (celt_encoder.c:380-416)
+        i32 spread_old[NB];
+        if (C == 1) {
+            spread_old[0] = F.oldBandE[0];
+            for (int i = 1; i < end; i++) spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, F.oldBandE[i]);
+        } else {
+            spread_old[0] = imax(F.oldBandE[0], F.oldBandE[NB]);
+            for (int i = 1; i < end; i++)
+                spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, imax(F.oldBandE[i], F.oldBandE[i + NB]));
+        }
+        for (int i = end - 2; i >= 0; i--) spread_old[i] = (i16)imax(spread_old[i], spread_old[i + 1] - 1024);
+        i32 mean_diff = 0;
+        for (int c = 0; c < C; c++)
+            for (int i = 2; i < end - 1; i++) {
+                i32 x1 = imax(0, F.bandLogE[i + c * NB]), x2 = imax(0, spread_old[i]);
+                mean_diff = add32(mean_diff, imax(0, sub16(x1, x2)));
+            }
+        mean_diff = mean_diff / (C * (end - 1 - 2));
+        if (mean_diff > 1024) {
+            isTransient = 1;
+            shortBlocks = M;
+            compute_mdcts_wave(F, fc, shortBlocks);
+            band_energies_wave(F, fc, F.bandLogE);
+            for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
+            wave_sync();
+            tf_estimate = 3277;                                  // QCONST16(.2f,14)
+        }
+    }
+    if (ec_tell(enc) + 3 <= total_bits) ec_enc_bit_logp(enc, isTransient, 3);
+
+    CA_TRACE("energies done");
+    // 10. normalise
+    normalise_bands_wave(F, fc);
+
+    CA_TAP("X", F.in, 2 * FRAME * 2);
+    // 11. TF resolution
+    int tf_select;
+    if (effectiveBytes >= 15 * C && cfg.complexity >= 2) {
+        int lambda;
+        if (effectiveBytes < 40) lambda = 12;
+        else if (effectiveBytes < 60) lambda = 6;
+        else if (effectiveBytes < 100) lambda = 4;
+        else lambda = 3;
+        lambda *= 2;
+        tf_select = tf_analysis_wave(F, isTransient, lambda, tf_estimate, tf_chan);
+    } else {
+        for (int i = lane(); i < end; i += LANES) F.tf_res[i] = isTransient;
+        wave_sync();
+        tf_select = 0;
+    }
+
+    CA_TRACE("tf done tf_select=%d", tf_select); CA_TRACE("");
+    // 12. coarse energy
+    quant_coarse_energy_wave(F, fc, enc, (u32)total_bits, nbAvailableBytes, cfg.complexity >= 4, cfg.loss_rate);
+
+    CA_TRACE("coarse done tell=%d", ec_tell(enc)); CA_TRACE("");
+    CA_TAP("oldBandE_after_coarse", F.oldBandE, sizeof(F.oldBandE)); CA_TAP("error", F.error, sizeof(F.error));
+    // 13. tf_encode, spread, dynalloc, trim
+    tf_encode_wave(F, enc, isTransient, tf_select);
+    if (ec_tell(enc) + 4 <= total_bits) {
+        if (shortBlocks || cfg.complexity < 3 || nbAvailableBytes < 10 * C) {
+            fc.spread_decision = cfg.complexity == 0 ? SPREAD_NONE : SPREAD_NORMAL;
+        } else {
+            fc.spread_decision = spreading_decision_wave(F, fc, pf_on && !shortBlocks);
+        }
+        ec_enc_icdf(enc, fc.spread_decision, CLT_spread_icdf, 5);
+    }
+    i32 tot_boost;
+    const i32 maxDepth = dynalloc_analysis_wave(F, fc, cfg.lsb_depth, isTransient, celt_vbr, constrained_vbr,
+                                                effectiveBytes, &tot_boost);
+    for (int i = lane(); i < NB; i += LANES) {                                     // init_caps (celt.c:246-256)
+        int Nb = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
+        F.cap[i] = ((CLT_cache_caps50[NB * (2 * LM + C - 1) + i] + 64) * C * Nb) >> 2;
+    }
+    wave_sync();
+    int dynalloc_logp = 6;
+    total_bits <<= BITRES;
+    i32 total_boost = 0;
+    tell = (i32)ec_tell_frac(enc);
+    for (int i = 0; i < end; i++) {
+        int width = (C * (CLT_eband5ms[i + 1] - CLT_eband5ms[i])) << LM;
+        int quanta = imin(width << BITRES, imax(6 << BITRES, width));
+        int dynalloc_loop_logp = dynalloc_logp;
+        int boost = 0, j;
+        const int off_i = F.offsets[i], cap_i = F.cap[i];
+        for (j = 0; tell + (dynalloc_loop_logp << BITRES) < total_bits - total_boost && boost < cap_i; j++) {
+            int flag = j < off_i;
+            ec_enc_bit_logp(enc, flag, (u32)dynalloc_loop_logp);
+            tell = (i32)ec_tell_frac(enc);
+            if (!flag) break;
+            boost += quanta;
+            total_boost += quanta;
+            dynalloc_loop_logp = 1;
+        }
+        if (j) dynalloc_logp = imax(2, dynalloc_logp - 1);
+        st0(&F.offsets[i], boost);
+    }
+    wave_sync();
+    int dual_stereo = 0;
+    if (C == 2) {
+        dual_stereo = stereo_analysis_wave(F);
+        fc.intensity = hysteresis_decision((i16)(equiv_rate / 1000), CLT_intensity_thresholds, CLT_intensity_histeresis, 21, fc.intensity);
+        fc.intensity = imin(end, imax(0, fc.intensity));
+    }
+    int alloc_trim = 5;
+    if (tell + (6 << BITRES) <= total_bits - total_boost) {
+        alloc_trim = alloc_trim_analysis_wave(F, fc, tf_estimate, fc.intensity);
+        ec_enc_icdf(enc, alloc_trim, CLT_trim_icdf, 7);
+        tell = (i32)ec_tell_frac(enc);
+    }
+
+    CA_TRACE("trim done alloc_trim=%d tell=%d", alloc_trim, tell); CA_TRACE("");
+    // 14. VBR target (celt_encoder.c:2002-2087)
+    if (vbr_rate > 0) {
+        const int lm_diff = 3 - LM;
+        nbCompressedBytes = imin(nbCompressedBytes, 1275 >> (3 - LM));
+        i32 base_target = vbr_rate - ((40 * C + 20) << BITRES);
+        if (constrained_vbr) base_target += (fc.vbr_offset >> lm_diff);
+        i32 target = compute_vbr_wave(fc, base_target, equiv_rate, constrained_vbr, tot_boost, tf_estimate, maxDepth, temporal_vbr);
+        target = target + tell;
+        i32 min_allowed = ((tell + total_boost + (1 << (BITRES + 3)) - 1) >> (BITRES + 3)) + 2 - nbFilledBytes;
+        nbAvailableBytes = (target + (1 << (BITRES + 2))) >> (BITRES + 3);
+        nbAvailableBytes = imax(min_allowed, nbAvailableBytes);
+        nbAvailableBytes = imin(nbCompressedBytes, nbAvailableBytes + nbFilledBytes) - nbFilledBytes;
+        i32 delta = target - vbr_rate;
+        target = nbAvailableBytes << (BITRES + 3);
+        if (silence) {
+            nbAvailableBytes = 2;
+            target = (2 * 8) << BITRES;
+            delta = 0;
+        }
+        i32 alpha;
+        if (fc.vbr_count < 970) {
+            fc.vbr_count++;
+            alpha = (i16)celt_rcp(shl32(fc.vbr_count + 20, 16));
+        } else {
+            alpha = 33;                                                             // QCONST16(.001f,15)
+        }
+        if (constrained_vbr) fc.vbr_reservoir += target - vbr_rate;
+        if (constrained_vbr) {
+            fc.vbr_drift += mul16_32_q15(alpha, (delta * (1 << lm_diff)) - fc.vbr_offset - fc.vbr_drift);
+            fc.vbr_offset = -fc.vbr_drift;
+        }
+        if (constrained_vbr && fc.vbr_reservoir < 0) {
+            int adjust = (-fc.vbr_reservoir) / (8 << BITRES);
+            nbAvailableBytes += silence ? 0 : adjust;
+            fc.vbr_reservoir = 0;
+        }
+        nbCompressedBytes = imin(nbCompressedBytes, nbAvailableBytes + nbFilledBytes);
+        ec_enc_shrink(enc, (u32)nbCompressedBytes);
+        wave_sync();
+    }
+
+    CA_TRACE("vbr done nbCompressedBytes=%d", nbCompressedBytes); CA_TRACE("");
+    // 15. allocation
+    i32 bits = (((i32)nbCompressedBytes * 8) << BITRES) - (i32)ec_tell_frac(enc) - 1;
+    const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
+    bits -= anti_collapse_rsv;
+    const int signalBandwidth = end - 1;
+    AllocOut ao = compute_allocation_wave(F, enc, C, alloc_trim, fc.intensity, dual_stereo, bits, fc.lastCodedBands, signalBandwidth);
+    fc.intensity = ao.intensity;
+    dual_stereo = ao.dual_stereo;
+    const int codedBands = ao.codedBands;
+    if (fc.lastCodedBands) fc.lastCodedBands = imin(fc.lastCodedBands + 1, imax(fc.lastCodedBands - 1, codedBands));
+    else fc.lastCodedBands = codedBands;
+
+    CA_TRACE("alloc done codedBands=%d", codedBands); CA_TRACE("");
+    CA_TAP("pulses", F.pulses, sizeof(F.pulses)); CA_TAP("fine_quant", F.fine_quant, sizeof(F.fine_quant)); CA_TAP("tf_res", F.tf_res, sizeof(F.tf_res));
+    // 16. fine energy
+    quant_fine_energy_wave(F, enc, C);
+
+    // 17. PVQ
+    quant_all_bands_wave(F, enc, C, shortBlocks, fc.spread_decision, dual_stereo, fc.intensity,
+                         nbCompressedBytes * (8 << BITRES) - anti_collapse_rsv, ao.balance, codedBands);
+
+    CA_TRACE("pvq done tell=%d", ec_tell(enc)); CA_TRACE("");
+    // 18. anti-collapse bit, energy finalise, state roll-over
+    if (anti_collapse_rsv > 0) {
+        int anti_collapse_on = fc.consec_transient < 2;
+        ec_enc_bits(enc, (u32)anti_collapse_on, 1);
+    }
+    quant_energy_finalise_wave(F, enc, nbCompressedBytes * 8 - ec_tell(enc), C);
+    if (silence)
+        for (int k = lane(); k < C * NB; k += LANES) F.oldBandE[k] = -28672;
+    fc.prefilter_period = pitch_index;
+    fc.prefilter_gain = gain1;
+    fc.prefilter_tapset = prefilter_tapset;
+    wave_sync();
+    if (!isTransient) {
+        for (int k = lane(); k < C * NB; k += LANES) { F.oldLogE2[k] = F.oldLogE[k]; F.oldLogE[k] = F.oldBandE[k]; }
+    } else {
+        for (int k = lane(); k < C * NB; k += LANES) F.oldLogE[k] = (i16)imin(F.oldLogE[k], F.oldBandE[k]);
+    }
+    if (isTransient || transient_got_disabled) fc.consec_transient++;
+    else fc.consec_transient = 0;
+    fc.rng = enc.rng;
+
+    // 19. flush
+    ec_enc_done(enc);
+
+    // Opus layer: TOC (gen_toc: CELT-only, 20 ms, fullband) + length (opus_encoder.c:1925-1970)
+    st0(&F.packet[0], (u8)(0x80 | (3 << 5) | (3 << 3) | ((C == 2) << 2)));
+    int ret = nbCompressedBytes + 1;
+    wave_sync();
+    if (!cfg.vbr) {
+        // opus_packet_pad to max_data_bytes: a CELT CBR packet already has that size (ret == max_data_bytes)
+        if (ret != max_data_bytes) enc.error = -1;
+    }
+    if (st_out) store_state(fc, F, st_out, st_in);
+    {   // packet -> HBM (word-wise; the slab stride is a multiple of 4)
+        const u32 *src = reinterpret_cast<const u32 *>(F.packet);
+        u32 *dst = reinterpret_cast<u32 *>(out);
+        for (int k = lane(); k < (ret + 3) / 4; k += LANES) dst[k] = src[k];
+    }
+    FrameResult r;
+    r.bytes = enc.error ? -3 : ret;                                                  // OPUS_INTERNAL_ERROR
+    r.final_range = fc.rng;
+    return r;
+}
+
+}  // namespace ca

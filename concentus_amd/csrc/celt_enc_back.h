@@ -1,0 +1,706 @@
+// celt_enc_back.h -- bit allocation, fine energy, and the PVQ band quantiser (encoder side).
+//
+// Wave-cooperative counterparts of:
+//   compute_allocation / interp_bits2pulses      opus-fix/celt/rate.c:527-639, :248-525; init_caps celt/celt.c:246-256
+//   quant_fine_energy / quant_energy_finalise    celt/quant_bands.c:369-404, :406-439
+//   quant_all_bands (encode = 1)                 celt/bands.c:1337-1502
+//     quant_band / quant_band_stereo / quant_partition / quant_band_n1 / compute_theta / compute_qn
+//                                                celt/bands.c:1044-1174, :1176-1335, :864-1042, :819-862, :645-817, :596-621
+//     deinterleave_hadamard / haar1 / intensity_stereo / stereo_split   celt/bands.c:524-549, :581-594, :336-360, :362-373
+//   alg_quant / exp_rotation / exp_rotation1 / stereo_itheta            celt/vq.c:161-325, :70-117, :43-68, :376-408
+//   encode_pulses / icwrs                        celt/cwrs.c:440-460
+//
+// Encoder-only simplifications that follow from `resynth == 0` in the reference (bands.c:1046-1050):
+// lowband folding, `norm`, `fill`, collapse masks, `gain` and the LCG `seed` never influence the coded
+// bits, so they are not carried here (the decoder path will need them).
+#pragma once
+#include "celt_enc_mid.h"
+
+namespace ca {
+
+enum { BITRES = 3, ALLOC_STEPS = 6, MAX_FINE_BITS = 8, FINE_OFFSET = 21, QTHETA_OFFSET = 4, QTHETA_OFFSET_TWOPHASE = 16 };
+
+CA_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1); }     // rate.h:46-49
+
+CA_DEV const u8 *pulse_cache(int band, int LM) { return CLT_cache_bits50 + CLT_cache_index50[(LM + 1) * NB + band]; }
+
+CA_DEV int bits2pulses(int band, int LM, int bits)                                         // rate.h:51-77
+{
+    const u8 *cache = pulse_cache(band, LM);
+    int lo = 0, hi = cache[0];
+    bits--;
+    for (int i = 0; i < 6; i++) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((int)cache[mid] >= bits) hi = mid; else lo = mid;
+    }
+    if (bits - (lo == 0 ? -1 : (int)cache[lo]) <= (int)cache[hi] - bits) return lo;
+    return hi;
+}
+
+CA_DEV int pulses2bits(int band, int LM, int pulses)                                       // rate.h:79-85
+{
+    return pulses == 0 ? 0 : pulse_cache(band, LM)[pulses] + 1;
+}
+
+CA_DEV u32 pvq_u(int n, int k)                                                             // cwrs.c:197
+{
+    int lo = n < k ? n : k, hi = n < k ? k : n;
+    return CLT_pvq_u_data[CLT_pvq_u_row[lo] + hi];
+}
+
+// ---- compute_allocation (rate.c:527-639 + :248-525), start 0, end 21, LM 3, encode 1 ---------------
+struct AllocOut { int codedBands; i32 balance; int intensity; int dual_stereo; };
+
+CA_DEVFN AllocOut compute_allocation_wave(FrameLds &F, RangeEnc &ec, int C, int alloc_trim, int intensity_in,
+                                          int dual_stereo_in, i32 total, int prev, int signalBandwidth)
+{
+    const int LM = LM3, end = NB, start = 0, len = NB;
+    const i16 *eB = CLT_eband5ms;
+    i32 *bits = F.pulses, *ebits = F.fine_quant, *fine_priority = F.fine_priority;
+    AllocOut out;
+    out.intensity = intensity_in;
+    out.dual_stereo = dual_stereo_in;
+    total = imax(total, 0);
+    int skip_start = start;
+    int skip_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
+    total -= skip_rsv;
+    int intensity_rsv = 0, dual_stereo_rsv = 0;
+    if (C == 2) {
+        intensity_rsv = CLT_log2_frac_table[end - start];
+        if (intensity_rsv > total) intensity_rsv = 0;
+        else {
+            total -= intensity_rsv;
+            dual_stereo_rsv = total >= 1 << BITRES ? 1 << BITRES : 0;
+            total -= dual_stereo_rsv;
+        }
+    }
+    for (int j = lane(); j < end; j += LANES) {
+        int w = eB[j + 1] - eB[j];
+        F.thresh[j] = imax(C << BITRES, ((3 * w) << LM << BITRES) >> 4);
+        i32 to = (C * w * (alloc_trim - 5 - LM) * (end - j - 1) * (1 << (LM + BITRES))) >> 6;
+        if ((w << LM) == 1) to -= C << BITRES;
+        F.trim_offset[j] = to;
+    }
+    wave_sync();
+    int lo = 1, hi = 11 - 1;
+    do {
+        int done = 0, psum = 0, mid = (lo + hi) >> 1;
+        for (int j = end; j-- > start;) {
+            int N = eB[j + 1] - eB[j];
+            int bitsj = (C * N * CLT_band_allocation[mid * len + j]) << LM >> 2;
+            if (bitsj > 0) bitsj = imax(0, bitsj + F.trim_offset[j]);
+            bitsj += F.offsets[j];
+            if (bitsj >= F.thresh[j] || done) { done = 1; psum += imin(bitsj, F.cap[j]); }
+            else if (bitsj >= C << BITRES) psum += C << BITRES;
+        }
+        if (psum > total) hi = mid - 1; else lo = mid + 1;
+    } while (lo <= hi);
+    hi = lo--;
+    for (int j = start; j < end; j++) {
+        int N = eB[j + 1] - eB[j];
+        int bits1j = (C * N * CLT_band_allocation[lo * len + j]) << LM >> 2;
+        int bits2j = hi >= 11 ? F.cap[j] : (C * N * CLT_band_allocation[hi * len + j]) << LM >> 2;
+        if (bits1j > 0) bits1j = imax(0, bits1j + F.trim_offset[j]);
+        if (bits2j > 0) bits2j = imax(0, bits2j + F.trim_offset[j]);
+        if (lo > 0) bits1j += F.offsets[j];
+        bits2j += F.offsets[j];
+        if (F.offsets[j] > 0) skip_start = j;
+        bits2j = imax(0, bits2j - bits1j);
+        st0(&F.bits1[j], bits1j);
+        st0(&F.bits2[j], bits2j);
+    }
+    wave_sync();
+    // ---- interp_bits2pulses ----
+    const int alloc_floor = C << BITRES, stereo = C > 1, logM = LM << BITRES;
+    i32 psum;
+    lo = 0;
+    hi = 1 << ALLOC_STEPS;
+    for (int i = 0; i < ALLOC_STEPS; i++) {
+        int mid = (lo + hi) >> 1, done = 0;
+        psum = 0;
+        for (int j = end; j-- > start;) {
+            int tmp = F.bits1[j] + ((mid * (i32)F.bits2[j]) >> ALLOC_STEPS);
+            if (tmp >= F.thresh[j] || done) { done = 1; psum += imin(tmp, F.cap[j]); }
+            else if (tmp >= alloc_floor) psum += alloc_floor;
+        }
+        if (psum > total) hi = mid; else lo = mid;
+    }
+    psum = 0;
+    {
+        int done = 0;
+        for (int j = end; j-- > start;) {
+            int tmp = F.bits1[j] + ((lo * F.bits2[j]) >> ALLOC_STEPS);
+            if (tmp < F.thresh[j] && !done) tmp = tmp >= alloc_floor ? alloc_floor : 0;
+            else done = 1;
+            tmp = imin(tmp, F.cap[j]);
+            st0(&bits[j], tmp);
+            psum += tmp;
+        }
+    }
+    wave_sync();
+    int codedBands;
+    for (codedBands = end;; codedBands--) {
+        int j = codedBands - 1;
+        if (j <= skip_start) { total += skip_rsv; break; }
+        i32 left = total - psum;
+        i32 percoeff = (u32)left / (u32)(eB[codedBands] - eB[start]);
+        left -= (eB[codedBands] - eB[start]) * percoeff;
+        int rem = imax(left - (eB[j] - eB[start]), 0);
+        int band_width = eB[codedBands] - eB[j];
+        int band_bits = (int)(bits[j] + percoeff * band_width + rem);
+        if (band_bits >= imax(F.thresh[j], alloc_floor + (1 << BITRES))) {
+            if (codedBands <= start + 2 || (band_bits > (((j < prev ? 7 : 9) * band_width) << LM << BITRES) >> 4 && j <= signalBandwidth)) {
+                ec_enc_bit_logp(ec, 1, 1);
+                break;
+            }
+            ec_enc_bit_logp(ec, 0, 1);
+            psum += 1 << BITRES;
+            band_bits -= 1 << BITRES;
+        }
+        psum -= bits[j] + intensity_rsv;
+        if (intensity_rsv > 0) intensity_rsv = CLT_log2_frac_table[j - start];
+        psum += intensity_rsv;
+        if (band_bits >= alloc_floor) { psum += alloc_floor; st0(&bits[j], (i32)alloc_floor); }
+        else st0(&bits[j], 0);
+    }
+    if (intensity_rsv > 0) {
+        out.intensity = imin(out.intensity, codedBands);
+        ec_enc_uint(ec, (u32)(out.intensity - start), (u32)(codedBands + 1 - start));
+    } else {
+        out.intensity = 0;
+    }
+    if (out.intensity <= start) { total += dual_stereo_rsv; dual_stereo_rsv = 0; }
+    if (dual_stereo_rsv > 0) ec_enc_bit_logp(ec, out.dual_stereo, 1);
+    else out.dual_stereo = 0;
+    wave_sync();
+    i32 left = total - psum;
+    i32 percoeff = (u32)left / (u32)(eB[codedBands] - eB[start]);
+    left -= (eB[codedBands] - eB[start]) * percoeff;
+    for (int j = start; j < codedBands; j++) st0(&bits[j], bits[j] + (int)percoeff * (eB[j + 1] - eB[j]));
+    for (int j = start; j < codedBands; j++) {
+        int tmp = (int)imin(left, eB[j + 1] - eB[j]);
+        st0(&bits[j], bits[j] + tmp);
+        left -= tmp;
+    }
+    i32 balance = 0;
+    int j;
+    for (j = start; j < codedBands; j++) {
+        int N0 = eB[j + 1] - eB[j], N = N0 << LM;
+        i32 bit = (i32)bits[j] + balance, excess;
+        i32 bj, ej, fp;
+        if (N > 1) {
+            excess = imax(bit - F.cap[j], 0);
+            bj = bit - excess;
+            int den = C * N + ((C == 2 && N > 2 && !out.dual_stereo && j < out.intensity) ? 1 : 0);
+            int NClogN = den * (CLT_logN400[j] + logM);
+            int offset = (NClogN >> 1) - den * FINE_OFFSET;
+            if (N == 2) offset += den << BITRES >> 2;
+            if (bj + offset < (den * 2) << BITRES) offset += NClogN >> 2;
+            else if (bj + offset < (den * 3) << BITRES) offset += NClogN >> 3;
+            ej = imax(0, bj + offset + (den << (BITRES - 1)));
+            ej = (i32)((u32)ej / (u32)den) >> BITRES;
+            if (C * ej > (bj >> BITRES)) ej = bj >> stereo >> BITRES;
+            ej = imin(ej, MAX_FINE_BITS);
+            fp = ej * (den << BITRES) >= bj + offset;
+            bj -= (C * ej) << BITRES;
+        } else {
+            excess = imax(0, bit - (C << BITRES));
+            bj = bit - excess;
+            ej = 0;
+            fp = 1;
+        }
+        if (excess > 0) {
+            int extra_fine = imin(excess >> (stereo + BITRES), MAX_FINE_BITS - ej);
+            ej += extra_fine;
+            int extra_bits = (extra_fine * C) << BITRES;
+            fp = extra_bits >= excess - balance;
+            excess -= extra_bits;
+        }
+        balance = excess;
+        st0(&bits[j], bj);
+        st0(&ebits[j], ej);
+        st0(&fine_priority[j], fp);
+    }
+    out.balance = balance;
+    for (; j < end; j++) {
+        i32 e = bits[j] >> stereo >> BITRES;
+        st0(&ebits[j], e);
+        st0(&bits[j], 0);
+        st0(&fine_priority[j], (i32)(e < 1));
+    }
+    wave_sync();
+    out.codedBands = codedBands;
+    return out;
+}
+
+CA_DEVFN void quant_fine_energy_wave(FrameLds &F, RangeEnc &enc, int C)                    // quant_bands.c:369-404
+{
+    for (int i = 0; i < NB; i++) {
+        int fq = F.fine_quant[i];
+        if (fq <= 0) continue;
+        i32 frac = (i16)(1 << fq);
+        for (int c = 0; c < C; c++) {
+            int q2 = (F.error[i + c * NB] + 512) >> (10 - fq);
+            if (q2 > frac - 1) q2 = frac - 1;
+            if (q2 < 0) q2 = 0;
+            ec_enc_bits(enc, (u32)q2, (u32)fq);
+            i32 offset = (i16)sub16((shl32(q2, 10) + 512) >> fq, 512);
+            st0(&F.oldBandE[i + c * NB], (i16)(F.oldBandE[i + c * NB] + offset));
+            st0(&F.error[i + c * NB], (i16)(F.error[i + c * NB] - offset));
+        }
+    }
+    wave_sync();
+}
+
+CA_DEVFN void quant_energy_finalise_wave(FrameLds &F, RangeEnc &enc, int bits_left, int C)   // quant_bands.c:406-439
+{
+    for (int prio = 0; prio < 2; prio++) {
+        for (int i = 0; i < NB && bits_left >= C; i++) {
+            if (F.fine_quant[i] >= MAX_FINE_BITS || F.fine_priority[i] != prio) continue;
+            for (int c = 0; c < C; c++) {
+                int q2 = F.error[i + c * NB] < 0 ? 0 : 1;
+                ec_enc_bits(enc, (u32)q2, 1);
+                i32 offset = (i16)((shl16(q2, 10) - 512) >> (F.fine_quant[i] + 1));
+                st0(&F.oldBandE[i + c * NB], (i16)(F.oldBandE[i + c * NB] + offset));
+                bits_left--;
+            }
+        }
+    }
+    wave_sync();
+}
+
+// ---- PVQ ---------------------------------------------------------------------------------------------
+struct BandCtx {                 // uniform; cf. struct band_ctx (bands.c:623-635)
+    int i, intensity, spread, tf_change;
+    i32 remaining_bits;
+};
+
+// exp_rotation1 chains (vq.c:43-68): positions r, r+stride, ... of one block form a serial recurrence; the
+// `stride` residues and the blocks are independent, one lane walks one chain.
+CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c, i32 s)
+{
+    const i32 ms = (i16)neg32(s);
+    for (int ch = lane(); ch < nblocks * stride; ch += LANES) {
+        i16 *x = X + (ch / stride) * len;
+        const int r = ch % stride;
+        int i;
+        for (i = r; i < len - stride; i += stride) {
+            i32 x1 = x[i], x2 = x[i + stride];
+            x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
+            x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
+        }
+        // backward pass: i = len-2*stride-1 .. 0, restricted to this residue
+        int top = len - 2 * stride - 1;
+        if (top >= r) {
+            i = top - ((top - r) % stride);
+            for (; i >= 0; i -= stride) {
+                i32 x1 = x[i], x2 = x[i + stride];
+                x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
+                x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
+            }
+        }
+    }
+    wave_sync();
+}
+
+CA_DEV void exp_rotation_wave(i16 *X, int len, int stride, int K, int spread)              // vq.c:70-117, dir = 1
+{
+    if (2 * K >= len || spread == SPREAD_NONE) return;
+    const int factor = spread == SPREAD_LIGHT ? 15 : spread == SPREAD_NORMAL ? 10 : 5;   // SPREAD_FACTOR[spread-1]
+    i32 gain = (i16)celt_div(mul16_16(32767, len), len + factor * K);
+    i32 theta = (i16)mul16_16_q15(gain, gain) >> 1;
+    i32 c = celt_cos_norm(theta);
+    i32 s = celt_cos_norm((i16)sub16(32767, theta));
+    int stride2 = 0;
+    if (len >= 8 * stride) {
+        stride2 = 1;
+        while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
+    }
+    const int blen = (int)((u32)len / (u32)stride);
+    exp_rotation1_chains(X, blen, stride, 1, c, (i16)neg32(s));
+    if (stride2) exp_rotation1_chains(X, blen, stride, stride2, s, (i16)neg32(c));
+}
+
+// encode_pulses(iy, N, K) = ec_enc_uint(icwrs(N, iy), V(N,K))  (cwrs.c:440-460)
+CA_DEVFN void encode_pulses_wave(FrameLds &F, RangeEnc &ec, int N, int K)
+{
+    const i32 *y = F.s.pvq.iy;
+    // suffix sums k_j = sum_{t>=j} |y_t| are produced serially (cheap), the table look-ups in parallel
+    i16 *suf = F.s.pvq.xabs;                         // free after the search: reuse as suffix sums
+    if (lane() == 0) {
+        int k = 0;
+        for (int j = N - 1; j >= 0; j--) { int a = y[j]; k += a < 0 ? -a : a; suf[j] = (i16)k; }
+    }
+    wave_sync();
+    u32 p = 0;
+    for (int j = lane(); j < N - 1; j += LANES) {
+        p += pvq_u(N - j, suf[j + 1]);
+        if (y[j] < 0) p += pvq_u(N - j, suf[j] + 1);
+    }
+    u32 idx = (u32)wave_add((i32)p) + (u32)(y[N - 1] < 0);
+    u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
+    wave_sync();
+    ec_enc_uint(ec, idx, V);
+}
+
+// alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build
+CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
+{
+    i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
+    i32 *iy = F.s.pvq.iy;
+    exp_rotation_wave(X, N, B, K, spread);
+    for (int j = lane(); j < N; j += LANES) {
+        i32 v = X[j];
+        xa[j] = (i16)(v > 0 ? v : -v);
+        iy[j] = 0;
+        y[j] = 0;
+    }
+    wave_sync();
+    i32 xy = 0, yy = 0;
+    int pulsesLeft = K;
+    if (K > (N >> 1)) {
+        i32 p = 0;
+        for (int j = lane(); j < N; j += LANES) p += xa[j];
+        i32 sum = wave_add(p);
+        if (sum <= K) {
+            for (int j = lane(); j < N; j += LANES) xa[j] = j == 0 ? 16384 : 0;
+            sum = 16384;
+            wave_sync();
+        }
+        i32 rcp = (i16)mul16_32_q16((i16)(K - 1), celt_rcp(sum));
+        i32 pyy = 0, pxy = 0, ppl = 0;
+        for (int j = lane(); j < N; j += LANES) {
+            i32 q = mul16_16_q15(xa[j], rcp);
+            iy[j] = q;
+            i32 yj = (i16)q;
+            pyy = mac16_16(pyy, yj, yj);
+            pxy = mac16_16(pxy, xa[j], yj);
+            y[j] = (i16)(yj * 2);
+            ppl += q;
+        }
+        yy = (i16)wave_add(pyy);
+        xy = wave_add(pxy);
+        pulsesLeft -= wave_add(ppl);
+        wave_sync();
+    }
+    if (pulsesLeft > N + 3) {
+        i32 tmp = (i16)pulsesLeft;
+        yy = (i16)mac16_16(yy, tmp, tmp);
+        yy = (i16)mac16_16(yy, tmp, y[0]);
+        st0(&iy[0], iy[0] + pulsesLeft);
+        pulsesLeft = 0;
+        wave_sync();
+    }
+    for (int i = 0; i < pulsesLeft; i++) {
+        const int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
+        yy = (i16)add32(yy, 1);
+        i32 best_num = -32767, best_den = 0;
+        int best_id = 0;
+        for (int j = lane(); j < N; j += LANES) {
+            i32 Rxy = (i16)(add32(xy, xa[j]) >> rshift);
+            i32 Ryy = add16(yy, y[j]);
+            Rxy = (i16)mul16_16_q15(Rxy, Rxy);
+            if (mul16_16(best_den, Rxy) > mul16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = j; }
+        }
+        // wave arg-max under the same (exact, cross-multiplied) order; ties go to the lower index
+        for (int m = LANES >> 1; m > 0; m >>= 1) {
+            i32 on = shfl_xor(best_num, m), od = shfl_xor(best_den, m);
+            int oi = shfl_xor(best_id, m);
+            i32 lhs = mul16_16(best_den, on), rhs = mul16_16(od, best_num);
+            if (lhs > rhs || (lhs == rhs && oi < best_id)) { best_num = on; best_den = od; best_id = oi; }
+        }
+        xy = add32(xy, xa[best_id]);
+        yy = add16(yy, y[best_id]);
+        if (lane() == (best_id & (LANES - 1))) { y[best_id] = (i16)(y[best_id] + 2); iy[best_id] = iy[best_id] + 1; }
+        wave_sync();
+    }
+    for (int j = lane(); j < N; j += LANES)
+        if (X[j] <= 0) iy[j] = -iy[j];                                            // signx[j] < 0  <=>  X[j] <= 0
+    wave_sync();
+    encode_pulses_wave(F, ec, N, K);
+}
+
+CA_DEV int stereo_itheta_wave(const i16 *X, const i16 *Y, int stereo, int N)               // vq.c:376-408
+{
+    i32 pm = 0, ps = 0;
+    if (stereo) {
+        for (int i = lane(); i < N; i += LANES) {
+            i32 m = add16(X[i] >> 1, Y[i] >> 1), s = (i16)sub16(X[i] >> 1, Y[i] >> 1);
+            pm = mac16_16(pm, m, m);
+            ps = mac16_16(ps, s, s);
+        }
+    } else {
+        for (int i = lane(); i < N; i += LANES) { pm = mac16_16(pm, X[i], X[i]); ps = mac16_16(ps, Y[i], Y[i]); }
+    }
+    i32 Emid = add32(1, wave_add(pm)), Eside = add32(1, wave_add(ps));
+    i32 mid = (i16)celt_sqrt(Emid), side = (i16)celt_sqrt(Eside);
+    return mul16_16_q15(20861, celt_atan2p(side, mid));                                   // QCONST16(0.63662f,15)
+}
+
+CA_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)                 // bands.c:596-621
+{
+    int N2 = 2 * N - 1;
+    if (stereo && N == 2) N2--;
+    int qb = (b + N2 * offset) / N2;
+    qb = imin(b - pulse_cap - (4 << BITRES), qb);
+    qb = imin(8 << BITRES, qb);
+    if (qb < (1 << BITRES >> 1)) return 1;
+    int qn = CLT_exp2_table8[qb & 0x7] >> (14 - (qb >> BITRES));
+    return (qn + 1) >> 1 << 1;
+}
+
+struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
+
+// compute_theta (bands.c:645-817), encode = 1
+CA_DEVFN SplitCtx compute_theta_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int *b, int B,
+                                     int B0, int LM, int stereo)
+{
+    (void)B;
+    SplitCtx sc;
+    const int i = ctx.i;
+    int inv = 0;
+    int pulse_cap = CLT_logN400[i] + LM * (1 << BITRES);
+    int offset = (pulse_cap >> 1) - (stereo && N == 2 ? QTHETA_OFFSET_TWOPHASE : QTHETA_OFFSET);
+    int qn = compute_qn(N, *b, offset, pulse_cap, stereo);
+    if (stereo && i >= ctx.intensity) qn = 1;
+    int itheta = stereo_itheta_wave(X, Y, stereo, N);
+    i32 tell = (i32)ec_tell_frac(ec);
+    if (qn != 1) {
+        itheta = (itheta * qn + 8192) >> 14;
+        if (stereo && N > 2) {
+            int p0 = 3, x = itheta, x0 = qn / 2, ft = p0 * (x0 + 1) + x0;
+            ec_encode(ec, (u32)(x <= x0 ? p0 * x : (x - 1 - x0) + (x0 + 1) * p0),
+                      (u32)(x <= x0 ? p0 * (x + 1) : (x - x0) + (x0 + 1) * p0), (u32)ft);
+        } else if (B0 > 1 || stereo) {
+            ec_enc_uint(ec, (u32)itheta, (u32)(qn + 1));
+        } else {
+            int ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
+            int fs = itheta <= (qn >> 1) ? itheta + 1 : qn + 1 - itheta;
+            int fl = itheta <= (qn >> 1) ? (itheta * (itheta + 1)) >> 1 : ft - (((qn + 1 - itheta) * (qn + 2 - itheta)) >> 1);
+            ec_encode(ec, (u32)fl, (u32)(fl + fs), (u32)ft);
+        }
+        itheta = (int)((u32)(itheta * 16384) / (u32)qn);
+        if (stereo) {
+            if (itheta == 0) {
+                // intensity_stereo (bands.c:336-360)
+                i32 bl = F.bandE[i], br = F.bandE[i + NB];
+                int shift = celt_zlog2(imax(bl, br)) - 13;
+                i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
+                i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
+                i32 a1 = (i16)(shl32(left, 14) / norm), a2 = (i16)(shl32(right, 14) / norm);
+                for (int j = lane(); j < N; j += LANES)
+                    X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
+            } else {
+                for (int j = lane(); j < N; j += LANES) {                                  // stereo_split (bands.c:362-373)
+                    i32 l = mul16_16(23170, X[j]), r = mul16_16(23170, Y[j]);
+                    X[j] = (i16)(add32(l, r) >> 15);
+                    Y[j] = (i16)(sub32(r, l) >> 15);
+                }
+            }
+            wave_sync();
+        }
+    } else if (stereo) {
+        inv = itheta > 8192;
+        if (inv)
+            for (int j = lane(); j < N; j += LANES) Y[j] = (i16)(-Y[j]);
+        wave_sync();
+        {
+            i32 bl = F.bandE[i], br = F.bandE[i + NB];
+            int shift = celt_zlog2(imax(bl, br)) - 13;
+            i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
+            i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
+            i32 a1 = (i16)(shl32(left, 14) / norm), a2 = (i16)(shl32(right, 14) / norm);
+            for (int j = lane(); j < N; j += LANES)
+                X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
+        }
+        wave_sync();
+        if (*b > 2 << BITRES && ctx.remaining_bits > 2 << BITRES) ec_enc_bit_logp(ec, inv, 2);
+        else inv = 0;
+        itheta = 0;
+    }
+    int qalloc = (int)((i32)ec_tell_frac(ec) - tell);
+    *b -= qalloc;
+    int imid, iside, delta;
+    if (itheta == 0) { imid = 32767; iside = 0; delta = -16384; }
+    else if (itheta == 16384) { imid = 0; iside = 32767; delta = 16384; }
+    else {
+        imid = bitexact_cos((i16)itheta);
+        iside = bitexact_cos((i16)(16384 - itheta));
+        delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
+    }
+    sc.inv = inv; sc.imid = imid; sc.iside = iside; sc.delta = delta; sc.itheta = itheta; sc.qalloc = qalloc;
+    return sc;
+}
+
+// quant_partition (bands.c:864-1042), encode only. Recursive (depth <= 4: LM goes 3 -> -1).
+CA_DEVFN void quant_partition_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, int N, int b, int B, int LM)
+{
+    const u8 *cache = pulse_cache(ctx.i, LM);
+    if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
+        const int B0 = B;
+        N >>= 1;
+        i16 *Y = X + N;
+        LM -= 1;
+        B = (B + 1) >> 1;
+        SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B0, LM, 0);
+        int delta = sc.delta;
+        const int itheta = sc.itheta;
+        if (B0 > 1 && (itheta & 0x3fff)) {
+            if (itheta > 8192) delta -= delta >> (4 - LM);
+            else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
+        }
+        int mbits = imax(0, imin(b, (b - delta) / 2));
+        int sbits = b - mbits;
+        ctx.remaining_bits -= sc.qalloc;
+        i32 rebalance = ctx.remaining_bits;
+        if (mbits >= sbits) {
+            quant_partition_wave(F, ec, ctx, X, N, mbits, B, LM);
+            rebalance = mbits - (rebalance - ctx.remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+            quant_partition_wave(F, ec, ctx, Y, N, sbits, B, LM);
+        } else {
+            quant_partition_wave(F, ec, ctx, Y, N, sbits, B, LM);
+            rebalance = sbits - (rebalance - ctx.remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+            quant_partition_wave(F, ec, ctx, X, N, mbits, B, LM);
+        }
+    } else {
+        int q = bits2pulses(ctx.i, LM, b);
+        int curr_bits = pulses2bits(ctx.i, LM, q);
+        ctx.remaining_bits -= curr_bits;
+        while (ctx.remaining_bits < 0 && q > 0) {
+            ctx.remaining_bits += curr_bits;
+            q--;
+            curr_bits = pulses2bits(ctx.i, LM, q);
+            ctx.remaining_bits -= curr_bits;
+        }
+        if (q != 0) alg_quant_wave(F, ec, X, N, get_pulses(q), ctx.spread, B);
+    }
+}
+
+CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i16 *Y)     // bands.c:819-862
+{
+    const i16 *x = X;
+    for (int c = 0; c < (Y ? 2 : 1); c++) {
+        if (ctx.remaining_bits >= 1 << BITRES) {
+            ec_enc_bits(ec, (u32)(x[0] < 0), 1);
+            ctx.remaining_bits -= 1 << BITRES;
+        }
+        x = Y;
+    }
+}
+
+CA_DEV void deinterleave_hadamard_wave(FrameLds &F, i16 *X, int N0, int stride, int hadamard)   // bands.c:524-549
+{
+    i16 *tmp = F.s.pvq.xabs;
+    const int N = N0 * stride;
+    const u8 *ordery = CLT_ordery_table + stride - 2;
+    for (int s = 0; s < stride; s++) {
+        int d = hadamard ? ordery[s] : s;
+        for (int j = lane(); j < N0; j += LANES) tmp[d * N0 + j] = X[j * stride + s];
+    }
+    wave_sync();
+    for (int k = lane(); k < N; k += LANES) X[k] = tmp[k];
+    wave_sync();
+}
+
+// quant_band (bands.c:1044-1174), encode only, no lowband
+CA_DEVFN void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, int N, int b, int B, int LM)
+{
+    int N_B = (int)((u32)N / (u32)B);
+    const int longBlocks = B == 1;
+    int tf_change = ctx.tf_change;
+    if (N == 1) { quant_band_n1_wave(ec, ctx, X, nullptr); return; }
+    int recombine = tf_change > 0 ? tf_change : 0;
+    for (int k = 0; k < recombine; k++) haar1_wave(X, N >> k, 1 << k);
+    B >>= recombine;
+    N_B <<= recombine;
+    while ((N_B & 1) == 0 && tf_change < 0) {
+        haar1_wave(X, N_B, B);
+        B <<= 1;
+        N_B >>= 1;
+        tf_change++;
+    }
+    const int B0 = B;
+    if (B0 > 1) deinterleave_hadamard_wave(F, X, N_B >> recombine, B0 << recombine, longBlocks);
+    quant_partition_wave(F, ec, ctx, X, N, b, B, LM);
+}
+
+// quant_band_stereo (bands.c:1176-1335), encode only
+CA_DEVFN void quant_band_stereo_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int b, int B, int LM)
+{
+    if (N == 1) { quant_band_n1_wave(ec, ctx, X, Y); return; }
+    SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B, LM, 1);
+    const int itheta = sc.itheta;
+    if (N == 2) {
+        int mbits = b, sbits = 0;
+        if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
+        mbits -= sbits;
+        const int c = itheta > 8192;
+        ctx.remaining_bits -= sc.qalloc + sbits;
+        i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
+        if (sbits) {
+            int sign = ((i32)x2[0] * y2[1] - (i32)x2[1] * y2[0]) < 0;
+            ec_enc_bits(ec, (u32)sign, 1);
+        }
+        quant_band_wave(F, ec, ctx, x2, N, mbits, B, LM);
+    } else {
+        int mbits = imax(0, imin(b, (b - sc.delta) / 2));
+        int sbits = b - mbits;
+        ctx.remaining_bits -= sc.qalloc;
+        i32 rebalance = ctx.remaining_bits;
+        if (mbits >= sbits) {
+            quant_band_wave(F, ec, ctx, X, N, mbits, B, LM);
+            rebalance = mbits - (rebalance - ctx.remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
+            quant_band_wave(F, ec, ctx, Y, N, sbits, B, LM);
+        } else {
+            quant_band_wave(F, ec, ctx, Y, N, sbits, B, LM);
+            rebalance = sbits - (rebalance - ctx.remaining_bits);
+            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
+            quant_band_wave(F, ec, ctx, X, N, mbits, B, LM);
+        }
+    }
+}
+
+// quant_all_bands(encode = 1, start 0, end 21, LM 3)  (bands.c:1337-1502)
+CA_DEVFN void quant_all_bands_wave(FrameLds &F, RangeEnc &ec, int C, int shortBlocks, int spread, int dual_stereo,
+                                   int intensity, i32 total_bits, i32 balance, int codedBands)
+{
+    const int LM = LM3, M = M8;
+    const int B = shortBlocks ? M : 1;
+    i16 *X_ = frame_X(F), *Y_ = C == 2 ? X_ + FRAME : nullptr;
+    BandCtx ctx;
+    ctx.intensity = intensity;
+    ctx.spread = spread;
+    for (int i = 0; i < NB; i++) {
+        ctx.i = i;
+        i16 *X = X_ + M * CLT_eband5ms[i];
+        i16 *Y = Y_ ? Y_ + M * CLT_eband5ms[i] : nullptr;
+        const int N = M * CLT_eband5ms[i + 1] - M * CLT_eband5ms[i];
+        i32 tell = (i32)ec_tell_frac(ec);
+        if (i != 0) balance -= tell;
+        i32 remaining_bits = total_bits - tell - 1;
+        ctx.remaining_bits = remaining_bits;
+        int b;
+        if (i <= codedBands - 1) {
+            i32 curr_balance = balance / imin(3, codedBands - i);
+            b = imax(0, imin(16383, imin(remaining_bits + 1, F.pulses[i] + curr_balance)));
+        } else {
+            b = 0;
+        }
+        ctx.tf_change = F.tf_res[i];
+        if (dual_stereo && i == intensity) dual_stereo = 0;
+        if (dual_stereo) {
+            quant_band_wave(F, ec, ctx, X, N, b / 2, B, LM);
+            quant_band_wave(F, ec, ctx, Y, N, b / 2, B, LM);
+        } else if (Y) {
+            quant_band_stereo_wave(F, ec, ctx, X, Y, N, b, B, LM);
+        } else {
+            quant_band_wave(F, ec, ctx, X, N, b, B, LM);
+        }
+        balance += F.pulses[i] + tell;
+    }
+}
+
+}  // namespace ca

@@ -1,0 +1,682 @@
+// celt_enc_front.h -- front half of the CELT frame encoder: PCM -> normalised MDCT bands + analysis.
+//
+// Wave-cooperative (one wavefront per frame) counterparts of, in call order:
+//   dc_reject                  opus-fix/src/opus_encoder.c:362-384
+//   celt_preemphasis           celt/celt_encoder.c:464-548 (fast path :476-488)
+//   run_prefilter              celt/celt_encoder.c:1067-1193
+//     pitch_downsample / celt_fir5 / _celt_autocorr / _celt_lpc     celt/pitch.c:147-223,105-145; celt/celt_lpc.c:232-330,37-92
+//     pitch_search / find_best_pitch / celt_pitch_xcorr              celt/pitch.c:260-369,45-103,225-258
+//     remove_doubling                                                celt/pitch.c:372-503
+//     comb_filter                                                    celt/celt.c:183-237
+//   transient_analysis         celt/celt_encoder.c:227-377
+//   compute_band_energies, normalise_bands, amp2Log2                 celt/bands.c:97-168, celt/quant_bands.c:551-575
+// Data-parallel loops are strided over the lanes; scalar decisions run identically on every lane and
+// only lane 0 stores ("st0"). The arithmetic of every element follows the reference bit for bit.
+#pragma once
+#include "celt_math.h"
+#include "celt_state.h"
+#include "device_tables.h"
+#include "mdct_dev.h"
+#include "rangecoder.h"
+
+namespace ca {
+
+#if defined(CA_HOST_EMU)
+#define CA_DEVFN static
+#else
+#define CA_DEVFN __device__ __noinline__
+#endif
+
+enum { NB = 21, OVL = 120, FRAME = 960, MAXP = 1024, MINP = 15, LM3 = 3, M8 = 8 };
+enum { SPREAD_NONE = 0, SPREAD_LIGHT = 1, SPREAD_NORMAL = 2, SPREAD_AGGRESSIVE = 3 };
+
+template <class T> CA_DEV void st0(T *p, T v) { if (lane() == 0) *p = v; }
+
+// ---- per-frame LDS working set (one per wavefront) -------------------------------------------------
+struct __attribute__((aligned(16))) FrameLds {
+    i32 in[2][FRAME + OVL];        // overlap + pre-emphasised (then comb-filtered) signal; later X[2][960] (i16)
+    i32 xf[2][FRAME];              // dc-rejected PCM (i16) -> unfiltered pre-emphasised samples -> MDCT coefficients
+    union {
+        i16 raw_pcm[2 * FRAME];                                     // interleaved input
+        struct { i16 buf[992]; i16 xlp4[240]; i16 ylp4[484]; i32 xcorr[520]; } pitch;
+        i16 trans[2][FRAME + OVL];
+        int2 f2[480];
+        struct { i16 tmp[176]; i16 tmp1[176]; } tf;
+        struct { i16 y[176]; i32 iy[176]; i16 xabs[176]; } pvq;
+    } s;
+    u8 packet[1280];
+    i32 bandE[2 * NB];
+    i16 bandLogE[2 * NB], bandLogE2[2 * NB], error[2 * NB];
+    i16 oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
+    i16 oldE_intra[2 * NB], error_intra[2 * NB];
+    i16 follower[2 * NB], noise_floor[NB];
+    i16 normg[2 * NB];
+    i8 normshift[2 * NB];
+    u8 coarse_save[256];
+    i32 offsets[NB], cap[NB], pulses[NB], fine_quant[NB], fine_priority[NB], tf_res[NB];
+    i32 bits1[NB], bits2[NB], thresh[NB], trim_offset[NB];
+    i32 metric[NB], path0[NB], path1[NB];
+    i32 scal[16];                  // scalar hand-off slots (lane-local results published to the wave)
+};
+
+CA_DEV i16 *frame_X(FrameLds &F) { return reinterpret_cast<i16 *>(&F.in[0][0]); }      // X[c*960 + j]
+CA_DEV i16 *frame_pcmf(FrameLds &F) { return reinterpret_cast<i16 *>(&F.xf[0][0]); }   // pcmf[c*960 + i]
+
+// Uniform per-frame scalars (identical in every lane).
+struct FrameCtx {
+    int C;
+    // stream state (celt_encoder.c:82-120)
+    i32 hp_mem[4];
+    u32 rng;
+    int spread_decision, tonal_average, lastCodedBands, hf_average, tapset_decision;
+    i32 delayedIntra;
+    int prefilter_period, prefilter_gain, prefilter_tapset, consec_transient;
+    i32 preemph_memE[2];
+    i32 vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max;
+    int stereo_saving, intensity, spec_avg;
+    const i32 *hist;               // prefilter_mem of the stream in HBM, or nullptr (all zero)
+};
+
+// ---- dc_reject (src/opus_encoder.c:362-384) + celt_maxabs16 ------------------------------------------
+// Serial per channel: lane c filters channel c. cutoff 3 Hz @ 48 kHz -> shift = ilog2(48000/9) = 12.
+CA_DEV void dc_reject_wave(FrameLds &F, FrameCtx &fc)
+{
+    const int C = fc.C;
+    i16 *pcmf = frame_pcmf(F);
+    for (int c = lane(); c < C; c += LANES) {
+        i32 m0 = fc.hp_mem[2 * c], m1 = fc.hp_mem[2 * c + 1];
+        for (int i = 0; i < FRAME; i++) {
+            i32 x = shl32(F.s.raw_pcm[C * i + c], 15);
+            i32 tmp = sub32(x, m0);
+            m0 = add32(m0, pshr32(sub32(x, m0), 12));
+            i32 y = sub32(tmp, m1);
+            m1 = add32(m1, pshr32(sub32(tmp, m1), 12));
+            i32 o = pshr32(y, 15);
+            o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);          // SATURATE(x, 32767)
+            pcmf[c * FRAME + i] = (i16)o;
+        }
+        F.scal[2 * c] = m0;
+        F.scal[2 * c + 1] = m1;
+    }
+    wave_sync();
+    for (int c = 0; c < C; c++) { fc.hp_mem[2 * c] = F.scal[2 * c]; fc.hp_mem[2 * c + 1] = F.scal[2 * c + 1]; }
+    wave_sync();
+}
+
+// celt_maxabs16 over samples [i0, i1) of all channels (mathops.h:47-58)
+CA_DEV i32 maxabs_pcm(FrameLds &F, int C, int i0, int i1)
+{
+    const i16 *pcmf = frame_pcmf(F);
+    i32 mx = 0, mn = 0;
+    for (int c = 0; c < C; c++)
+        for (int i = i0 + lane(); i < i1; i += LANES) {
+            i32 v = pcmf[c * FRAME + i];
+            mx = imax(mx, v);
+            mn = imin(mn, v);
+        }
+    mx = wave_max(mx);
+    mn = wave_min(mn);
+    return imax(mx, -mn);
+}
+
+// ---- celt_preemphasis, fast path (celt_encoder.c:476-488): coef0 = 27853, SIG_SHIFT = 12 -----------
+CA_DEV void preemphasis_wave(FrameLds &F, FrameCtx &fc)
+{
+    const i16 *pcmf = frame_pcmf(F);
+    for (int c = 0; c < fc.C; c++) {
+        for (int i = lane(); i < FRAME; i += LANES) {
+            i32 x = pcmf[c * FRAME + i];
+            i32 m = i == 0 ? fc.preemph_memE[c] : (mul16_16(27853, pcmf[c * FRAME + i - 1]) >> 3);
+            F.in[c][OVL + i] = sub32(shl32(x, 12), m);
+        }
+        fc.preemph_memE[c] = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+    }
+    wave_sync();
+}
+
+// ---- pitch analysis --------------------------------------------------------------------------------
+// pre[c][k], k in [0, 1984): 1024 samples of history (stream state, HBM) followed by the 960 new ones.
+CA_DEV i32 pre_at(const FrameLds &F, const FrameCtx &fc, int c, int k)
+{
+    if (k >= MAXP) return F.xf[c][k - MAXP];
+    return fc.hist ? fc.hist[c * MAXP + k] : 0;
+}
+
+CA_DEVFN void pitch_downsample_wave(FrameLds &F, const FrameCtx &fc)              // pitch.c:147-223
+{
+    const int C = fc.C, len = MAXP + FRAME;
+    i16 *x_lp = F.s.pitch.buf;
+    i32 mx = 0, mn = 0;                                                            // celt_maxabs32 per channel
+    for (int c = 0; c < C; c++)
+        for (int k = lane(); k < len; k += LANES) {
+            i32 v = pre_at(F, fc, c, k);
+            mx = imax(mx, v);
+            mn = imin(mn, v);
+        }
+    i32 maxabs = imax(wave_max(mx), neg32(wave_min(mn)));
+    if (maxabs < 1) maxabs = 1;
+    int shift = celt_ilog2(maxabs) - 10;
+    if (shift < 0) shift = 0;
+    if (C == 2) shift++;
+    for (int i = lane(); i < (len >> 1); i += LANES) {
+        i32 acc = 0;
+        for (int c = 0; c < C; c++) {
+            i32 v;
+            if (i == 0)
+                v = (add32(pre_at(F, fc, c, 1) >> 1, pre_at(F, fc, c, 0)) >> 1) >> shift;
+            else
+                v = (add32(add32(pre_at(F, fc, c, 2 * i - 1), pre_at(F, fc, c, 2 * i + 1)) >> 1,
+                           pre_at(F, fc, c, 2 * i)) >> 1) >> shift;
+            acc = c == 0 ? (i16)v : (i16)(acc + v);                               // x_lp is opus_val16
+        }
+        x_lp[i] = (i16)acc;
+    }
+    wave_sync();
+
+    // _celt_autocorr(x_lp, ac, NULL, 0, 4, n = 992)  (celt_lpc.c:232-330), overlap == 0
+    const int n = len >> 1, lag = 4, fastN = n - lag;
+    i32 part = 0;
+    for (int i = lane(); i < n; i += LANES) part = add32(part, mul16_16(x_lp[i], x_lp[i]) >> 9);
+    i32 ac0 = add32(1 + (n << 7), wave_add(part));
+    int sh = (celt_ilog2(ac0) - 30 + 10) / 2;
+    i32 ac[5];
+    if (sh <= 0) sh = 0;
+    // ac[k] = sum_{i=0}^{n-1-k} xs[i]*xs[i+k] with xs = PSHR32(x_lp, sh): the reference's fastN split
+    // (celt_pitch_xcorr over fastN + tail loop) adds up to exactly this, and MAC16_16 sums wrap.
+    (void)fastN;
+    for (int k = 0; k <= lag; k++) {
+        i32 p = 0;
+        for (int i = lane(); i + k < n; i += LANES) {
+            i32 a = sh ? (i16)pshr32(x_lp[i], sh) : x_lp[i];
+            i32 b = sh ? (i16)pshr32(x_lp[i + k], sh) : x_lp[i + k];
+            p = mac16_16(p, a, b);
+        }
+        ac[k] = wave_add(p);
+    }
+    int shift2x = 2 * sh;
+    if (shift2x <= 0) ac[0] = add32(ac[0], shl32(1, -shift2x));
+    if (ac[0] < 268435456) {
+        int s2 = 29 - ec_ilog((u32)ac[0]);
+        for (int k = 0; k <= lag; k++) ac[k] = shl32(ac[k], s2);
+    } else if (ac[0] >= 536870912) {
+        int s2 = 1;
+        if (ac[0] >= 1073741824) s2++;
+        for (int k = 0; k <= lag; k++) ac[k] = ac[k] >> s2;
+    }
+    // noise floor -40 dB, lag windowing (pitch.c:186-199)
+    ac[0] = add32(ac[0], ac[0] >> 13);
+    for (int i = 1; i <= 4; i++) ac[i] = sub32(ac[i], mul16_32_q15(2 * i * i, ac[i]));
+    // _celt_lpc(lpc, ac, 4)  (celt_lpc.c:37-92)
+    i32 lpc32[4] = {0, 0, 0, 0};
+    i32 err = ac[0];
+    if (ac[0] != 0) {
+        for (int i = 0; i < 4; i++) {
+            i32 rr = 0;
+            for (int j = 0; j < i; j++) rr = add32(rr, mul32_32_q31(lpc32[j], ac[i - j]));
+            rr = add32(rr, ac[i + 1] >> 3);
+            i32 r = neg32(frac_div32(shl32(rr, 3), err));
+            lpc32[i] = r >> 3;
+            for (int j = 0; j < ((i + 1) >> 1); j++) {
+                i32 t1 = lpc32[j], t2 = lpc32[i - 1 - j];
+                lpc32[j] = add32(t1, mul32_32_q31(r, t2));
+                lpc32[i - 1 - j] = add32(t2, mul32_32_q31(r, t1));
+            }
+            err = sub32(err, mul32_32_q31(mul32_32_q31(r, r), err));
+            if (err < (ac[0] >> 10)) break;
+        }
+    }
+    i32 lpc[4], tmp = 32767;
+    for (int i = 0; i < 4; i++) {
+        i32 l = (i16)pshr32(lpc32[i], 16);                                        // ROUND16(lpc,16)
+        tmp = (i16)mul16_16_q15(29491, tmp);                                      // QCONST16(.9f,15)
+        lpc[i] = (i16)mul16_16_q15(l, tmp);
+    }
+    const i32 c1 = 26214;                                                          // QCONST16(.8f,15)
+    i32 num[5];
+    num[0] = (i16)(lpc[0] + 3277);                                                 // QCONST16(.8f,SIG_SHIFT)
+    num[1] = (i16)(lpc[1] + mul16_16_q15(c1, lpc[0]));
+    num[2] = (i16)(lpc[2] + mul16_16_q15(c1, lpc[1]));
+    num[3] = (i16)(lpc[3] + mul16_16_q15(c1, lpc[2]));
+    num[4] = (i16)mul16_16_q15(c1, lpc[3]);
+    // celt_fir5 in place, zero initial memory (pitch.c:105-145). Chunks go from the end so that the taps
+    // x[i-1..i-5] are still unfiltered when read.
+    for (int base = ((n - 1) / LANES) * LANES; base >= 0; base -= LANES) {
+        int i = base + lane();
+        i32 y = 0;
+        if (i < n) {
+            i32 sum = shl32(x_lp[i], 12);
+            for (int k = 0; k < 5; k++) {
+                i32 xm = i - 1 - k >= 0 ? x_lp[i - 1 - k] : 0;
+                sum = mac16_16(sum, num[k], xm);
+            }
+            y = (i16)pshr32(sum, 12);
+        }
+        wave_sync();
+        if (i < n) x_lp[i] = (i16)y;
+        wave_sync();
+    }
+}
+
+// find_best_pitch (pitch.c:45-103): inherently ordered (cross-multiplied comparisons against the running
+// best two), so it runs as uniform scalar code on every lane.
+CA_DEV void find_best_pitch_uniform(const i32 *xcorr, const i16 *y, int len, int max_pitch, int *best_pitch,
+                                    int yshift, i32 maxcorr)
+{
+    i32 Syy = 1;
+    i32 best_num[2] = {-1, -1};
+    i32 best_den[2] = {0, 0};
+    int xshift = celt_ilog2(maxcorr) - 14;
+    best_pitch[0] = 0;
+    best_pitch[1] = 1;
+    {
+        i32 p = 0;
+        for (int j = lane(); j < len; j += LANES) p = add32(p, mul16_16(y[j], y[j]) >> yshift);
+        Syy = add32(Syy, wave_add(p));
+    }
+    for (int i = 0; i < max_pitch; i++) {
+        if (xcorr[i] > 0) {
+            i32 xcorr16 = (i16)vshr32(xcorr[i], xshift);
+            i32 num = (i16)mul16_16_q15(xcorr16, xcorr16);
+            if (mul16_32_q15(num, best_den[1]) > mul16_32_q15(best_num[1], Syy)) {
+                if (mul16_32_q15(num, best_den[0]) > mul16_32_q15(best_num[0], Syy)) {
+                    best_num[1] = best_num[0];
+                    best_den[1] = best_den[0];
+                    best_pitch[1] = best_pitch[0];
+                    best_num[0] = num;
+                    best_den[0] = Syy;
+                    best_pitch[0] = i;
+                } else {
+                    best_num[1] = num;
+                    best_den[1] = Syy;
+                    best_pitch[1] = i;
+                }
+            }
+        }
+        Syy = add32(Syy, sub32(mul16_16(y[i + len], y[i + len]) >> yshift, mul16_16(y[i], y[i]) >> yshift));
+        Syy = imax(1, Syy);
+    }
+}
+
+// pitch_search(x_lp = buf+512, y = buf, len = 960, max_pitch = 979)  (pitch.c:260-369)
+CA_DEVFN int pitch_search_wave(FrameLds &F)
+{
+    const int len = FRAME, max_pitch = MAXP - 3 * MINP, lag = len + max_pitch;
+    const i16 *y = F.s.pitch.buf, *x_lp = F.s.pitch.buf + (MAXP >> 1);
+    i16 *x4 = F.s.pitch.xlp4, *y4 = F.s.pitch.ylp4;
+    i32 *xcorr = F.s.pitch.xcorr;
+    i32 mx = 0, mn = 0, my = 0, ny = 0;
+    for (int j = lane(); j < (len >> 2); j += LANES) { i32 v = x_lp[2 * j]; x4[j] = (i16)v; mx = imax(mx, v); mn = imin(mn, v); }
+    for (int j = lane(); j < (lag >> 2); j += LANES) { i32 v = y[2 * j]; y4[j] = (i16)v; my = imax(my, v); ny = imin(ny, v); }
+    i32 xmax = imax(wave_max(mx), -wave_min(mn));
+    i32 ymax = imax(wave_max(my), -wave_min(ny));
+    int shift = celt_ilog2(imax(1, imax(xmax, ymax))) - 11;
+    wave_sync();
+    if (shift > 0) {
+        for (int j = lane(); j < (len >> 2); j += LANES) x4[j] = (i16)(x4[j] >> shift);
+        for (int j = lane(); j < (lag >> 2); j += LANES) y4[j] = (i16)(y4[j] >> shift);
+        shift *= 2;
+    } else {
+        shift = 0;
+    }
+    wave_sync();
+    // coarse search, 4x decimation: celt_pitch_xcorr(x4, y4, xcorr, 240, 244) -- one lane per lag
+    i32 mc = 1;
+    for (int i = lane(); i < (max_pitch >> 2); i += LANES) {
+        i32 sum = 0;
+        for (int j = 0; j < (len >> 2); j++) sum = mac16_16(sum, x4[j], y4[i + j]);
+        xcorr[i] = sum;
+        mc = imax(mc, sum);
+    }
+    i32 maxcorr = wave_max(mc);
+    wave_sync();
+    int best_pitch[2];
+    find_best_pitch_uniform(xcorr, y4, len >> 2, max_pitch >> 2, best_pitch, 0, maxcorr);
+    wave_sync();
+    // finer search, 2x decimation: only lags within +-2 of the two candidates are evaluated
+    for (int i = lane(); i < (max_pitch >> 1); i += LANES) xcorr[i] = 0;
+    wave_sync();
+    maxcorr = 1;
+    for (int i = 0; i < (max_pitch >> 1); i++) {
+        int d0 = i - 2 * best_pitch[0], d1 = i - 2 * best_pitch[1];
+        if ((d0 < 0 ? -d0 : d0) > 2 && (d1 < 0 ? -d1 : d1) > 2) continue;
+        i32 p = 0;
+        for (int j = lane(); j < (len >> 1); j += LANES) p = add32(p, mul16_16(x_lp[j], y[i + j]) >> shift);
+        i32 sum = wave_add(p);
+        st0(&xcorr[i], imax(-1, sum));
+        maxcorr = imax(maxcorr, sum);
+    }
+    wave_sync();
+    find_best_pitch_uniform(xcorr, y, len >> 1, max_pitch >> 1, best_pitch, shift + 1, maxcorr);
+    int offset = 0;
+    if (best_pitch[0] > 0 && best_pitch[0] < (max_pitch >> 1) - 1) {
+        i32 a = xcorr[best_pitch[0] - 1], b = xcorr[best_pitch[0]], c = xcorr[best_pitch[0] + 1];
+        if (sub32(c, a) > mul16_32_q15(22938, sub32(b, a))) offset = 1;            // QCONST16(.7f,15)
+        else if (sub32(a, c) > mul16_32_q15(22938, sub32(b, c))) offset = -1;
+    }
+    wave_sync();
+    return 2 * best_pitch[0] - offset;
+}
+
+// inner products over the half-rate pitch buffer: sum_{i<N} x[i]*y1[i], x[i]*y2[i]  (pitch.h:132-160)
+CA_DEV void dual_inner_prod_wave(const i16 *x, const i16 *y1, const i16 *y2, int N, i32 &xy1, i32 &xy2)
+{
+    i32 a = 0, b = 0;
+    for (int i = lane(); i < N; i += LANES) { a = mac16_16(a, x[i], y1[i]); b = mac16_16(b, x[i], y2[i]); }
+    xy1 = wave_add(a);
+    xy2 = wave_add(b);
+}
+
+CA_DEV i32 pitch_gain_from(i32 xy, i32 xx, i32 yy, bool halve)                      // pitch.c:406-421,:455-460
+{
+    i32 m = mul32_32_q31(xx, yy);
+    i32 x2y2 = add32(1, halve ? (m >> 1) : m);
+    int sh = celt_ilog2(x2y2) >> 1;
+    i32 t = vshr32(x2y2, 2 * (sh - 7));
+    return vshr32(mul16_32_q15(celt_rsqrt_norm(t), xy), sh + 1);
+}
+
+// remove_doubling(x = buf, maxperiod 1024, minperiod 15, N 960, &T0, prev_period, prev_gain)  (pitch.c:372-503)
+CA_DEVFN i32 remove_doubling_wave(FrameLds &F, int *T0_, int prev_period, i32 prev_gain)
+{
+    const int minperiod0 = MINP, maxperiod = MAXP / 2, minperiod = MINP / 2, N = FRAME / 2;
+    const i16 *x = F.s.pitch.buf + maxperiod;
+    i32 *yy_lookup = F.s.pitch.xcorr;                                               // 513 entries (xcorr is dead)
+    *T0_ /= 2;
+    prev_period /= 2;
+    if (*T0_ >= maxperiod) *T0_ = maxperiod - 1;
+    int T, T0;
+    T = T0 = *T0_;
+    i32 xx, xy;
+    dual_inner_prod_wave(x, x, x - T0, N, xx, xy);
+    {   // yy_lookup[i] = max(0, xx + sum_{j=1..i} (x[-j]^2 - x[N-j]^2)): serial running sum, lane 0 stores
+        i32 yy = xx;
+        st0(&yy_lookup[0], xx);
+        for (int i = 1; i <= maxperiod; i++) {
+            yy = sub32(add32(yy, mul16_16(x[-i], x[-i])), mul16_16(x[N - i], x[N - i]));
+            st0(&yy_lookup[i], imax(0, yy));
+        }
+    }
+    wave_sync();
+    i32 yy = yy_lookup[T0];
+    i32 best_xy = xy, best_yy = yy;
+    i32 g, g0;
+    g = g0 = pitch_gain_from(xy, xx, yy, true);
+    for (int k = 2; k <= 15; k++) {
+        int T1 = (2 * T0 + k) / (2 * k), T1b;
+        if (T1 < minperiod) break;
+        if (k == 2) T1b = (T1 + T0 > maxperiod) ? T0 : T0 + T1;
+        else T1b = (2 * CLT_second_check[k] * T0 + k) / (2 * k);
+        i32 xy2;
+        dual_inner_prod_wave(x, x - T1, x - T1b, N, xy, xy2);
+        xy = add32(xy, xy2);
+        yy = add32(yy_lookup[T1], yy_lookup[T1b]);
+        i32 g1 = pitch_gain_from(xy, xx, yy, false);
+        int dT = T1 - prev_period;
+        if (dT < 0) dT = -dT;
+        i32 cont;
+        if (dT <= 1) cont = prev_gain;
+        else if (dT <= 2 && 5 * k * k < T0) cont = (i16)(prev_gain >> 1);
+        else cont = 0;
+        i32 thresh = imax(9830, sub32(mul16_32_q15(22938, g0), cont));              // .3, .7
+        if (T1 < 3 * minperiod) thresh = imax(13107, sub32(mul16_32_q15(27853, g0), cont));   // .4, .85
+        else if (T1 < 2 * minperiod) thresh = imax(16384, sub32(mul16_32_q15(29491, g0), cont));
+        if (g1 > thresh) { best_xy = xy; best_yy = yy; T = T1; g = g1; }
+    }
+    best_xy = imax(0, best_xy);
+    i32 pg;
+    if (best_yy <= best_xy) pg = 32767;
+    else pg = (i16)(frac_div32(best_xy, add32(best_yy, 1)) >> 16);
+    i32 xc[3];
+    for (int k = 0; k < 3; k++) {
+        i32 p = 0;
+        const i16 *yk = x - (T + k - 1);
+        for (int i = lane(); i < N; i += LANES) p = mac16_16(p, x[i], yk[i]);
+        xc[k] = wave_add(p);
+    }
+    int offset = 0;
+    if (sub32(xc[2], xc[0]) > mul16_32_q15(22938, sub32(xc[1], xc[0]))) offset = 1;
+    else if (sub32(xc[0], xc[2]) > mul16_32_q15(22938, sub32(xc[1], xc[2]))) offset = -1;
+    if (pg > g) pg = (i16)g;
+    *T0_ = 2 * T + offset;
+    if (*T0_ < minperiod0) *T0_ = minperiod0;
+    wave_sync();
+    return pg;
+}
+
+// comb_filter(y = in[c]+OVL, x = pre[c]+1024, T0, T1, N = 960, g0, g1, tapset0, tapset1, window, 120)
+// (celt.c:183-237; the x86 build uses the plain comb_filter_const_c, celt.c:156-181). Pure FIR on the
+// unfiltered signal, so every output sample is independent.
+CA_DEVFN void comb_filter_wave(FrameLds &F, const FrameCtx &fc, int c, int T0, int T1, i32 g0, i32 g1,
+                               int tapset0, int tapset1)
+{
+    if (g0 == 0 && g1 == 0) {
+        for (int i = lane(); i < FRAME; i += LANES) F.in[c][OVL + i] = F.xf[c][i];
+        return;
+    }
+    const i16 *G = CLT_comb_gains;
+    i32 g00 = (i16)mul16_16_p15(g0, G[tapset0 * 3 + 0]), g01 = (i16)mul16_16_p15(g0, G[tapset0 * 3 + 1]),
+        g02 = (i16)mul16_16_p15(g0, G[tapset0 * 3 + 2]);
+    i32 g10 = (i16)mul16_16_p15(g1, G[tapset1 * 3 + 0]), g11 = (i16)mul16_16_p15(g1, G[tapset1 * 3 + 1]),
+        g12 = (i16)mul16_16_p15(g1, G[tapset1 * 3 + 2]);
+    int overlap = OVL;
+    if (g0 == g1 && T0 == T1 && tapset0 == tapset1) overlap = 0;
+#define CA_PX(k) pre_at(F, fc, c, MAXP + (k))
+    for (int i = lane(); i < FRAME; i += LANES) {
+        i32 xi = F.xf[c][i];
+        i32 y;
+        if (i < overlap) {
+            i32 w = CLT_window120[i];
+            i32 f = (i16)mul16_16_q15(w, w);
+            i32 nf = (i16)(32767 - f);
+            y = add32(xi, mul16_32_q15((i16)mul16_16_q15(nf, g00), CA_PX(i - T0)));
+            y = add32(y, mul16_32_q15((i16)mul16_16_q15(nf, g01), add32(CA_PX(i - T0 + 1), CA_PX(i - T0 - 1))));
+            y = add32(y, mul16_32_q15((i16)mul16_16_q15(nf, g02), add32(CA_PX(i - T0 + 2), CA_PX(i - T0 - 2))));
+            y = add32(y, mul16_32_q15((i16)mul16_16_q15(f, g10), CA_PX(i - T1)));
+            y = add32(y, mul16_32_q15((i16)mul16_16_q15(f, g11), add32(CA_PX(i - T1 + 1), CA_PX(i - T1 - 1))));
+            y = add32(y, mul16_32_q15((i16)mul16_16_q15(f, g12), add32(CA_PX(i - T1 + 2), CA_PX(i - T1 - 2))));
+        } else if (g1 == 0) {
+            y = xi;
+        } else {
+            y = add32(xi, mul16_32_q15(g10, CA_PX(i - T1)));
+            y = add32(y, mul16_32_q15(g11, add32(CA_PX(i - T1 + 1), CA_PX(i - T1 - 1))));
+            y = add32(y, mul16_32_q15(g12, add32(CA_PX(i - T1 + 2), CA_PX(i - T1 - 2))));
+        }
+        F.in[c][OVL + i] = y;
+    }
+#undef CA_PX
+}
+
+struct PrefilterOut { int pf_on, pitch_index, qg; i32 gain1; };
+
+// run_prefilter (celt_encoder.c:1067-1193). `in_mem` = previous frame's last 120 filtered samples (or zero).
+CA_DEVFN PrefilterOut run_prefilter_wave(FrameLds &F, FrameCtx &fc, const i32 *in_mem, int prefilter_tapset,
+                                         int enabled, int nbAvailableBytes, int loss_rate)
+{
+    const int C = fc.C;
+    PrefilterOut o;
+    // pre[c] = [history | new]: keep the unfiltered new samples in xf
+    for (int c = 0; c < C; c++)
+        for (int i = lane(); i < FRAME; i += LANES) F.xf[c][i] = F.in[c][OVL + i];
+    wave_sync();
+    int pitch_index;
+    i32 gain1;
+    if (enabled) {
+        pitch_downsample_wave(F, fc);
+        pitch_index = pitch_search_wave(F);
+        pitch_index = MAXP - pitch_index;
+        gain1 = remove_doubling_wave(F, &pitch_index, fc.prefilter_period, fc.prefilter_gain);
+        if (pitch_index > MAXP - 2) pitch_index = MAXP - 2;
+        gain1 = (i16)mul16_16_q15(22938, gain1);                                    // QCONST16(.7f,15)
+        if (loss_rate > 2) gain1 = (i16)(gain1 >> 1);
+        if (loss_rate > 4) gain1 = (i16)(gain1 >> 1);
+        if (loss_rate > 8) gain1 = 0;
+    } else {
+        gain1 = 0;
+        pitch_index = MINP;
+    }
+    i32 pf_threshold = 6554;                                                         // QCONST16(.2f,15)
+    {
+        int d = pitch_index - fc.prefilter_period;
+        if (d < 0) d = -d;
+        if (d * 10 > pitch_index) pf_threshold += 6554;
+    }
+    if (nbAvailableBytes < 25) pf_threshold += 3277;
+    if (nbAvailableBytes < 35) pf_threshold += 3277;
+    if (fc.prefilter_gain > 13107) pf_threshold -= 3277;
+    if (fc.prefilter_gain > 18022) pf_threshold -= 3277;
+    pf_threshold = imax(pf_threshold, 6554);
+    if (gain1 < pf_threshold) {
+        gain1 = 0;
+        o.pf_on = 0;
+        o.qg = 0;
+    } else {
+        i32 d = gain1 - fc.prefilter_gain;
+        if ((d < 0 ? -d : d) < 3277) gain1 = fc.prefilter_gain;
+        int qg = ((gain1 + 1536) >> 10) / 3 - 1;
+        qg = imax(0, imin(7, qg));
+        gain1 = 3072 * (qg + 1);                                                     // QCONST16(0.09375f,15)*(qg+1)
+        o.pf_on = 1;
+        o.qg = qg;
+    }
+    fc.prefilter_period = imax(fc.prefilter_period, MINP);
+    for (int c = 0; c < C; c++) {
+        for (int i = lane(); i < OVL; i += LANES) F.in[c][i] = in_mem ? in_mem[c * OVL + i] : 0;
+        // shortMdctSize - overlap == 0, so only the cross-faded filter runs (celt_encoder.c:1168-1176)
+        comb_filter_wave(F, fc, c, fc.prefilter_period, pitch_index, (i16)neg32(fc.prefilter_gain),
+                         (i16)neg32(gain1), fc.prefilter_tapset, prefilter_tapset);
+    }
+    wave_sync();
+    o.gain1 = gain1;
+    o.pitch_index = pitch_index;
+    return o;
+}
+
+// ---- transient_analysis (celt_encoder.c:227-377), len = 1080 ---------------------------------------
+struct TransientOut { int is_transient, tf_chan; i32 tf_estimate; };
+
+CA_DEVFN TransientOut transient_analysis_wave(FrameLds &F, const FrameCtx &fc)
+{
+    const int C = fc.C, len = FRAME + OVL, len2 = len / 2;
+    // serial IIR/followers: lane c owns channel c
+    for (int c = lane(); c < C; c += LANES) {
+        i16 *tmp = F.s.trans[c];
+        i32 mem0 = 0, mem1 = 0;
+        for (int i = 0; i < len; i++) {
+            i32 x = F.in[c][i] >> 12;
+            i32 y = add32(mem0, x);
+            mem0 = sub32(add32(mem1, y), shl32(x, 1));
+            mem1 = sub32(x, y >> 1);
+            tmp[i] = (i16)(y >> 2);
+        }
+        for (int i = 0; i < 12; i++) tmp[i] = 0;
+        i32 mx = 0, mn = 0;
+        for (int i = 0; i < len; i++) { mx = imax(mx, tmp[i]); mn = imin(mn, tmp[i]); }
+        int shift = 14 - celt_ilog2(1 + imax(mx, -mn));
+        if (shift != 0)
+            for (int i = 0; i < len; i++) tmp[i] = (i16)shl16(tmp[i], shift);
+        i32 mean = 0;
+        mem0 = 0;
+        for (int i = 0; i < len2; i++) {
+            i32 x2 = (i16)pshr32(add32(mul16_16(tmp[2 * i], tmp[2 * i]), mul16_16(tmp[2 * i + 1], tmp[2 * i + 1])), 16);
+            mean = add32(mean, x2);
+            tmp[i] = (i16)(mem0 + pshr32(x2 - mem0, 4));
+            mem0 = tmp[i];
+        }
+        mem0 = 0;
+        i32 maxE = 0;
+        for (int i = len2 - 1; i >= 0; i--) {
+            tmp[i] = (i16)(mem0 + pshr32(tmp[i] - mem0, 3));
+            mem0 = tmp[i];
+            maxE = imax(maxE, mem0);
+        }
+        mean = mul16_16(celt_sqrt(mean), celt_sqrt(mul16_16(maxE, len2 >> 1)));
+        i32 norm = shl32(len2, 6 + 14) / add32(1, mean >> 1);
+        F.scal[4 + c] = norm;
+    }
+    wave_sync();
+    TransientOut o;
+    o.tf_chan = 0;
+    i32 mask_metric = 0;
+    for (int c = 0; c < C; c++) {
+        const i16 *tmp = F.s.trans[c];
+        i32 norm = F.scal[4 + c];
+        i32 p = 0;
+        for (int k = lane(); 12 + 4 * k < len2 - 5; k += LANES) {
+            int i = 12 + 4 * k;
+            i32 id = imax(0, imin(127, mul16_32_q15((i16)(tmp[i] + 1), norm)));
+            p += CLT_inv_table[id];
+        }
+        i32 unmask = wave_add(p);
+        unmask = 64 * unmask * 4 / (6 * (len2 - 17));
+        if (unmask > mask_metric) { o.tf_chan = c; mask_metric = unmask; }
+    }
+    o.is_transient = mask_metric > 200;
+    i32 tf_max = imax(0, (i16)(celt_sqrt(27 * mask_metric) - 42));
+    o.tf_estimate = (i16)celt_sqrt(imax(0, sub32(shl32(mul16_16(113, imin(163, tf_max)), 14), 37312528)));   // .0069 Q14, .139 Q28
+    wave_sync();
+    return o;
+}
+
+// ---- MDCTs of one frame (compute_mdcts, celt_encoder.c:418-461): in -> xf (as freq) ------------------
+CA_DEVFN void compute_mdcts_wave(FrameLds &F, const FrameCtx &fc, int shortBlocks)
+{
+    for (int c = 0; c < fc.C; c++) {
+        if (shortBlocks) {
+            const MdctTab T = mdct_global_tab<3>();
+            mdct_forward_wave<3, 8>(F.in[c], F.s.f2, F.xf[c], 1, T, lane());
+        } else {
+            const MdctTab T = mdct_global_tab<0>();
+            mdct_forward_wave<0, 1>(F.in[c], F.s.f2, F.xf[c], 1, T, lane());
+        }
+    }
+}
+
+// ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
+CA_DEVFN void band_energies_wave(FrameLds &F, const FrameCtx &fc, i16 *bandLogE)
+{
+    for (int c = 0; c < fc.C; c++) {
+        for (int b = 0; b < NB; b++) {
+            const int j0 = CLT_eband5ms[b] << LM3, j1 = CLT_eband5ms[b + 1] << LM3;
+            const i32 *X = F.xf[c];
+            i32 mx = 0, mn = 0;
+            for (int j = j0 + lane(); j < j1; j += LANES) { mx = imax(mx, X[j]); mn = imin(mn, X[j]); }
+            i32 maxval = imax(wave_max(mx), neg32(wave_min(mn)));
+            i32 E = 1;
+            if (maxval > 0) {
+                int shift = celt_ilog2(maxval) - 14 + (((CLT_logN400[b] >> 3) + LM3 + 1) >> 1);
+                i32 p = 0;
+                for (int j = j0 + lane(); j < j1; j += LANES) {
+                    i32 v = shift > 0 ? (i16)(X[j] >> shift) : (i16)shl32(X[j], -shift);
+                    p = mac16_16(p, v, v);
+                }
+                i32 sum = wave_add(p);
+                E = add32(1, vshr32(celt_sqrt(sum), -shift));
+            }
+            st0(&F.bandE[b + c * NB], E);
+            st0(&bandLogE[b + c * NB], (i16)(celt_log2(shl32(E, 2)) - shl16(CLT_eMeans[b], 6)));
+        }
+    }
+    wave_sync();
+}
+
+// ---- normalise_bands (bands.c:146-168): xf (freq) -> X (int16, aliases `in`) ------------------------
+CA_DEVFN void normalise_bands_wave(FrameLds &F, const FrameCtx &fc)
+{
+    i16 *X = frame_X(F);
+    for (int k = lane(); k < fc.C * NB; k += LANES) {
+        i32 bE = F.bandE[k];
+        int shift = celt_zlog2(bE) - 13;
+        i32 E = (i16)vshr32(bE, shift);                                              // opus_val16 E
+        F.normg[k] = (i16)celt_rcp(shl32(E, 3));
+        F.normshift[k] = (i8)shift;
+    }
+    wave_sync();
+    for (int c = 0; c < fc.C; c++)
+        for (int j = lane(); j < (CLT_eband5ms[NB] << LM3); j += LANES) {
+            int b = CLT_bin2band[j >> 3] + c * NB;
+            X[c * FRAME + j] = (i16)mul16_16_q15(vshr32(F.xf[c][j], F.normshift[b] - 1), F.normg[b]);
+        }
+    wave_sync();
+}
+
+}  // namespace ca

@@ -1,0 +1,72 @@
+// celt_state.h -- per-stream encoder state and per-batch parameters of the CELT frame path.
+//
+// CeltEncState is the pointer-free equivalent of everything the reference keeps between frames for one
+// stream: the fields of `struct OpusCustomEncoder` past ENCODER_RESET_START plus its trailing arrays
+// (opus-fix/celt/celt_encoder.c:82-128) and the Opus layer's dc_reject memory (src/opus_encoder.c:86,
+// hp_mem). It lives in HBM (one record per stream); a frame kernel loads it, encodes one 20 ms frame
+// and stores it back. A NULL state pointer means "every frame is the first frame of its own stream"
+// (SURVEY.md 8d): the reset values below are then materialised in registers/LDS and nothing is stored.
+#pragma once
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUSGPU_CELT_NBANDS 21
+#define OPUSGPU_CELT_OVERLAP 120
+#define OPUSGPU_CELT_FRAME 960
+#define OPUSGPU_COMBFILTER_MAXPERIOD 1024
+#define OPUSGPU_COMBFILTER_MINPERIOD 15
+
+typedef struct opusgpu_celt_state {
+    /* Opus layer (src/opus_encoder.c) */
+    int32_t hp_mem[4];              /* dc_reject memories, 2 per channel */
+    /* CELT layer, scalars (celt_encoder.c:82-120) */
+    uint32_t rng;
+    int32_t spread_decision;
+    int32_t delayedIntra;
+    int32_t tonal_average;
+    int32_t lastCodedBands;
+    int32_t hf_average;
+    int32_t tapset_decision;
+    int32_t prefilter_period;
+    int32_t prefilter_gain;         /* opus_val16 */
+    int32_t prefilter_tapset;
+    int32_t consec_transient;
+    int32_t preemph_memE[2];
+    int32_t vbr_reservoir;
+    int32_t vbr_drift;
+    int32_t vbr_offset;
+    int32_t vbr_count;
+    int32_t overlap_max;
+    int32_t stereo_saving;          /* opus_val16 */
+    int32_t intensity;
+    int32_t spec_avg;               /* opus_val16 */
+    int32_t reserved[5];
+    /* CELT layer, arrays (celt_encoder.c:123-127) */
+    int16_t oldBandE[2 * OPUSGPU_CELT_NBANDS];
+    int16_t oldLogE[2 * OPUSGPU_CELT_NBANDS];
+    int16_t oldLogE2[2 * OPUSGPU_CELT_NBANDS];
+    int16_t pad16[2];
+    int32_t in_mem[2 * OPUSGPU_CELT_OVERLAP];
+    int32_t prefilter_mem[2 * OPUSGPU_COMBFILTER_MAXPERIOD];
+} opusgpu_celt_state;
+
+/* Encoder configuration shared by all frames of a batch: what opus_encoder_create() + the ctl sequence
+ * of opus_demo (src/opus_demo.c:531-543) establish. Only CELT-only 48 kHz 20 ms frames are supported
+ * (OPUS_APPLICATION_RESTRICTED_LOWDELAY). */
+typedef struct opusgpu_celt_config {
+    int32_t channels;          /* 2 (stereo) or 1 */
+    int32_t bitrate;           /* OPUS_SET_BITRATE, bits/s */
+    int32_t vbr;               /* OPUS_SET_VBR */
+    int32_t constrained_vbr;   /* OPUS_SET_VBR_CONSTRAINT */
+    int32_t complexity;        /* OPUS_SET_COMPLEXITY 0..10 */
+    int32_t lsb_depth;         /* OPUS_SET_LSB_DEPTH (16 for int16 input) */
+    int32_t loss_rate;         /* OPUS_SET_PACKET_LOSS_PERC */
+    int32_t max_data_bytes;    /* opus_encode()'s max_data_bytes (opus_demo: 1500) */
+} opusgpu_celt_config;
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,6 +1,6 @@
-// device_tables.h -- the generated CELT tables (celt_tables.h) as device-global constants.
-// One definition per translation unit that includes it; arrays are tiny and L2-resident.
+// device_tables.h -- the generated CELT tables (celt_tables.h) as device-global constants
+// (plain static const arrays in the CA_HOST_EMU build). Arrays are tiny and L2-resident.
 #pragma once
-#include <hip/hip_runtime.h>
-#define CLT_TABLE_QUAL static __device__ const
+#include "wave.h"
+#define CLT_TABLE_QUAL CA_DEVICE_CONST
 #include "celt_tables.h"

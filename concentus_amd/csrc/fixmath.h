@@ -5,29 +5,18 @@
 // integer multiplier (v_mul_i32_i24 / v_mad_i32_i24) instead of the quarter-rate 32x32 multiplier;
 // wrap-around on overflow is two's complement, as in the reference binary.
 #pragma once
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-
-#define CA_DEV __device__ __forceinline__
+#include "wave.h"
 
 namespace ca {
 
 typedef int16_t i16;
 typedef uint16_t u16;
 typedef uint8_t u8;
+typedef int8_t i8;
 typedef int32_t i32;
 typedef uint32_t u32;
 typedef int64_t i64;
 typedef uint64_t u64;
-
-// Order LDS traffic between the lanes of ONE wavefront (each wave owns its frame; LDS operations of
-// a wave execute in issue order, so only the compiler needs to be fenced).
-CA_DEV void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // fixed_generic.h:46 MULT16_32_Q15(a,b) = (a*(b>>16))<<1 + (a*(b&0xffff))>>15
 CA_DEV i32 mul16_32_q15(i32 a16, i32 b)

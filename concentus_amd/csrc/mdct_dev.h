@@ -12,37 +12,51 @@
 
 namespace ca {
 
-// ---- LDS-resident constant tables (staged once per workgroup) ------------------------------------
-// "A" holds the tables of the long transform in use (shift 0 in the frame kernels), "B" those of the
-// short one (shift 3); trig entries are packed (trig[i] & 0xffff) | (trig[N4+i] << 16).
-struct MdctLds {
-    u32 tw[480];        // fft twiddles, packed (r & 0xffff) | (i << 16)   static_modes_fixed.h:104
-    u32 trigA[480];
-    u32 trigB[60];
-    u16 bitrevA[480];
-    u16 bitrevB[64];
-    i16 window[120];    // window120
+// ---- constant tables --------------------------------------------------------------------------------
+// The transforms read their tables through an MdctTab of pointers, so a kernel may point it at the
+// device-global packed tables (celt_tables.h) or at copies it staged into LDS.
+//   tw      fft twiddles, packed (r & 0xffff) | (i << 16)              static_modes_fixed.h:104
+//   trig    packed (trig[i] & 0xffff) | (trig[N4+i] << 16) for the shift in use (mdct.c:141-146)
+//   bitrev  fft_bitrev{480,240,120,60} for the shift in use
+struct MdctTab {
+    const u32 *tw;
+    const u32 *trig;
+    const i16 *bitrev;
+    const i16 *window;
 };
 
 template <int SHIFT>
-CA_DEV void mdct_stage_shift(u32 *trig, u16 *bitrev, int tid, int nthreads)
+CA_DEV MdctTab mdct_global_tab()
 {
-    constexpr int N4 = 480 >> SHIFT;
-    constexpr int OFF = SHIFT == 0 ? 0 : SHIFT == 1 ? 960 : SHIFT == 2 ? 1440 : 1680;   // mdct.c:141-146
-    const i16 *br = SHIFT == 0 ? CLT_fft_bitrev480 : SHIFT == 1 ? CLT_fft_bitrev240
-                  : SHIFT == 2 ? CLT_fft_bitrev120 : CLT_fft_bitrev60;
-    const i16 *t = CLT_mdct_trig960 + OFF;
-    for (int i = tid; i < N4; i += nthreads) {
-        trig[i] = (u32)(uint16_t)t[i] | ((u32)(uint16_t)t[N4 + i] << 16);
-        bitrev[i] = (u16)br[i];
-    }
+    MdctTab t;
+    t.tw = CLT_fft_tw_packed;
+    t.trig = SHIFT == 0 ? CLT_mdct_trig_packed0 : SHIFT == 1 ? CLT_mdct_trig_packed1
+           : SHIFT == 2 ? CLT_mdct_trig_packed2 : CLT_mdct_trig_packed3;
+    t.bitrev = SHIFT == 0 ? CLT_fft_bitrev480 : SHIFT == 1 ? CLT_fft_bitrev240
+             : SHIFT == 2 ? CLT_fft_bitrev120 : CLT_fft_bitrev60;
+    t.window = CLT_window120;
+    return t;
 }
 
-CA_DEV void mdct_stage_common(MdctLds &L, int tid, int nthreads)
+// LDS copy of one shift's tables (staged once per workgroup by the MDCT-only kernels).
+struct MdctLds {
+    u32 tw[480];
+    u32 trig[480];
+    i16 bitrev[480];
+    i16 window[120];
+};
+
+template <int SHIFT>
+CA_DEV MdctTab mdct_stage_tables(MdctLds &L, int tid, int nthreads)
 {
-    for (int i = tid; i < 480; i += nthreads)
-        L.tw[i] = (u32)(uint16_t)CLT_fft_twiddles480[2 * i] | ((u32)(uint16_t)CLT_fft_twiddles480[2 * i + 1] << 16);
-    for (int i = tid; i < 120; i += nthreads) L.window[i] = CLT_window120[i];
+    constexpr int N4 = 480 >> SHIFT;
+    MdctTab g = mdct_global_tab<SHIFT>();
+    for (int i = tid; i < 480; i += nthreads) L.tw[i] = g.tw[i];
+    for (int i = tid; i < N4; i += nthreads) { L.trig[i] = g.trig[i]; L.bitrev[i] = g.bitrev[i]; }
+    for (int i = tid; i < 120; i += nthreads) L.window[i] = g.window[i];
+    MdctTab t;
+    t.tw = L.tw; t.trig = L.trig; t.bitrev = L.bitrev; t.window = L.window;
+    return t;
 }
 
 // ---- complex helpers ------------------------------------------------------------------------------
@@ -69,7 +83,7 @@ template <int NFFT, int B>
 CA_DEV void fft_radix4_first(int2 *x, int lane)     // kiss_fft.c:123-145, m == 1
 {
     constexpr int CNT = B * NFFT / 4;
-    for (int idx = lane; idx < CNT; idx += 64) {
+    for (int idx = lane; idx < CNT; idx += LANES) {
         int2 *f = x + 4 * idx;
         cpx x0 = ld(f), x1 = ld(f + 1), x2 = ld(f + 2), x3 = ld(f + 3);
         cpx s0 = c_sub(x0, x2);
@@ -91,7 +105,7 @@ CA_DEV void fft_radix2_m4(int2 *x, int lane)        // kiss_fft.c:72-107, m == 4
     // one lane per (group, k) pair: k selects which of the four fixed rotations applies
     constexpr int CNT = B * NFFT / 2;
     constexpr i32 TW = 23170;
-    for (int idx = lane; idx < CNT; idx += 64) {
+    for (int idx = lane; idx < CNT; idx += LANES) {
         int g = idx >> 2, k = idx & 3;
         int2 *f = x + 8 * g + k;
         cpx a = ld(f), b = ld(f + 4), t;
@@ -118,7 +132,7 @@ CA_DEV void fft_radix4(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:146-176
     constexpr int G = NFFT / (4 * M);
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 4;
-    for (int idx = lane; idx < CNT; idx += 64) {
+    for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
         int2 *f = x + blk * NFFT + g * 4 * M + j;
@@ -144,7 +158,7 @@ CA_DEV void fft_radix3(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:185-241
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 3;
     constexpr i32 EPI3 = -28378;
-    for (int idx = lane; idx < CNT; idx += 64) {
+    for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
         int2 *f = x + blk * NFFT + g * 3 * M + j;
@@ -169,7 +183,7 @@ CA_DEV void fft_radix5(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:245-322
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 5;
     constexpr i32 YAR = 10126, YAI = -31164, YBR = -26510, YBI = -19261;
-    for (int idx = lane; idx < CNT; idx += 64) {
+    for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, u = r % M;
         int2 *f = x + blk * NFFT + g * 5 * M + u;
@@ -226,22 +240,23 @@ CA_DEV void fft_wave(int2 *x, const u32 *tw, int lane)
 // ---- MDCT ------------------------------------------------------------------------------------------
 // Forward MDCT of B blocks (hop N2, block b reads sin[b*N2 .. b*N2+N2+120)); coefficient k of block b
 // goes to dst[(k*B + b) * dstride] -- the interleaved layout of compute_mdcts (celt_encoder.c:441).
-// trig/bitrev are the packed LDS tables for this SHIFT. dst may be LDS or global; it may alias sin
+// T holds the tables for this SHIFT. dst may be LDS or global; it may alias sin
 // (all reads of sin complete before the first write to dst).      Reference: mdct.c:121-259.
 template <int SHIFT, int B>
-CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, const MdctLds &L,
-                              const u32 *trig, const u16 *bitrev, int lane)
+CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, const MdctTab &T, int lane)
 {
+    const u32 *trig = T.trig;
+    const i16 *bitrev = T.bitrev;
     constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
     constexpr int OV = 120, OV2 = 60, Q = 30;
     constexpr int SCALE_SHIFT = (8 - SHIFT) - 1;                     // st->scale_shift - 1
-    for (int idx = lane; idx < B * N4; idx += 64) {
+    for (int idx = lane; idx < B * N4; idx += LANES) {
         int blk = idx / N4, i = idx % N4;
         const i32 *in = sin + blk * N2;
         int a = OV2 + 2 * i, b = N2 - 1 + OV2 - 2 * i;
         i32 re, im;
         if (i < Q) {                                                  // mdct.c:162-175
-            i32 w1 = L.window[OV2 + 2 * i], w2 = L.window[OV2 - 1 - 2 * i];
+            i32 w1 = T.window[OV2 + 2 * i], w2 = T.window[OV2 - 1 - 2 * i];
             re = add32(mul16_32_q15(w2, in[a + N2]), mul16_32_q15(w1, in[b]));
             im = sub32(mul16_32_q15(w1, in[a]), mul16_32_q15(w2, in[b - N2]));
         } else if (i < N4 - Q) {                                      // mdct.c:178-189
@@ -249,7 +264,7 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
             im = in[a];
         } else {                                                      // mdct.c:190-203
             int k = i - (N4 - Q);
-            i32 w1 = L.window[2 * k], w2 = L.window[OV - 1 - 2 * k];
+            i32 w1 = T.window[2 * k], w2 = T.window[OV - 1 - 2 * k];
             re = add32(neg32(mul16_32_q15(w1, in[a - N2])), mul16_32_q15(w2, in[b]));
             im = add32(mul16_32_q15(w2, in[a]), mul16_32_q15(w1, in[b + N2]));
         }
@@ -262,8 +277,8 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
         f2[blk * NFFT + bitrev[i]] = make_int2(yr, yi);
     }
     wave_sync();
-    fft_wave<SHIFT, B>(f2, L.tw, lane);
-    for (int idx = lane; idx < B * N4; idx += 64) {                  // mdct.c:237-257
+    fft_wave<SHIFT, B>(f2, T.tw, lane);
+    for (int idx = lane; idx < B * N4; idx += LANES) {                  // mdct.c:237-257
         int blk = idx / N4, i = idx % N4;
         cpx f = ld(f2 + blk * NFFT + i);
         u32 t = trig[i];
@@ -278,12 +293,13 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
 // out[b*N2 + 60 .. b*N2 + 60 + N2) and TDAC-mixes out[b*N2 .. b*N2+120) (the first 60 samples of
 // block 0 are the previous frame's tail). src must not alias out.    Reference: mdct.c:263-363.
 template <int SHIFT, int B>
-CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, const MdctLds &L,
-                               const u32 *trig, const u16 *bitrev, int lane)
+CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, const MdctTab &T, int lane)
 {
+    const u32 *trig = T.trig;
+    const i16 *bitrev = T.bitrev;
     constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
     constexpr int OV = 120, OV2 = 60;
-    for (int idx = lane; idx < B * N4; idx += 64) {                  // mdct.c:283-304
+    for (int idx = lane; idx < B * N4; idx += LANES) {                  // mdct.c:283-304
         int blk = idx / N4, i = idx % N4;
         i32 x1 = src[((2 * i) * B + blk) * sstride];
         i32 x2 = src[((N2 - 1 - 2 * i) * B + blk) * sstride];
@@ -294,11 +310,11 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
         f2[blk * NFFT + bitrev[i]] = make_int2(yi, yr);              // re/im swapped: FFT as IFFT
     }
     wave_sync();
-    fft_wave<SHIFT, B>(f2, L.tw, lane);
+    fft_wave<SHIFT, B>(f2, T.tw, lane);
     // post-rotate + de-shuffle (mdct.c:310-342). The reference walks the buffer from both ends in
     // place; element k always lands as y[2k] = yr(k), y[2(N4-1-k)+1] = yi(k) with twiddles
     // trig[k], trig[N4+k], which is what each lane computes here.
-    for (int idx = lane; idx < B * N4; idx += 64) {
+    for (int idx = lane; idx < B * N4; idx += LANES) {
         int blk = idx / N4, k = idx % N4;
         cpx f = ld(f2 + blk * NFFT + k);
         i32 re = f.i, im = f.r;
@@ -309,11 +325,11 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
         y[2 * (N4 - 1 - k) + 1] = sub32(CA_SMUL(re, t1), CA_SMUL(im, t0));
     }
     wave_sync();
-    for (int idx = lane; idx < B * OV2; idx += 64) {                 // mdct.c:345-361 TDAC mirror
+    for (int idx = lane; idx < B * OV2; idx += LANES) {                 // mdct.c:345-361 TDAC mirror
         int blk = idx / OV2, i = idx % OV2;
         i32 *o = out + blk * N2;
         i32 x1 = o[OV - 1 - i], x2 = o[i];
-        i32 w1 = L.window[i], w2 = L.window[OV - 1 - i];
+        i32 w1 = T.window[i], w2 = T.window[OV - 1 - i];
         o[i] = sub32(mul16_32_q15(w2, x2), mul16_32_q15(w1, x1));
         o[OV - 1 - i] = add32(mul16_32_q15(w1, x2), mul16_32_q15(w2, x1));
     }

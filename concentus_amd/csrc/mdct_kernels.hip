@@ -24,15 +24,14 @@ __global__ __launch_bounds__(64) void mdct_forward_kernel(const i32 *__restrict_
     constexpr int B = 1 << SHIFT;
     __shared__ MdctFwdLds S;
     const int lane = threadIdx.x;
-    mdct_stage_common(S.tab, lane, 64);
-    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
     wave_sync();
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
         const int4 *src = reinterpret_cast<const int4 *>(sig + (size_t)t * 1080);
         int4 *b4 = reinterpret_cast<int4 *>(S.buf);
         for (int i = lane; i < 270; i += 64) b4[i] = src[i];
         wave_sync();
-        mdct_forward_wave<SHIFT, B>(S.buf, S.f2, S.buf, 1, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+        mdct_forward_wave<SHIFT, B>(S.buf, S.f2, S.buf, 1, T, lane);
         int4 *dst = reinterpret_cast<int4 *>(freq + (size_t)t * 960);
         for (int i = lane; i < 240; i += 64) dst[i] = b4[i];
         wave_sync();
@@ -53,8 +52,7 @@ __global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict
     constexpr int B = 1 << SHIFT;
     __shared__ MdctBwdLds S;
     const int lane = threadIdx.x;
-    mdct_stage_common(S.tab, lane, 64);
-    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
     wave_sync();
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
         const int4 *src = reinterpret_cast<const int4 *>(freq + (size_t)t * 960);
@@ -65,7 +63,7 @@ __global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict
         int4 *o4 = reinterpret_cast<int4 *>(S.out);
         if (lane < 15) o4[lane] = io[lane];
         wave_sync();
-        mdct_backward_wave<SHIFT, B>(S.coef, 1, S.f2, S.out, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+        mdct_backward_wave<SHIFT, B>(S.coef, 1, S.f2, S.out, T, lane);
         for (int i = lane; i < 255; i += 64) io[i] = o4[i];      // 1020 samples; [1020,1080) untouched
         wave_sync();
     }
@@ -78,11 +76,10 @@ __global__ __launch_bounds__(64) void mdct_forward_single_kernel(const i32 *in, 
     __shared__ MdctFwdLds S;
     const int lane = threadIdx.x;
     constexpr int N2 = 960 >> SHIFT;
-    mdct_stage_common(S.tab, lane, 64);
-    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
     for (int i = lane; i < N2 + 120; i += 64) S.buf[i] = in[i];
     wave_sync();
-    mdct_forward_wave<SHIFT, 1>(S.buf, S.f2, out, stride, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+    mdct_forward_wave<SHIFT, 1>(S.buf, S.f2, out, stride, T, lane);
 }
 
 template <int SHIFT>
@@ -91,12 +88,11 @@ __global__ __launch_bounds__(64) void mdct_backward_single_kernel(const i32 *in,
     __shared__ MdctBwdLds S;
     const int lane = threadIdx.x;
     constexpr int N2 = 960 >> SHIFT;
-    mdct_stage_common(S.tab, lane, 64);
-    mdct_stage_shift<SHIFT>(S.tab.trigA, S.tab.bitrevA, lane, 64);
+    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
     for (int i = lane; i < N2; i += 64) S.coef[i] = in[i * stride];
     for (int i = lane; i < 120; i += 64) S.out[i] = out[i];
     wave_sync();
-    mdct_backward_wave<SHIFT, 1>(S.coef, 1, S.f2, S.out, S.tab, S.tab.trigA, S.tab.bitrevA, lane);
+    mdct_backward_wave<SHIFT, 1>(S.coef, 1, S.f2, S.out, T, lane);
     for (int i = lane; i < N2 + 60; i += 64) out[i] = S.out[i];
 }
 

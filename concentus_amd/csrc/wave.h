@@ -1,0 +1,97 @@
+// wave.h -- the execution abstraction the frame kernels are written against.
+//
+// On gfx950 one 64-lane wavefront cooperates on one Opus frame: data-parallel loops are strided over
+// the lanes (`for (i = lane(); i < n; i += LANES)`), scalar control code runs redundantly (and
+// identically) on all lanes, and `wave_sync()` orders LDS traffic between the lanes of the wave.
+//
+// With -DCA_HOST_EMU the same sources compile as plain C++ with LANES == 1 (every collective becomes
+// the identity). That build exists ONLY so tests can single-step the kernel logic on a CPU
+// (tests/emu); it is not a product path and nothing in concentus_amd/ loads it.
+#pragma once
+#include <stdint.h>
+
+#if defined(CA_HOST_EMU)
+#include <stdio.h>
+#if defined(CA_HOST_EMU_TRACE)
+#define CA_TRACE(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); } while (0)
+#else
+#define CA_TRACE(...) do {} while (0)
+#endif
+// debug taps (host emulation only): record a named snapshot of an intermediate array
+extern "C" void emu_tap(const char *name, const void *p, int bytes);
+#define CA_TAP(name, p, bytes) emu_tap(name, p, bytes)
+#define CA_DEV static inline
+#define CA_HOSTDEV static inline
+#define CA_DEVICE_CONST static const
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline int2 make_int2(int x, int y) { int2 v = {x, y}; return v; }
+static inline int __mul24(int a, int b)
+{
+    int32_t sa = (int32_t)((uint32_t)a << 8) >> 8, sb = (int32_t)((uint32_t)b << 8) >> 8;
+    return (int32_t)((uint32_t)sa * (uint32_t)sb);
+}
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+#else
+#include <hip/hip_runtime.h>
+#define CA_DEV __device__ __forceinline__
+#define CA_HOSTDEV __host__ __device__ __forceinline__
+#define CA_DEVICE_CONST static __device__ const
+#define CA_TRACE(...) do {} while (0)
+#define CA_TAP(name, p, bytes) do {} while (0)
+#endif
+
+namespace ca {
+
+#if defined(CA_HOST_EMU)
+enum { LANES = 1 };
+CA_DEV int lane() { return 0; }
+CA_DEV void wave_sync() {}
+template <class T> CA_DEV T shfl_xor(T v, int) { return v; }
+template <class T> CA_DEV T bcast(T v, int) { return v; }
+#else
+enum { LANES = 64 };
+CA_DEV int lane() { return (int)(threadIdx.x & 63); }
+// LDS operations of one wave execute in issue order, so ordering between its lanes only needs the
+// compiler fenced (verified in the ISA: no s_barrier, no extra waitcnt).
+CA_DEV void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class T> CA_DEV T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+template <class T> CA_DEV T bcast(T v, int src) { return __shfl(v, src, 64); }
+#endif
+
+// All-lanes reductions (result valid in every lane).
+CA_DEV int32_t wave_add(int32_t v)
+{
+    for (int m = LANES >> 1; m > 0; m >>= 1) v = (int32_t)((uint32_t)v + (uint32_t)shfl_xor(v, m));
+    return v;
+}
+CA_DEV int32_t wave_max(int32_t v)
+{
+    for (int m = LANES >> 1; m > 0; m >>= 1) { int32_t o = shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+CA_DEV int32_t wave_min(int32_t v)
+{
+    for (int m = LANES >> 1; m > 0; m >>= 1) { int32_t o = shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
+CA_DEV uint32_t wave_or(uint32_t v)
+{
+    for (int m = LANES >> 1; m > 0; m >>= 1) v |= shfl_xor(v, m);
+    return v;
+}
+CA_DEV int64_t wave_add64(int64_t v)
+{
+    for (int m = LANES >> 1; m > 0; m >>= 1) {
+        uint32_t lo = shfl_xor((uint32_t)v, m), hi = shfl_xor((uint32_t)((uint64_t)v >> 32), m);
+        v = (int64_t)((uint64_t)v + (((uint64_t)hi << 32) | lo));
+    }
+    return v;
+}
+
+}  // namespace ca

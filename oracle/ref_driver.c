@@ -75,3 +75,77 @@ void refdrv_mdct_batch(const int32_t *sig_in, int32_t *freq, int32_t *sig_out, l
     free(th);
     free(jobs);
 }
+
+/* ---- opus_encode() batches --------------------------------------------------------------------------
+ * Drives the reference's public API exactly as opus_demo does (src/opus_demo.c:519-543):
+ * opus_encoder_create(48000, ch, OPUS_APPLICATION_RESTRICTED_LOWDELAY) + the ctl sequence, then
+ * opus_encode(enc, pcm, 960, data, max_data_bytes) and OPUS_GET_FINAL_RANGE per frame.
+ * Frames are stream-major: frame f of stream s is at index s*frames_per_stream + f; a new encoder is
+ * created per stream, so frames_per_stream == 1 gives SURVEY 8d's "independent first frames".
+ * Request codes: include/opus_defines.h:130-167. */
+typedef struct OpusEncoder OpusEncoder;
+extern OpusEncoder *opus_encoder_create(int32_t Fs, int channels, int application, int *error);
+extern int opus_encoder_ctl(OpusEncoder *st, int request, ...);
+extern int32_t opus_encode(OpusEncoder *st, const int16_t *pcm, int frame_size, unsigned char *data, int32_t max_data_bytes);
+extern void opus_encoder_destroy(OpusEncoder *st);
+
+typedef struct {
+    int32_t channels, bitrate, vbr, constrained_vbr, complexity, lsb_depth, loss_rate, max_data_bytes;
+} refdrv_config;   /* same layout as opusgpu_celt_config */
+
+typedef struct {
+    const refdrv_config *cfg; const int16_t *pcm; unsigned char *out; int out_stride; int *out_len; uint32_t *out_rng;
+    long first_stream, nstreams; int frames_per_stream;
+} enc_job;
+
+static void *enc_worker(void *arg)
+{
+    enc_job *j = (enc_job *)arg;
+    const refdrv_config *c = j->cfg;
+    for (long s = j->first_stream; s < j->first_stream + j->nstreams; s++) {
+        int err = 0;
+        OpusEncoder *enc = opus_encoder_create(48000, c->channels, 2051, &err);
+        if (!enc) continue;
+        opus_encoder_ctl(enc, 4002, c->bitrate);          /* OPUS_SET_BITRATE */
+        opus_encoder_ctl(enc, 4008, -1000);               /* OPUS_SET_BANDWIDTH(OPUS_AUTO) */
+        opus_encoder_ctl(enc, 4006, c->vbr);              /* OPUS_SET_VBR */
+        opus_encoder_ctl(enc, 4020, c->constrained_vbr);  /* OPUS_SET_VBR_CONSTRAINT */
+        opus_encoder_ctl(enc, 4010, c->complexity);       /* OPUS_SET_COMPLEXITY */
+        opus_encoder_ctl(enc, 4012, 0);                   /* OPUS_SET_INBAND_FEC */
+        opus_encoder_ctl(enc, 4022, -1000);               /* OPUS_SET_FORCE_CHANNELS(OPUS_AUTO) */
+        opus_encoder_ctl(enc, 4016, 0);                   /* OPUS_SET_DTX */
+        opus_encoder_ctl(enc, 4014, c->loss_rate);        /* OPUS_SET_PACKET_LOSS_PERC */
+        opus_encoder_ctl(enc, 4036, c->lsb_depth);        /* OPUS_SET_LSB_DEPTH */
+        opus_encoder_ctl(enc, 4040, 5000);                /* OPUS_SET_EXPERT_FRAME_DURATION(OPUS_FRAMESIZE_ARG) */
+        for (int f = 0; f < j->frames_per_stream; f++) {
+            long n = s * j->frames_per_stream + f;
+            j->out_len[n] = opus_encode(enc, j->pcm + n * 960 * c->channels, 960, j->out + n * (long)j->out_stride,
+                                        c->max_data_bytes < j->out_stride ? c->max_data_bytes : j->out_stride);
+            opus_encoder_ctl(enc, 4031, &j->out_rng[n]);  /* OPUS_GET_FINAL_RANGE */
+        }
+        opus_encoder_destroy(enc);
+    }
+    return NULL;
+}
+
+void refdrv_encode_frames(const refdrv_config *cfg, const int16_t *pcm, long nframes, int frames_per_stream,
+                          unsigned char *out, int out_stride, int *out_len, uint32_t *out_rng, int threads)
+{
+    long nstreams = nframes / frames_per_stream;
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    enc_job *jobs = (enc_job *)malloc(sizeof(enc_job) * threads);
+    long per = (nstreams + threads - 1) / threads;
+    int used = 0;
+    for (int i = 0; i < threads; i++) {
+        long first = (long)i * per;
+        if (first >= nstreams) break;
+        long cnt = nstreams - first < per ? nstreams - first : per;
+        jobs[i] = (enc_job){cfg, pcm, out, out_stride, out_len, out_rng, first, cnt, frames_per_stream};
+        pthread_create(&th[i], NULL, enc_worker, &jobs[i]);
+        used++;
+    }
+    for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
+    free(th);
+    free(jobs);
+}

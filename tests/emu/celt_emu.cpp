@@ -1,0 +1,60 @@
+// tests/emu/celt_emu.cpp -- TEST INFRASTRUCTURE: host build of the frame-kernel sources with
+// CA_HOST_EMU (one "lane"), so the kernel logic can be single-stepped and compared against the
+// reference on a CPU. Not a product path: concentus_amd/ never loads this library.
+#define CA_HOST_EMU 1
+#include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+static std::map<std::string, std::vector<unsigned char>> g_taps;
+extern "C" void emu_tap(const char *name, const void *p, int bytes)
+{
+    g_taps[name].assign((const unsigned char *)p, (const unsigned char *)p + bytes);
+}
+extern "C" int emu_tap_get(const char *name, void *out, int cap)
+{
+    auto it = g_taps.find(name);
+    if (it == g_taps.end()) return -1;
+    int n = (int)it->second.size();
+    memcpy(out, it->second.data(), n < cap ? n : cap);
+    return n;
+}
+#include "../../concentus_amd/csrc/celt_enc.h"
+
+using namespace ca;
+
+extern "C" int emu_celt_encode_frames(const opusgpu_celt_config *cfg, opusgpu_celt_state *states /* or NULL */,
+                                      const int16_t *pcm, int nframes, int frames_per_stream,
+                                      unsigned char *out, int out_stride, int *out_len, uint32_t *out_rng)
+{
+    // frames are laid out stream-major: frame f of stream s at index s*frames_per_stream + f
+    FrameLds *F = (FrameLds *)aligned_alloc(64, sizeof(FrameLds));
+    const int C = cfg->channels;
+    for (int n = 0; n < nframes; n++) {
+        memset(F, 0xAB, sizeof(FrameLds));      // poison: catch reads of never-written LDS
+        opusgpu_celt_state *st = states ? &states[n / frames_per_stream] : NULL;
+        FrameResult r = celt_encode_frame(*F, *cfg, st, st, pcm + (size_t)n * 960 * C, out + (size_t)n * out_stride);
+        out_len[n] = r.bytes;
+        out_rng[n] = r.final_range;
+    }
+    free(F);
+    return 0;
+}
+
+extern "C" int emu_sizeof_state(void) { return (int)sizeof(opusgpu_celt_state); }
+extern "C" int emu_sizeof_frame_lds(void) { return (int)sizeof(FrameLds); }
+
+// MDCT device functions under emulation (same sources as the MDCT-only kernels)
+extern "C" void emu_mdct_forward(const int32_t *in, int32_t *out, int shift)
+{
+    static int2 f2[480];
+    if (shift == 0) { MdctTab T = mdct_global_tab<0>(); mdct_forward_wave<0, 1>(in, f2, out, 1, T, 0); }
+    else { MdctTab T = mdct_global_tab<3>(); mdct_forward_wave<3, 8>(in, f2, out, 1, T, 0); }
+}
+extern "C" void emu_mdct_backward(const int32_t *coef, int32_t *out, int shift)
+{
+    static int2 f2[480];
+    if (shift == 0) { MdctTab T = mdct_global_tab<0>(); mdct_backward_wave<0, 1>(coef, 1, f2, out, T, 0); }
+    else { MdctTab T = mdct_global_tab<3>(); mdct_backward_wave<3, 8>(coef, 1, f2, out, T, 0); }
+}

@@ -41,3 +41,17 @@ def test_emitted_header_is_current(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert p.read_text() == open(os.path.join(root, "concentus_amd", "csrc", "celt_tables.h")).read()
     assert p.read_text() == open(os.path.join(root, "oracle", "oracle_tables.h")).read()
+
+
+def test_literal_tables_match_reference():
+    """Hand-tuned tables listed literally in tools/gen_tables.py vs the reference's .rodata."""
+    fmt = {"int8_t": "b", "uint8_t": "B", "int16_t": "h", "uint32_t": "I"}
+    ref_name = {"comb_gains": "gains", "tell_frac_correction": "correction", "log2_frac_table": "LOG2_FRAC_TABLE"}
+    as_int = {"second_check", "ordery_table"}      # `int` arrays in the reference
+    for name, ctype, vals, _cite in g.LITERAL_TABLES:
+        if name.endswith("_icdf") and name != "small_energy_icdf":
+            f = "B"
+        else:
+            f = "i" if name in as_int else fmt[ctype]
+        got = reflib.static_table(ref_name.get(name, name), f, len(vals))
+        assert got == list(vals), name

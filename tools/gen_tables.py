@@ -336,6 +336,87 @@ BAND_ALLOCATION = [
     200, 200, 200, 200, 200, 200, 200, 200, 198, 193, 188, 183, 178, 173, 168, 163, 158, 153, 148, 129, 104,
 ]
 
+# ---------------------------------------------------------------- literal spec tables (part 2)
+# Hand-tuned constants of the codec; (name, C type, values, reference location)
+LITERAL_TABLES = [
+    ("eMeans", "int8_t", [
+        103, 100, 92, 85, 81, 77, 72, 70, 78, 75, 73, 71, 78, 74, 69, 72, 70, 74, 76, 71, 60, 60,
+        60, 60, 60,
+    ], "celt/quant_bands.c:46  mean band energy, Q4"),
+    ("e_prob_model", "uint8_t", [
+        72, 127, 65, 129, 66, 128, 65, 128, 64, 128, 62, 128, 64, 128, 64, 128, 92, 78, 92, 79, 92,
+        78, 90, 79, 116, 41, 115, 40, 114, 40, 132, 26, 132, 26, 145, 17, 161, 12, 176, 10, 177, 11,
+        24, 179, 48, 138, 54, 135, 54, 132, 53, 134, 56, 133, 55, 132, 55, 132, 61, 114, 70, 96, 74,
+        88, 75, 88, 87, 74, 89, 66, 91, 67, 100, 59, 108, 50, 120, 40, 122, 37, 97, 43, 78, 50, 83,
+        78, 84, 81, 88, 75, 86, 74, 87, 71, 90, 73, 93, 74, 93, 74, 109, 40, 114, 36, 117, 34, 117,
+        34, 143, 17, 145, 18, 146, 19, 162, 12, 165, 10, 178, 7, 189, 6, 190, 8, 177, 9, 23, 178,
+        54, 115, 63, 102, 66, 98, 69, 99, 74, 89, 71, 91, 73, 91, 78, 89, 86, 80, 92, 66, 93, 64,
+        102, 59, 103, 60, 104, 60, 117, 52, 123, 44, 138, 35, 133, 31, 97, 38, 77, 45, 61, 90, 93,
+        60, 105, 42, 107, 41, 110, 45, 116, 38, 113, 38, 112, 38, 124, 26, 132, 27, 136, 19, 140,
+        20, 155, 14, 159, 16, 158, 18, 170, 13, 177, 10, 187, 8, 192, 6, 175, 9, 159, 10, 21, 178,
+        59, 110, 71, 86, 75, 85, 84, 83, 91, 66, 88, 73, 87, 72, 92, 75, 98, 72, 105, 58, 107, 54,
+        115, 52, 114, 55, 112, 56, 129, 51, 132, 40, 150, 33, 140, 29, 98, 35, 77, 42, 42, 121, 96,
+        66, 108, 43, 111, 40, 117, 44, 123, 32, 120, 36, 119, 33, 127, 33, 134, 34, 139, 21, 147,
+        23, 152, 20, 158, 25, 154, 26, 166, 21, 173, 16, 184, 13, 184, 10, 150, 13, 139, 15, 22,
+        178, 63, 114, 74, 82, 84, 83, 92, 82, 103, 62, 96, 72, 96, 67, 101, 73, 107, 72, 113, 55,
+        118, 52, 125, 52, 118, 52, 117, 55, 135, 49, 137, 39, 157, 32, 145, 29, 97, 33, 77, 40,
+    ], "celt/quant_bands.c:79  Laplace model [LM][intra][2*band] (prob0, decay), Q8"),
+    ("pred_coef", "int16_t", [
+        29440, 26112, 21248, 16384,
+    ], "celt/quant_bands.c:67"),
+    ("beta_coef", "int16_t", [
+        30147, 22282, 12124, 6554,
+    ], "celt/quant_bands.c:68"),
+    ("small_energy_icdf", "uint8_t", [
+        2, 1, 0,
+    ], "celt/quant_bands.c:140"),
+    ("log2_frac_table", "uint8_t", [
+        0, 8, 13, 16, 19, 21, 23, 24, 26, 27, 28, 29, 30, 31, 32, 32, 33, 34, 34, 35, 36, 36, 37, 37,
+    ], "celt/rate.c:42"),
+    ("inv_table", "uint8_t", [
+        255, 255, 156, 110, 86, 70, 59, 51, 45, 40, 37, 33, 31, 28, 26, 25, 23, 22, 21, 20, 19, 18,
+        17, 16, 16, 15, 15, 14, 13, 13, 12, 12, 12, 12, 11, 11, 11, 10, 10, 10, 9, 9, 9, 9, 9, 9, 8,
+        8, 8, 8, 8, 7, 7, 7, 7, 7, 7, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 6, 5, 5, 5, 5, 5,
+        5, 5, 5, 5, 5, 5, 5, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
+        4, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 2,
+    ], "celt/celt_encoder.c:239  6*64/x for transient_analysis"),
+    ("intensity_thresholds", "int16_t", [
+        1, 2, 3, 4, 5, 6, 7, 8, 16, 24, 36, 44, 50, 56, 62, 67, 72, 79, 88, 106, 134,
+    ], "celt/celt_encoder.c:1967"),
+    ("intensity_histeresis", "int16_t", [
+        1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3, 4, 5, 6, 8, 8,
+    ], "celt/celt_encoder.c:1970"),
+    ("comb_gains", "int16_t", [
+        10048, 7112, 4248, 15200, 8784, 0, 26208, 3280, 0,
+    ], "celt/celt.c:195  comb filter taps [tapset][3], Q15"),
+    ("tell_frac_correction", "uint32_t", [
+        35733, 38967, 42495, 46340, 50535, 55109, 60097, 65535,
+    ], "celt/entcode.c:74  ec_tell_frac thresholds"),
+    ("exp2_table8", "int16_t", [
+        16384, 17866, 19483, 21247, 23170, 25267, 27554, 30048,
+    ], "celt/bands.c:598  compute_qn"),
+    ("tf_select_table", "int8_t", [
+        0, -1, 0, -1, 0, -1, 0, -1, 0, -1, 0, -2, 1, 0, 1, -1, 0, -2, 0, -3, 2, 0, 1, -1, 0, -2, 0,
+        -3, 3, 0, 1, -1,
+    ], "celt/celt.c:239  [LM][4*isTransient+2*tf_select+tf_res]"),
+    ("second_check", "uint8_t", [
+        0, 0, 3, 2, 3, 2, 5, 2, 3, 2, 3, 2, 5, 2, 3, 2,
+    ], "celt/pitch.c:371"),
+    ("ordery_table", "uint8_t", [
+        1, 0, 3, 0, 2, 1, 7, 0, 4, 3, 6, 1, 5, 2, 15, 0, 8, 7, 12, 3, 11, 4, 14, 1, 9, 6, 13, 2, 10,
+        5,
+    ], "celt/bands.c:517  natural -> ordery Hadamard, rows for N=2,4,8,16"),
+    ("bit_interleave_table", "uint8_t", [
+        0, 1, 1, 1, 2, 3, 3, 3, 2, 3, 3, 3, 2, 3, 3, 3,
+    ], "celt/bands.c:1090"),
+    ("bit_deinterleave_table", "uint8_t", [
+        0, 3, 12, 15, 48, 51, 60, 63, 192, 195, 204, 207, 240, 243, 252, 255,
+    ], "celt/bands.c:1156"),
+    ("trim_icdf", "uint8_t", [126, 124, 119, 109, 87, 41, 19, 9, 4, 2, 0], "celt/celt.h:150"),
+    ("spread_icdf", "uint8_t", [25, 23, 2, 0], "celt/celt.h:152"),
+    ("tapset_icdf", "uint8_t", [2, 1, 0], "celt/celt.h:154"),
+]
+
 
 def all_tables():
     idx, bits, caps = pulse_cache()
@@ -357,6 +438,22 @@ def all_tables():
         "pvq_u_data": ("uint32_t", pvq_u_table()),
         "pvq_u_row": ("uint16_t", PVQ_ROW_OFFSET),
     }
+    for name, ctype, vals, _cite in LITERAL_TABLES:
+        t[name] = (ctype, vals)
+    # device-friendly derived layouts (pure re-packing of the tables above)
+    u16 = lambda v: v & 0xFFFF
+    t["fft_tw_packed"] = ("uint32_t", [u16(r) | (u16(i) << 16) for r, i in tw])
+    trig = t["mdct_trig960"][1]
+    off = 0
+    for shift, n4 in enumerate([480, 240, 120, 60]):
+        t["mdct_trig_packed%d" % shift] = ("uint32_t", [u16(trig[off + i]) | (u16(trig[off + n4 + i]) << 16) for i in range(n4)])
+        off += 2 * n4
+    # band index of each group of 8 coefficients (LM = 3): bins eBands[i]..eBands[i+1]-1 -> i; 100..119 -> 21
+    b2b = []
+    for i in range(NB_EBANDS):
+        b2b += [i] * (EBAND5MS[i + 1] - EBAND5MS[i])
+    b2b += [NB_EBANDS] * (120 - len(b2b))
+    t["bin2band"] = ("uint8_t", b2b)
     return t
 
 
