@@ -8,6 +8,7 @@
 // (SURVEY.md 8d): the reset values below are then materialised in registers/LDS and nothing is stored.
 #pragma once
 #include <stdint.h>
+#include "../../include/opusgpu.h"   /* opusgpu_celt_config */
 
 #ifdef __cplusplus
 extern "C" {
@@ -52,20 +53,6 @@ typedef struct opusgpu_celt_state {
     int32_t in_mem[2 * OPUSGPU_CELT_OVERLAP];
     int32_t prefilter_mem[2 * OPUSGPU_COMBFILTER_MAXPERIOD];
 } opusgpu_celt_state;
-
-/* Encoder configuration shared by all frames of a batch: what opus_encoder_create() + the ctl sequence
- * of opus_demo (src/opus_demo.c:531-543) establish. Only CELT-only 48 kHz 20 ms frames are supported
- * (OPUS_APPLICATION_RESTRICTED_LOWDELAY). */
-typedef struct opusgpu_celt_config {
-    int32_t channels;          /* 2 (stereo) or 1 */
-    int32_t bitrate;           /* OPUS_SET_BITRATE, bits/s */
-    int32_t vbr;               /* OPUS_SET_VBR */
-    int32_t constrained_vbr;   /* OPUS_SET_VBR_CONSTRAINT */
-    int32_t complexity;        /* OPUS_SET_COMPLEXITY 0..10 */
-    int32_t lsb_depth;         /* OPUS_SET_LSB_DEPTH (16 for int16 input) */
-    int32_t loss_rate;         /* OPUS_SET_PACKET_LOSS_PERC */
-    int32_t max_data_bytes;    /* opus_encode()'s max_data_bytes (opus_demo: 1500) */
-} opusgpu_celt_config;
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,9 @@ SYMBOLS = [
     ("opusgpu_mdct_backward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
     ("opusgpu_clt_mdct_forward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_clt_mdct_backward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    ("opusgpu_celt_state_size", _i, []),
+    ("opusgpu_celt_state_init", _i, [_vp, _i, _vp]),
+    ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
 ]
 
 _lib = None

@@ -68,6 +68,49 @@ void opusgpu_clt_mdct_forward(const void *l, int32_t *in, int32_t *out, const in
 void opusgpu_clt_mdct_backward(const void *l, int32_t *in, int32_t *out, const int16_t *window,
                                int overlap, int shift, int stride, int arch);
 
+/* ---- Opus CELT-only frame encode, batched (BASELINE config #3) -------------------------------------
+ * Replaces opus_encode() (opus-fix/src/opus_encoder.c:2007-2025 -> opus_encode_native :938 ->
+ * celt_encode_with_ec, opus-fix/celt/celt_encoder.c:1379) for encoders created as
+ *   opus_encoder_create(48000, channels, OPUS_APPLICATION_RESTRICTED_LOWDELAY)
+ * and configured with the ctl sequence of opus_demo (src/opus_demo.c:531-543), 20 ms frames (960 samples).
+ * Output packets (TOC byte + CELT payload) and OPUS_GET_FINAL_RANGE values are bit-exact with the
+ * FIXED_POINT reference.
+ *
+ * opusgpu_celt_config mirrors the ctl-settable encoder configuration; opusgpu_celt_state is the
+ * pointer-free per-stream state (what the reference keeps inside OpusEncoder/CELTEncoder between
+ * frames, celt_encoder.c:82-128), one record per stream in device memory.
+ */
+typedef struct opusgpu_celt_config {
+    int32_t channels;          /* 2; (1 and stereo->mono downmix are not implemented) */
+    int32_t bitrate;           /* OPUS_SET_BITRATE, bits/s (>= 32000: stereo + fullband region) */
+    int32_t vbr;               /* OPUS_SET_VBR */
+    int32_t constrained_vbr;   /* OPUS_SET_VBR_CONSTRAINT */
+    int32_t complexity;        /* OPUS_SET_COMPLEXITY 0..10 */
+    int32_t lsb_depth;         /* OPUS_SET_LSB_DEPTH (16 for int16 input) */
+    int32_t loss_rate;         /* OPUS_SET_PACKET_LOSS_PERC */
+    int32_t max_data_bytes;    /* opus_encode()'s max_data_bytes (opus_demo passes 1500) */
+} opusgpu_celt_config;
+
+/* sizeof(opusgpu_celt_state): bytes per stream record. */
+int opusgpu_celt_state_size(void);
+/* Initialise n_streams records to the state of a freshly created encoder (OPUS_RESET_STATE). */
+int opusgpu_celt_state_init(void *d_states, int n_streams, void *hip_stream);
+
+/* Encode one 20 ms frame for each of n_frames streams.
+ *   d_states   device, n_frames records (frame n advances stream n), or NULL: every frame is encoded as
+ *              the first frame of its own fresh stream ("independent frames") and no state is kept.
+ *   d_pcm      device, int16 [n_frames][960][channels] interleaved (as opus_encode's pcm).
+ *   d_out      device, packet slab [n_frames][out_stride] bytes; out_stride % 4 == 0 and
+ *              out_stride >= min(max_data_bytes, 1276) rounded up to 4.
+ *   d_out_len  device, int32 [n_frames]: packet length, or a negative OPUSGPU_* code for that frame
+ *              (opus_encode's return value).
+ *   d_out_rng  device, uint32 [n_frames]: OPUS_GET_FINAL_RANGE after the frame.
+ * Asynchronous on hip_stream. Returns OPUSGPU_UNIMPLEMENTED for configurations outside the
+ * stereo/fullband CELT-only operating region. */
+int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const int16_t *d_pcm,
+                         unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
+                         int n_frames, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

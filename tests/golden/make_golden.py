@@ -60,3 +60,78 @@ if __name__ == "__main__":
         sys.exit("oracle/_ref/libopus_ref.so missing: run `make -C oracle ref` where /root/reference exists")
     np.savez_compressed(os.path.join(HERE, "mdct_golden.npz"), **mdct_vectors())
     print("wrote mdct_golden.npz")
+
+
+# ---- opus_encode() packets (BASELINE configs #1/#3) ------------------------------------------------
+class _Cfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                "channels bitrate vbr constrained_vbr complexity lsb_depth loss_rate max_data_bytes".split()]
+
+
+def synth_pcm(kind, nframes, seed):
+    """Synthetic stereo int16 frames [n][960][2]: 'noise' = uniform in [-8192, 8191],
+    'music' = sine mix + low-level noise (band-limited, exercises the pitch pre-filter and long blocks),
+    'edge' = silence, full-scale square, single impulse, DC."""
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        return rng.integers(-8192, 8192, size=(nframes, 960, 2), dtype=np.int16)
+    if kind == "music":
+        t = np.arange(nframes * 960)
+        f0 = 220.0 * (1 + (seed % 7))
+        x = 7000 * np.sin(2 * np.pi * f0 * t / 48000) + 2500 * np.sin(2 * np.pi * 3.01 * f0 * t / 48000)
+        x = x * (0.6 + 0.4 * np.sin(2 * np.pi * 3.0 * t / 48000))
+        pcm = np.stack([x, 0.7 * x], -1).reshape(nframes, 960, 2)
+        return (pcm + rng.integers(-40, 40, size=(nframes, 960, 2))).astype(np.int16)
+    pcm = np.zeros((nframes, 960, 2), np.int16)
+    for n in range(nframes):
+        m = n % 4
+        if m == 1:
+            pcm[n, :, :] = np.where((np.arange(960) // 24) % 2 == 0, 32767, -32768)[:, None]
+        elif m == 2:
+            pcm[n, 480 + n % 100, 0] = 30000
+        elif m == 3:
+            pcm[n, :, :] = 12345
+    return pcm
+
+
+def ref_encode(cfg, pcm, frames_per_stream, threads=4):
+    drv = C.CDLL(os.path.join(os.path.dirname(HERE), "..", "oracle", "_ref", "librefdrv.so"))
+    n = pcm.shape[0]
+    out = np.zeros((n, 1280), np.uint8)
+    lens = np.zeros(n, np.int32)
+    rng = np.zeros(n, np.uint32)
+    pcm = np.ascontiguousarray(pcm)
+    drv.refdrv_encode_frames(C.byref(cfg), _p(pcm), C.c_long(n), frames_per_stream, _p(out), 1280, _p(lens), _p(rng), threads)
+    return out, lens, rng
+
+
+ENCODE_CASES = [
+    # name, kind, nframes, frames_per_stream, seed, (bitrate, vbr, cvbr, complexity)
+    ("noise_vbr_indep", "noise", 24, 1, 3, (96000, 1, 0, 10)),
+    ("music_vbr_indep", "music", 24, 1, 4, (96000, 1, 0, 10)),
+    ("edge_vbr_indep", "edge", 8, 1, 5, (96000, 1, 0, 10)),
+    ("noise_cbr_indep", "noise", 16, 1, 6, (96000, 0, 0, 10)),
+    ("music_vbr_stream", "music", 32, 16, 7, (96000, 1, 0, 10)),
+    ("noise_cvbr_stream", "noise", 32, 16, 8, (64000, 1, 1, 10)),
+    ("music_cbr_stream_cx5", "music", 32, 16, 9, (128000, 0, 0, 5)),
+    ("noise_vbr_stream_cx0", "noise", 16, 8, 10, (48000, 1, 0, 0)),
+]
+
+
+def encode_vectors():
+    out = {}
+    for name, kind, n, fps, seed, (br, vbr, cvbr, cx) in ENCODE_CASES:
+        cfg = _Cfg(2, br, vbr, cvbr, cx, 16, 0, 1500)
+        pcm = synth_pcm(kind, n, seed)
+        pk, ln, rg = ref_encode(cfg, pcm, fps)
+        assert (ln > 0).all(), name
+        out[name + "_pcm"] = pcm
+        out[name + "_packets"] = pk[:, :int(ln.max())]
+        out[name + "_len"] = ln
+        out[name + "_rng"] = rg
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "encode_golden.npz"), **encode_vectors())
+    print("wrote encode_golden.npz")

@@ -1,0 +1,124 @@
+"""GPU parity tests for the batched CELT frame encoder, through the C-ABI (opusgpu_encode_batch):
+packets + final range byte-exact against (a) committed golden vectors from the compiled reference,
+(b) the compiled reference itself, live, when oracle/_ref travelled with the snapshot,
+(c) at BASELINE config #3's full size (65 536 frames) through batch-size independence and a sampled
+exact check."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import encode_cases as ec
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import torch
+    assert torch.cuda.is_available()
+    import concentus_amd
+    concentus_amd.lib.load()
+    return concentus_amd
+
+
+def _cfg(ca, vals):
+    br, vbr, cvbr, cx = vals
+    return ca.CeltConfig(2, br, vbr, cvbr, cx, 16, 0, 1500)
+
+
+def _gpu_encode(ca, pcm, fps, cfgvals):
+    import torch
+    cfg = _cfg(ca, cfgvals)
+    n = pcm.shape[0]
+    if fps == 1:
+        out, lens, rng = ca.encode_independent(torch.from_numpy(np.ascontiguousarray(pcm)).cuda(), cfg)
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), lens.cpu().numpy(), rng.cpu().numpy().view(np.uint32)
+    ns = n // fps
+    enc = ca.OpusEncoderBatch(ns).apply_opus_demo_ctls(*cfgvals)
+    outs = np.zeros((n, 1280), np.uint8)
+    lens = np.zeros(n, np.int32)
+    rngs = np.zeros(n, np.uint32)
+    p4 = pcm.reshape(ns, fps, 960, 2)
+    for f in range(fps):
+        o, l = enc.encode(torch.from_numpy(np.ascontiguousarray(p4[:, f])).cuda())
+        torch.cuda.synchronize()
+        idx = np.arange(ns) * fps + f
+        o = o.cpu().numpy()
+        outs[idx, :o.shape[1]] = o
+        lens[idx] = l.cpu().numpy()
+        rngs[idx] = enc.ctl(4031).cpu().numpy().view(np.uint32)
+    return outs, lens, rngs
+
+
+@pytest.mark.parametrize("case", ec.cases(), ids=lambda c: c[0])
+def test_gpu_matches_golden_packets(ca, case):
+    name, _kind, _n, fps, _seed, cfgvals = case
+    pcm, pk, ln, rg = ec.load_case(name)
+    out, lens, rng = _gpu_encode(ca, pcm, fps, cfgvals)
+    ec.assert_packets_equal(out, lens, rng, pk, ln, rg, name)
+
+
+@pytest.mark.parametrize("kind,n,fps,cfgvals", [
+    ("noise", 512, 1, (96000, 1, 0, 10)),
+    ("music", 512, 1, (96000, 1, 0, 10)),
+    ("music", 384, 24, (96000, 1, 0, 10)),
+    ("noise", 256, 16, (96000, 0, 0, 10)),
+    ("edge", 64, 1, (96000, 1, 0, 10)),
+    ("music", 256, 16, (40000, 1, 1, 7)),
+])
+def test_gpu_matches_live_reference(ca, kind, n, fps, cfgvals):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("oracle/_ref did not travel")
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm(kind, n, 4321 + n + fps)
+    br, vbr, cvbr, cx = cfgvals
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, br, vbr, cvbr, cx, 16, 0, 1500), pcm, fps, threads=8)
+    out, lens, rng = _gpu_encode(ca, pcm, fps, cfgvals)
+    ec.assert_packets_equal(out, lens, rng, pk, ln, rg, "%s n=%d fps=%d %r" % (kind, n, fps, cfgvals))
+
+
+def test_config3_full_size_65536_frames(ca):
+    """65 536 independent frames, 96 kb/s, complexity 10 (BASELINE config #3). Exact check on a strided
+    sample of 512 frames (live reference if present, else batch-size independence only), and the result of
+    every frame must not depend on the batch it was encoded in."""
+    import torch
+    gm = ec.golden_module()
+    n = 65536
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-8192, 8192, size=(n, 960, 2), dtype=np.int16)
+    d = torch.from_numpy(pcm).cuda()
+    cfg = ca.default_config()
+    out, lens, fr = ca.encode_independent(d, cfg)
+    torch.cuda.synchronize()
+    lens_h = lens.cpu().numpy()
+    assert (lens_h > 2).all() and (lens_h <= 1276).all()
+    idx = np.arange(0, n, 128)
+    sub = torch.from_numpy(np.ascontiguousarray(pcm[idx])).cuda()
+    o2, l2, r2 = ca.encode_independent(sub, cfg)
+    torch.cuda.synchronize()
+    out_h = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert np.array_equal(l2.cpu().numpy(), lens_h[idx])
+    assert np.array_equal(r2.cpu().numpy(), fr.cpu().numpy()[idx])
+    assert np.array_equal(o2.cpu().numpy(), out_h)
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pk, ln, rg = gm.ref_encode(gm._Cfg(2, 96000, 1, 0, 10, 16, 0, 1500), pcm[idx], 1, threads=8)
+        ec.assert_packets_equal(out_h, lens_h[idx], fr.cpu().numpy()[idx].view(np.uint32), pk, ln, rg, "config3 sample")
+
+
+def test_bad_configs_rejected(ca):
+    import torch
+    pcm = torch.zeros((2, 960, 2), dtype=torch.int16, device="cuda")
+    with pytest.raises(ca.lib.OpusGpuError) as e:
+        ca.encode_independent(pcm, ca.CeltConfig(2, 16000, 1, 0, 10, 16, 0, 1500))
+    assert e.value.code == -5
+    with pytest.raises(ca.lib.OpusGpuError) as e:
+        ca.encode_independent(pcm, ca.CeltConfig(2, 96000, 1, 0, 11, 16, 0, 1500))
+    assert e.value.code == -1
+    with pytest.raises(ValueError):
+        ca.encode_independent(torch.zeros((2, 480, 2), dtype=torch.int16, device="cuda"))
+    out, lens, _ = ca.encode_independent(torch.zeros((0, 960, 2), dtype=torch.int16, device="cuda"))
+    assert out.shape[0] == 0
