@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched Opus frame path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload mdct] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload celt|mdct] [--frames F]
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM.
-Workload `mdct` is BASELINE.json configs[1]: 4 096 independent 48 kHz stereo 20 ms frames,
-clt_mdct_forward + clt_mdct_backward (33 600 algorithmic bytes per stereo frame).
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank processes its own shard of
-F frames -- the frame corpus partitions with no data-path collective -- so scaling is "weak" and
-`value` is the whole-job frames/s.
+
+  celt (default)  BASELINE.json configs[2]: 65 536 independent 48 kHz stereo 20 ms frames per GPU,
+                  full CELT encode (opus_encode(): dc_reject, pre-emphasis, pitch pre-filter, MDCT,
+                  PVQ quant_all_bands, range coder) at 96 kb/s VBR complexity 10 -- the configuration the
+                  metric "frames encoded/sec" is quoted on. Algorithmic bytes: 3 840 B PCM in + packet
+                  (~255 B) + 8 B (len, rng) per frame (~4 090 B/frame).
+  mdct            BASELINE.json configs[1]: 4 096 frames, clt_mdct_forward + clt_mdct_backward only
+                  (33 600 algorithmic bytes per stereo frame) -- the HBM-bound slice.
+
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes its own shard of F
+frames -- the frame corpus partitions with no data-path collective -- then the packets are gathered to
+rank 0 over RCCL (outside the timed region's hot loop but inside the timed region, once per step), so
+scaling is "weak" and `value` is the whole-job frames/s.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
-timed with events on the launch stream) and `cpu_baseline` (the reference's own C code, or the
-oracle port, timed on this box's host cores over a bounded sample).
+timed with events on the launch stream) and `cpu_baseline` (the reference's own C code timed on this
+box's host cores over a bounded sample).
 """
 import argparse
 import ctypes as C
@@ -27,57 +35,72 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4            # 16 320 B / stereo frame  
-BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4   # 17 280 B / stereo frame
-BYTES_FRAME = BYTES_FWD + BYTES_BWD               # 33 600 B
+BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
+BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
+PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="mdct", choices=["mdct"])
-    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="celt", choices=["celt", "mdct"])
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL packet gather (N > 1)")
     return ap.parse_args()
 
 
-def cpu_baseline_mdct(seed_sig):
-    """Time the reference's clt_mdct_forward_c + clt_mdct_backward_c (oracle/_ref, kind "reference")
-    or, if that library did not travel, our C restatement (kind "port") on a bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def host_threads():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(cores, 16)                    # one GPU's share of the host (the box allots 16 per GPU)
-    n = 2048                                  # stereo frames per pass
+    return min(cores, 16)          # one GPU's share of the host (the box allots 16 per GPU)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cpu_baseline_mdct(seed_sig):
+    """Reference clt_mdct_forward_c + clt_mdct_backward_c (oracle/_ref, kind "reference"), or our C
+    restatement (kind "port") if that library did not travel, on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = host_threads()
+    n = 2048
     sig = np.ascontiguousarray(np.tile(seed_sig, (n // seed_sig.shape[0] + 1, 1, 1))[:n])
     freq = np.zeros((n, 2, 960), np.int32)
     rec = sig.copy()
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
     refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
     if os.path.exists(refdrv):
         drv = C.CDLL(refdrv)
         drv.refdrv_mdct_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
 
         def run(threads):
-            drv.refdrv_mdct_batch(p(sig), p(freq), p(rec), n * 2, 0, 3, threads)
+            drv.refdrv_mdct_batch(_p(sig), _p(freq), _p(rec), n * 2, 0, 3, threads)
         kind = "reference"
     else:
         import oraclelib
         orc = oraclelib.lib()
 
         def run(threads):
-            orc.orc_mdct_forward_batch(p(sig), p(freq), n, 2, 0)
-            orc.orc_mdct_backward_batch(p(freq), p(rec), n, 2, 0)
+            orc.orc_mdct_forward_batch(_p(sig), _p(freq), n, 2, 0)
+            orc.orc_mdct_backward_batch(_p(freq), _p(rec), n, 2, 0)
         kind = "port"
         cores = 1
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": kind,
+            "sample": "%d stereo frames x clt_mdct_forward_c+clt_mdct_backward_c (shift 0) per pass, "
+                      "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+
+
+def _time_cpu(run, n, cores):
     run(1)
     t0 = time.perf_counter()
-    reps1 = 0
+    reps = 0
     while time.perf_counter() - t0 < 4.0:
         run(1)
-        reps1 += 1
-    one = reps1 * n / (time.perf_counter() - t0)
+        reps += 1
+    one = reps * n / (time.perf_counter() - t0)
     multi = one
     if cores > 1:
         run(cores)
@@ -87,8 +110,34 @@ def cpu_baseline_mdct(seed_sig):
             run(cores)
             reps += 1
         multi = reps * n / (time.perf_counter() - t0)
-    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": "%d stereo frames x clt_mdct_forward_c+clt_mdct_backward_c (shift 0) per pass, "
+    return one, multi
+
+
+def cpu_baseline_celt(pcm_sample, cfgvals):
+    """The reference's own opus_encode() (unmodified opus-fix, FIXED_POINT, -O2; oracle/_ref) over a
+    bounded sample of the same workload: independent frames = fresh opus_encoder_create + opus_demo
+    ctl sequence + one opus_encode per frame."""
+    refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
+    if not os.path.exists(refdrv):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/librefdrv.so did not travel; no CPU baseline"}
+    drv = C.CDLL(refdrv)
+
+    class Cfg(C.Structure):
+        _fields_ = [(k, C.c_int32) for k in "channels bitrate vbr constrained_vbr complexity lsb_depth loss_rate max_data_bytes".split()]
+    cfg = Cfg(*cfgvals)
+    cores = host_threads()
+    n = pcm_sample.shape[0]
+    pcm = np.ascontiguousarray(pcm_sample)
+    out = np.zeros((n, 1280), np.uint8)
+    lens = np.zeros(n, np.int32)
+    rng = np.zeros(n, np.uint32)
+
+    def run(threads):
+        drv.refdrv_encode_frames(C.byref(cfg), _p(pcm), C.c_long(n), 1, _p(out), 1280, _p(lens), _p(rng), threads)
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": "%d independent frames per pass through opus-fix opus_encode() (create+ctl+encode per frame), "
                       "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
 
 
@@ -108,87 +157,132 @@ def main():
     import concentus_amd as ca
     ca.lib.load()
 
-    F = a.frames
-    rng = np.random.default_rng(2 + rank)      # seed 2, int16 uniform x 4096 (Q12)
-    host = (rng.integers(-16384, 16384, size=(F, 2, 1080), dtype=np.int64) * 4096).astype(np.int32)
-    sig = torch.from_numpy(host).to(dev)
-    freq = torch.empty((F, 2, 960), dtype=torch.int32, device=dev)
-    rec = sig.clone()
-
-    def step():
-        ca.mdct_forward_batch(sig, freq, shift=0)
-        ca.mdct_backward_batch(freq, rec, shift=0)
-
-    for _ in range(a.warmup):
-        step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(a.steps)]
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(a.steps):
-        ev[k][0].record()
-        ca.mdct_forward_batch(sig, freq, shift=0)
-        ev[k][1].record()
-        ca.mdct_backward_batch(freq, rec, shift=0)
-        ev[k][2].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    traffic_db = {}
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic_db = json.load(open(tp))
+        except Exception:
+            traffic_db = {}
+
+    if a.workload == "mdct":
+        F = a.frames or 4096
+        steps = a.steps or 200
+        warm = a.warmup if a.warmup is not None else 20
+        rng = np.random.default_rng(2 + rank)      # seed 2, int16 uniform x 4096 (Q12)
+        host = (rng.integers(-16384, 16384, size=(F, 2, 1080), dtype=np.int64) * 4096).astype(np.int32)
+        sig = torch.from_numpy(host).to(dev)
+        freq = torch.empty((F, 2, 960), dtype=torch.int32, device=dev)
+        rec = sig.clone()
+        for _ in range(warm):
+            ca.mdct_forward_batch(sig, freq, shift=0)
+            ca.mdct_backward_batch(freq, rec, shift=0)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.mdct_forward_batch(sig, freq, shift=0)
+            ev[k][1].record()
+            ca.mdct_backward_batch(freq, rec, shift=0)
+            ev[k][2].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        if fwd_ms >= bwd_ms:
+            kname, kbytes, kms = "mdct_forward_kernel<0>", BYTES_FWD * F, fwd_ms
+        else:
+            kname, kbytes, kms = "mdct_backward_kernel<0>", BYTES_BWD * F, bwd_ms
+        metric = "48kHz stereo 20ms CELT frames/sec (clt_mdct_forward+backward only, config #2)"
+        workload = ("configs[1]: %d independent 48 kHz stereo 20 ms frames per GPU, clt_mdct_forward+backward "
+                    "only (shift 0), bit-exact vs FIXED_POINT" % F)
+        dtype = "int32"
+        extra = {"other_kernel_ms": round(bwd_ms if kname.startswith("mdct_forward") else fwd_ms, 5)}
+        cpu = (lambda: cpu_baseline_mdct(host[:256]))
+    else:
+        F = a.frames or 65536
+        steps = a.steps or 10
+        warm = a.warmup if a.warmup is not None else 2
+        cfg = ca.default_config(2, 96000)          # opus_demo restricted-lowdelay 48000 2 96000, complexity 10, VBR
+        rng = np.random.default_rng(3 + rank)      # seed 3, uniform int16 in [-8192, 8191]
+        host = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
+        pcm = torch.from_numpy(host).to(dev)
+        out = lens = None
+        for _ in range(warm):
+            out, lens, _r = ca.encode_independent(pcm, cfg)
+        torch.cuda.synchronize()
+        from concentus_amd.sharding import gather_packets
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            out, lens, _r = ca.encode_independent(pcm, cfg)
+            ev[k][1].record()
+            if world > 1 and not a.no_gather:
+                # the only exchange of the path: packets + lengths to rank 0 over RCCL/xGMI
+                gathered = gather_packets(out, lens, _r, world)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        lens_h = lens.cpu().numpy()
+        assert (lens_h > 0).all(), "encoder reported an error"
+        mean_len = float(lens_h.mean())
+        kname = "celt_encode_kernel"
+        kbytes = int(F * (PCM_BYTES + mean_len + 8))
+        metric = "48kHz stereo 20ms CELT frames encoded/sec"
+        workload = ("configs[2]: %d independent 48 kHz stereo 20 ms frames per GPU, full CELT encode "
+                    "(MDCT + PVQ + range enc) 96 kb/s VBR complexity 10, packets bit-exact vs FIXED_POINT "
+                    "opus_encode(); mean packet %.1f B" % (F, mean_len))
+        dtype = "int16/int32 fixed-point"
+        extra = {"mean_packet_bytes": round(mean_len, 2),
+                 "realtime_factor": None}
+        cpu = (lambda: cpu_baseline_celt(host[:4096], (2, 96000, 1, 0, 10, 16, 0, 1500)))
+
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-
-    fwd_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    bwd_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-    if fwd_ms >= bwd_ms:
-        kname, kbytes, kms = "mdct_forward_kernel<0>", BYTES_FWD * F, fwd_ms
-    else:
-        kname, kbytes, kms = "mdct_backward_kernel<0>", BYTES_BWD * F, bwd_ms
     achieved = kbytes / (kms * 1e-3) / 1e9
 
     if rank == 0:
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get(kname)
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "48kHz stereo 20ms CELT frames/sec (clt_mdct_forward+backward, config #2)",
-            "value": round(F * world * a.steps / elapsed, 1),
+        value = F * world * steps / elapsed
+        if "realtime_factor" in extra:
+            extra["realtime_factor"] = round(value * 0.02, 1)        # 20 ms of audio per frame
+        out_line = {
+            "metric": metric,
+            "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "steps": steps,
+            "warmup": warm,
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int32",
+            "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d independent 48 kHz stereo 20 ms frames per GPU, "
-                                   "clt_mdct_forward+backward only (shift 0), bit-exact vs FIXED_POINT" % F,
-                       "frames_per_gpu": F, "channels": 2, "sharding": "frames block-partitioned, no collective"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 5),
-                         "other_kernel_ms": round(bwd_ms if kname.startswith("mdct_forward") else fwd_ms, 5),
-                         "whole_step_GBps": round(BYTES_FRAME * F / ((fwd_ms + bwd_ms) * 1e-3) / 1e9, 1)},
+            "config": {"workload": workload, "frames_per_gpu": F, "channels": 2,
+                       "sharding": "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0"},
+            "roofline": dict({"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic_db.get(kname),
+                              "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 5)}, **extra),
         }
-        if not a.no_cpu_baseline and world >= 1:
+        if not a.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline_mdct(host[:256])
+                out_line["cpu_baseline"] = cpu()
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
-                out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
-        print(json.dumps(out))
+                out_line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
+                                            "sample": "failed: %r" % (e,)}
+        print(json.dumps(out_line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

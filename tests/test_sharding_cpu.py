@@ -1,0 +1,72 @@
+"""CPU tier, world_size 2 (gloo): the multi-GPU layout of the frame path -- block partition of the
+frame range, every rank encodes only its shard (here: with the host-emulated kernel sources), packets
+gathered to rank 0 -- reproduces the single-process result (= the golden packets)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_shard_range_partitions_exactly():
+    from concentus_amd.sharding import shard_range
+    for n in (0, 1, 7, 8, 65536, 1048576 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import emulib
+    import encode_cases as ec
+    from concentus_amd.sharding import gather_packets, shard_range
+    pcm, pk, ln, rg = ec.load_case("noise_vbr_indep")          # 24 frames; world 2 -> 12 + 12, world 5 -> uneven
+    n = pcm.shape[0] - 1                                        # 23: uneven split
+    lo, hi = shard_range(n, rank, world)
+    emu = emulib.lib()
+    cfg = emulib.Config(2, 96000, 1, 0, 10, 16, 0, 1500)
+    m = hi - lo
+    out = np.zeros((m, 1280), np.uint8)
+    lens = np.zeros(m, np.int32)
+    rng = np.zeros(m, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    shard = np.ascontiguousarray(pcm[lo:hi])
+    emu.emu_celt_encode_frames(C.byref(cfg), None, p(shard), m, 1, p(out), 1280, p(lens), p(rng))
+    res = gather_packets(torch.from_numpy(out), torch.from_numpy(lens), torch.from_numpy(rng.view(np.int32)), world)
+    if rank == 0:
+        o, l, r = (t.numpy() for t in res)
+        try:
+            ec.assert_packets_equal(o, l, r.view(np.uint32), pk[:n], ln[:n], rg[:n], "sharded")
+            q.put("ok")
+        except AssertionError as e:
+            q.put("FAIL: %s" % e)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_two_rank_sharded_encode_matches_golden(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) == "ok"
