@@ -508,6 +508,9 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
         if (ret != max_data_bytes) enc.error = -1;
     }
     if (st_out) store_state(fc, F, st_out, st_in);
+    if (lane() == 0)
+        for (int k = ret; k < ((ret + 3) & ~3); k++) F.packet[k] = 0;               // deterministic pad bytes
+    wave_sync();
     {   // packet -> HBM (word-wise; the slab stride is a multiple of 4)
         const u32 *src = reinterpret_cast<const u32 *>(F.packet);
         u32 *dst = reinterpret_cast<u32 *>(out);
