@@ -116,8 +116,9 @@ CA_DEV void store_state(const FrameCtx &fc, FrameLds &F, opusgpu_celt_state *st,
 // One frame. pcm: 960*C interleaved int16 (global). out: packet bytes (global, >= max packet size).
 // st_in == nullptr: independent first frame. st_out may be nullptr (state discarded) or == st_in.
 CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
-                                       opusgpu_celt_state *st_out, const i16 *pcm, u8 *out)
+                                       opusgpu_celt_state *st_out, const i16 *pcm, u8 *out, StageClock *stage_clock = nullptr)
 {
+    (void)stage_clock;
     const int C = cfg.channels, N = FRAME, LM = LM3, M = M8, end = NB;
     FrameCtx fc;
     load_state(fc, F, st_in, C);
@@ -152,6 +153,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     dc_reject_wave(F, fc);
     CA_TRACE("dc_reject done");
 
+    CA_STAMP(0);
     // ---- celt_encode_with_ec ----
     i32 tell = ec_tell(enc);                                   // == 1
     const int nbFilledBytes = (tell + 4) >> 3;                 // == 0
@@ -201,11 +203,13 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
         enc.nbits_total += tell - ec_tell(enc);
     }
 
+    CA_STAMP(1);
     // 3. pre-emphasis
     preemphasis_wave(F, fc);
     CA_TAP("in_preemph", F.in, sizeof(F.in));
     CA_TRACE("preemph done");
 
+    CA_STAMP(2);
     // 4. pitch pre-filter
     int pitch_index, pf_on, prefilter_tapset;
     i32 gain1;
@@ -249,6 +253,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
 
     CA_TRACE("prefilter done pitch=%d gain=%d pf_on=%d", pitch_index, gain1, pf_on); CA_TRACE("");
     CA_TAP("in_filtered", F.in, sizeof(F.in));
+    CA_STAMP(3);
     // 5. transient analysis
     int isTransient = 0, shortBlocks = 0, tf_chan = 0, transient_got_disabled = 0;
     i32 tf_estimate = 0;
@@ -266,50 +271,62 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     }
 
     CA_TRACE("transient done isT=%d tf_est=%d", isTransient, tf_estimate); CA_TRACE("");
-    // 6./7./8. MDCT + band energies
+    CA_STAMP(4);
+    // 6./7./8./9. MDCT + band energies, temporal VBR, transient patch.
+    // The reference runs compute_mdcts up to three times (extra long-block pass for bandLogE2 when
+    // complexity >= 8, the main pass, and a short-block redo when patch_transient_decision fires,
+    // celt_encoder.c:1698-1711, :1825-1845); here they are three trips through ONE inlined copy.
     const int secondMdct = shortBlocks && cfg.complexity >= 8;
-    if (secondMdct) {
-        compute_mdcts_wave(F, fc, 0);
-        band_energies_wave(F, fc, F.bandLogE2);
-        for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
-        wave_sync();
-    }
-    compute_mdcts_wave(F, fc, shortBlocks);
-    band_energies_wave(F, fc, F.bandLogE);
-
-    CA_TAP("freq", F.xf, sizeof(F.xf)); CA_TAP("bandE", F.bandE, sizeof(F.bandE)); CA_TAP("bandLogE", F.bandLogE, sizeof(F.bandLogE));
-    // 9. temporal VBR, transient patch
-    i32 temporal_vbr;
-    {
-        i32 follow = -10240;
-        i32 frame_avg = 0;
-        i32 offset = shortBlocks ? (shl16(LM, 10) >> 1) : 0;
-        for (int i = 0; i < end; i++) {
-            follow = (i16)imax(follow - 1024, F.bandLogE[i] - offset);
-            if (C == 2) follow = (i16)imax(follow, F.bandLogE[i + NB] - offset);
-            frame_avg += follow;
+    i32 temporal_vbr = 0;
+    for (int mdct_pass = secondMdct ? 0 : 1;;) {
+        compute_mdcts_wave(F, fc, mdct_pass == 0 ? 0 : shortBlocks);
+        band_energies_wave(F, fc, mdct_pass == 0 ? F.bandLogE2 : F.bandLogE);
+        if (mdct_pass == 0) {
+            for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
+            wave_sync();
+            mdct_pass = 1;
+            continue;
         }
-        frame_avg /= end;
-        temporal_vbr = (i16)sub16(frame_avg, fc.spec_avg);
-        temporal_vbr = imin(3072, imax(-1536, temporal_vbr));
-        fc.spec_avg = (i16)(fc.spec_avg + mul16_16_q15(655, temporal_vbr));
-    }
-    if (!secondMdct) {
-        for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = F.bandLogE[k];
-        wave_sync();
-    }
-    if (ec_tell(enc) + 3 <= total_bits && !isTransient && cfg.complexity >= 5) {
-        // patch_transient_decision (celt_encoder.c:380-416)
-        i32 spread_old[NB];
-        if (C == 1) {
-            spread_old[0] = F.oldBandE[0];
-            for (int i = 1; i < end; i++) spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, F.oldBandE[i]);
-        } else {
-            spread_old[0] = imax(F.oldBandE[0], F.oldBandE[NB]);
-            for (int i = 1; i < end; i++)
-                spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, imax(F.oldBandE[i], F.oldBandE[i + NB]));
+        if (mdct_pass == 2) {
+            for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
+            wave_sync();
+            tf_estimate = 3277;                                  // QCONST16(.2f,14)
+            break;
         }
-        for (int i = end - 2; i >= 0; i--) spread_old[i] = (i16)imax(spread_old[i], spread_old[i + 1] - 1024);
+        CA_TAP("freq", F.xf, sizeof(F.xf)); CA_TAP("bandE", F.bandE, sizeof(F.bandE)); CA_TAP("bandLogE", F.bandLogE, sizeof(F.bandLogE));
+        {   // temporal VBR (celt_encoder.c:1803-1819)
+            i32 follow = -10240;
+            i32 frame_avg = 0;
+            i32 offset = shortBlocks ? (shl16(LM, 10) >> 1) : 0;
+            for (int i = 0; i < end; i++) {
+                follow = (i16)imax(follow - 1024, F.bandLogE[i] - offset);
+                if (C == 2) follow = (i16)imax(follow, F.bandLogE[i + NB] - offset);
+                frame_avg += follow;
+            }
+            frame_avg /= end;
+            temporal_vbr = (i16)sub16(frame_avg, fc.spec_avg);
+            temporal_vbr = imin(3072, imax(-1536, temporal_vbr));
+            fc.spec_avg = (i16)(fc.spec_avg + mul16_16_q15(655, temporal_vbr));
+        }
+        if (!secondMdct) {
+            for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = F.bandLogE[k];
+            wave_sync();
+        }
+        if (!(ec_tell(enc) + 3 <= total_bits && !isTransient && cfg.complexity >= 5)) break;
+        // patch_transient_decision (celt_encoder.c:380-416); spread_old lives in LDS (F.follower is free here)
+        i16 *spread_old = F.follower;
+        if (lane() == 0) {
+            if (C == 1) {
+                spread_old[0] = F.oldBandE[0];
+                for (int i = 1; i < end; i++) spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, F.oldBandE[i]);
+            } else {
+                spread_old[0] = (i16)imax(F.oldBandE[0], F.oldBandE[NB]);
+                for (int i = 1; i < end; i++)
+                    spread_old[i] = (i16)imax(spread_old[i - 1] - 1024, imax(F.oldBandE[i], F.oldBandE[i + NB]));
+            }
+            for (int i = end - 2; i >= 0; i--) spread_old[i] = (i16)imax(spread_old[i], spread_old[i + 1] - 1024);
+        }
+        wave_sync();
         i32 mean_diff = 0;
         for (int c = 0; c < C; c++)
             for (int i = 2; i < end - 1; i++) {
@@ -317,23 +334,20 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
                 mean_diff = add32(mean_diff, imax(0, sub16(x1, x2)));
             }
         mean_diff = mean_diff / (C * (end - 1 - 2));
-        if (mean_diff > 1024) {
-            isTransient = 1;
-            shortBlocks = M;
-            compute_mdcts_wave(F, fc, shortBlocks);
-            band_energies_wave(F, fc, F.bandLogE);
-            for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
-            wave_sync();
-            tf_estimate = 3277;                                  // QCONST16(.2f,14)
-        }
+        wave_sync();
+        if (!(mean_diff > 1024)) break;
+        isTransient = 1;
+        shortBlocks = M;
+        mdct_pass = 2;
     }
     if (ec_tell(enc) + 3 <= total_bits) ec_enc_bit_logp(enc, isTransient, 3);
 
-    CA_TRACE("energies done");
+    CA_STAMP(5);
     // 10. normalise
     normalise_bands_wave(F, fc);
 
     CA_TAP("X", F.in, 2 * FRAME * 2);
+    CA_STAMP(6);
     // 11. TF resolution
     int tf_select;
     if (effectiveBytes >= 15 * C && cfg.complexity >= 2) {
@@ -351,11 +365,13 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     }
 
     CA_TRACE("tf done tf_select=%d", tf_select); CA_TRACE("");
+    CA_STAMP(7);
     // 12. coarse energy
     quant_coarse_energy_wave(F, fc, enc, (u32)total_bits, nbAvailableBytes, cfg.complexity >= 4, cfg.loss_rate);
 
     CA_TRACE("coarse done tell=%d", ec_tell(enc)); CA_TRACE("");
     CA_TAP("oldBandE_after_coarse", F.oldBandE, sizeof(F.oldBandE)); CA_TAP("error", F.error, sizeof(F.error));
+    CA_STAMP(8);
     // 13. tf_encode, spread, dynalloc, trim
     tf_encode_wave(F, enc, isTransient, tf_select);
     if (ec_tell(enc) + 4 <= total_bits) {
@@ -411,6 +427,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     }
 
     CA_TRACE("trim done alloc_trim=%d tell=%d", alloc_trim, tell); CA_TRACE("");
+    CA_STAMP(9);
     // 14. VBR target (celt_encoder.c:2002-2087)
     if (vbr_rate > 0) {
         const int lm_diff = 3 - LM;
@@ -453,6 +470,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     }
 
     CA_TRACE("vbr done nbCompressedBytes=%d", nbCompressedBytes); CA_TRACE("");
+    CA_STAMP(10);
     // 15. allocation
     i32 bits = (((i32)nbCompressedBytes * 8) << BITRES) - (i32)ec_tell_frac(enc) - 1;
     const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
@@ -467,14 +485,17 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
 
     CA_TRACE("alloc done codedBands=%d", codedBands); CA_TRACE("");
     CA_TAP("pulses", F.pulses, sizeof(F.pulses)); CA_TAP("fine_quant", F.fine_quant, sizeof(F.fine_quant)); CA_TAP("tf_res", F.tf_res, sizeof(F.tf_res));
+    CA_STAMP(11);
     // 16. fine energy
     quant_fine_energy_wave(F, enc, C);
 
+    CA_STAMP(12);
     // 17. PVQ
     quant_all_bands_wave(F, enc, C, shortBlocks, fc.spread_decision, dual_stereo, fc.intensity,
                          nbCompressedBytes * (8 << BITRES) - anti_collapse_rsv, ao.balance, codedBands);
 
     CA_TRACE("pvq done tell=%d", ec_tell(enc)); CA_TRACE("");
+    CA_STAMP(13);
     // 18. anti-collapse bit, energy finalise, state roll-over
     if (anti_collapse_rsv > 0) {
         int anti_collapse_on = fc.consec_transient < 2;
@@ -496,6 +517,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
     else fc.consec_transient = 0;
     fc.rng = enc.rng;
 
+    CA_STAMP(14);
     // 19. flush
     ec_enc_done(enc);
 
@@ -516,6 +538,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
         u32 *dst = reinterpret_cast<u32 *>(out);
         for (int k = lane(); k < (ret + 3) / 4; k += LANES) dst[k] = src[k];
     }
+    CA_STAMP(15);
     FrameResult r;
     r.bytes = enc.error ? -3 : ret;                                                  // OPUS_INTERNAL_ERROR
     r.final_range = fc.rng;

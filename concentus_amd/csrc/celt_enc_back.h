@@ -283,21 +283,31 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
     for (int ch = lane(); ch < nblocks * stride; ch += LANES) {
         i16 *x = X + (ch / stride) * len;
         const int r = ch % stride;
-        int i;
-        for (i = r; i < len - stride; i += stride) {
-            i32 x1 = x[i], x2 = x[i + stride];
-            x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
-            x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
+        // forward: the value written to x[i+stride] is the x1 of the next step -> carried in a register,
+        // so each step needs one independent LDS read instead of a read-after-write round trip
+        if (r < len - stride) {
+            i32 x1 = x[r];
+            int i;
+            for (i = r; i < len - stride; i += stride) {
+                i32 x2 = x[i + stride];
+                i32 n2 = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
+                x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
+                x1 = n2;
+            }
+            x[i] = (i16)x1;
         }
-        // backward pass: i = len-2*stride-1 .. 0, restricted to this residue
+        // backward pass: i = len-2*stride-1 .. 0 restricted to this residue; the value written to x[i]
+        // is the x2 of the next (lower) step
         int top = len - 2 * stride - 1;
         if (top >= r) {
-            i = top - ((top - r) % stride);
+            int i = top - ((top - r) % stride);
+            i32 x2 = x[i + stride];
             for (; i >= 0; i -= stride) {
-                i32 x1 = x[i], x2 = x[i + stride];
+                i32 x1 = x[i];
                 x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
-                x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
+                x2 = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
             }
+            x[i + stride] = (i16)x2;
         }
     }
     wave_sync();
@@ -342,6 +352,31 @@ CA_DEVFN void encode_pulses_wave(FrameLds &F, RangeEnc &ec, int N, int K)
     wave_sync();
     ec_enc_uint(ec, idx, V);
 }
+
+// Wave arg-max of (num/den) with index tie-break. `o` beats `m` iff m.den*o.num > o.den*m.num, or the
+// cross products are equal and o.id < m.id -- the order the sequential scan of vq.c:277-300 induces.
+#if defined(CA_HOST_EMU)
+CA_DEV void pvq_argmax(i32 &, i32 &, int &) {}
+#else
+#define CA_ARGMAX_STEP(ctrl, rowmask)                                                          \
+    do {                                                                                        \
+        i32 on = CA_DPP(-32767, num, ctrl, rowmask), od = CA_DPP(0, den, ctrl, rowmask);        \
+        int oi = CA_DPP(0x7fff, id, ctrl, rowmask);                                             \
+        i32 lhs = __mul24(den, on), rhs = __mul24(od, num);                                     \
+        bool take = lhs > rhs || (lhs == rhs && oi < id);                                       \
+        num = take ? on : num; den = take ? od : den; id = take ? oi : id;                      \
+    } while (0)
+CA_DEV void pvq_argmax(i32 &num, i32 &den, int &id)
+{
+    CA_ARGMAX_STEP(0x111, 0xf);
+    CA_ARGMAX_STEP(0x112, 0xf);
+    CA_ARGMAX_STEP(0x114, 0xf);
+    CA_ARGMAX_STEP(0x118, 0xf);
+    CA_ARGMAX_STEP(0x142, 0xa);
+    CA_ARGMAX_STEP(0x143, 0xc);
+    id = __builtin_amdgcn_readlane(id, 63);
+}
+#endif
 
 // alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build
 CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
@@ -403,12 +438,7 @@ CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, in
             if (mul16_16(best_den, Rxy) > mul16_16(Ryy, best_num)) { best_den = Ryy; best_num = Rxy; best_id = j; }
         }
         // wave arg-max under the same (exact, cross-multiplied) order; ties go to the lower index
-        for (int m = LANES >> 1; m > 0; m >>= 1) {
-            i32 on = shfl_xor(best_num, m), od = shfl_xor(best_den, m);
-            int oi = shfl_xor(best_id, m);
-            i32 lhs = mul16_16(best_den, on), rhs = mul16_16(od, best_num);
-            if (lhs > rhs || (lhs == rhs && oi < best_id)) { best_num = on; best_den = od; best_id = oi; }
-        }
+        pvq_argmax(best_num, best_den, best_id);
         xy = add32(xy, xa[best_id]);
         yy = add16(yy, y[best_id]);
         if (lane() == (best_id & (LANES - 1))) { y[best_id] = (i16)(y[best_id] + 2); iy[best_id] = iy[best_id] + 1; }
@@ -532,52 +562,6 @@ CA_DEVFN SplitCtx compute_theta_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i1
     return sc;
 }
 
-// quant_partition (bands.c:864-1042), encode only. Recursive (depth <= 4: LM goes 3 -> -1).
-CA_DEVFN void quant_partition_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, int N, int b, int B, int LM)
-{
-    const u8 *cache = pulse_cache(ctx.i, LM);
-    if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
-        const int B0 = B;
-        N >>= 1;
-        i16 *Y = X + N;
-        LM -= 1;
-        B = (B + 1) >> 1;
-        SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B0, LM, 0);
-        int delta = sc.delta;
-        const int itheta = sc.itheta;
-        if (B0 > 1 && (itheta & 0x3fff)) {
-            if (itheta > 8192) delta -= delta >> (4 - LM);
-            else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
-        }
-        int mbits = imax(0, imin(b, (b - delta) / 2));
-        int sbits = b - mbits;
-        ctx.remaining_bits -= sc.qalloc;
-        i32 rebalance = ctx.remaining_bits;
-        if (mbits >= sbits) {
-            quant_partition_wave(F, ec, ctx, X, N, mbits, B, LM);
-            rebalance = mbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            quant_partition_wave(F, ec, ctx, Y, N, sbits, B, LM);
-        } else {
-            quant_partition_wave(F, ec, ctx, Y, N, sbits, B, LM);
-            rebalance = sbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-            quant_partition_wave(F, ec, ctx, X, N, mbits, B, LM);
-        }
-    } else {
-        int q = bits2pulses(ctx.i, LM, b);
-        int curr_bits = pulses2bits(ctx.i, LM, q);
-        ctx.remaining_bits -= curr_bits;
-        while (ctx.remaining_bits < 0 && q > 0) {
-            ctx.remaining_bits += curr_bits;
-            q--;
-            curr_bits = pulses2bits(ctx.i, LM, q);
-            ctx.remaining_bits -= curr_bits;
-        }
-        if (q != 0) alg_quant_wave(F, ec, X, N, get_pulses(q), ctx.spread, B);
-    }
-}
-
 CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i16 *Y)     // bands.c:819-862
 {
     const i16 *x = X;
@@ -604,68 +588,99 @@ CA_DEV void deinterleave_hadamard_wave(FrameLds &F, i16 *X, int N0, int stride, 
     wave_sync();
 }
 
-// quant_band (bands.c:1044-1174), encode only, no lowband
-CA_DEVFN void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, int N, int b, int B, int LM)
+// quant_band (bands.c:1044-1174) + quant_partition (bands.c:864-1042), encode only, no lowband.
+// The reference recurses (a partition splits into two half-size partitions, LM 3 -> -1, depth <= 4); here
+// the recursion is an explicit depth-first walk: when a node splits, its second child is parked in a
+// 4-entry LDS stack (F.pstack) and revived -- with the re-balanced bit budget, bands.c:961-981 -- once the
+// first child's subtree has been coded. One call site of alg_quant, no device-side recursion.
+CA_DEV void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N, int b, int B, int LM)
 {
     int N_B = (int)((u32)N / (u32)B);
     const int longBlocks = B == 1;
     int tf_change = ctx.tf_change;
-    if (N == 1) { quant_band_n1_wave(ec, ctx, X, nullptr); return; }
+    if (N == 1) { quant_band_n1_wave(ec, ctx, Xband, nullptr); return; }
     int recombine = tf_change > 0 ? tf_change : 0;
-    for (int k = 0; k < recombine; k++) haar1_wave(X, N >> k, 1 << k);
+    for (int k = 0; k < recombine; k++) haar1_wave(Xband, N >> k, 1 << k);
     B >>= recombine;
     N_B <<= recombine;
     while ((N_B & 1) == 0 && tf_change < 0) {
-        haar1_wave(X, N_B, B);
+        haar1_wave(Xband, N_B, B);
         B <<= 1;
         N_B >>= 1;
         tf_change++;
     }
-    const int B0 = B;
-    if (B0 > 1) deinterleave_hadamard_wave(F, X, N_B >> recombine, B0 << recombine, longBlocks);
-    quant_partition_wave(F, ec, ctx, X, N, b, B, LM);
-}
+    const int B0band = B;
+    if (B0band > 1) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
 
-// quant_band_stereo (bands.c:1176-1335), encode only
-CA_DEVFN void quant_band_stereo_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int b, int B, int LM)
-{
-    if (N == 1) { quant_band_n1_wave(ec, ctx, X, Y); return; }
-    SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B, LM, 1);
-    const int itheta = sc.itheta;
-    if (N == 2) {
-        int mbits = b, sbits = 0;
-        if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
-        mbits -= sbits;
-        const int c = itheta > 8192;
-        ctx.remaining_bits -= sc.qalloc + sbits;
-        i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
-        if (sbits) {
-            int sign = ((i32)x2[0] * y2[1] - (i32)x2[1] * y2[0]) < 0;
-            ec_enc_bits(ec, (u32)sign, 1);
+    int sp = 0;
+    int xoff = 0;
+    for (;;) {
+        i16 *X = Xband + xoff;
+        const u8 *cache = pulse_cache(ctx.i, LM);
+        if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
+            const int B0 = B;
+            N >>= 1;
+            i16 *Y = X + N;
+            LM -= 1;
+            B = (B + 1) >> 1;
+            SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B0, LM, 0);
+            int delta = sc.delta;
+            const int itheta = sc.itheta;
+            if (B0 > 1 && (itheta & 0x3fff)) {
+                if (itheta > 8192) delta -= delta >> (4 - LM);
+                else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
+            }
+            const int mbits = imax(0, imin(b, (b - delta) / 2));
+            const int sbits = b - mbits;
+            ctx.remaining_bits -= sc.qalloc;
+            const int mid_first = mbits >= sbits;
+            // park the second child: {xoff, bits, N, B, LM, remaining_bits at the split, first child's bits, re-balance allowed}
+            if (lane() == 0) {
+                i32 *fr = F.pstack[sp];
+                fr[0] = mid_first ? xoff + N : xoff;
+                fr[1] = mid_first ? sbits : mbits;
+                fr[2] = N;
+                fr[3] = B;
+                fr[4] = LM;
+                fr[5] = ctx.remaining_bits;
+                fr[6] = mid_first ? mbits : sbits;
+                fr[7] = mid_first ? (itheta != 0) : (itheta != 16384);
+            }
+            sp++;
+            wave_sync();
+            if (!mid_first) xoff += N;
+            b = mid_first ? mbits : sbits;
+            continue;
         }
-        quant_band_wave(F, ec, ctx, x2, N, mbits, B, LM);
-    } else {
-        int mbits = imax(0, imin(b, (b - sc.delta) / 2));
-        int sbits = b - mbits;
-        ctx.remaining_bits -= sc.qalloc;
-        i32 rebalance = ctx.remaining_bits;
-        if (mbits >= sbits) {
-            quant_band_wave(F, ec, ctx, X, N, mbits, B, LM);
-            rebalance = mbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            quant_band_wave(F, ec, ctx, Y, N, sbits, B, LM);
-        } else {
-            quant_band_wave(F, ec, ctx, Y, N, sbits, B, LM);
-            rebalance = sbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-            quant_band_wave(F, ec, ctx, X, N, mbits, B, LM);
+        // leaf: the basic no-split case (bands.c:983-1039)
+        int q = bits2pulses(ctx.i, LM, b);
+        int curr_bits = pulses2bits(ctx.i, LM, q);
+        ctx.remaining_bits -= curr_bits;
+        while (ctx.remaining_bits < 0 && q > 0) {
+            ctx.remaining_bits += curr_bits;
+            q--;
+            curr_bits = pulses2bits(ctx.i, LM, q);
+            ctx.remaining_bits -= curr_bits;
         }
+        if (q != 0) alg_quant_wave(F, ec, X, N, get_pulses(q), ctx.spread, B);
+        if (sp == 0) break;
+        sp--;
+        const i32 *fr = F.pstack[sp];
+        xoff = fr[0];
+        b = fr[1];
+        N = fr[2];
+        B = fr[3];
+        LM = fr[4];
+        i32 rebalance = fr[6] - (fr[5] - ctx.remaining_bits);
+        if (rebalance > 3 << BITRES && fr[7]) b += rebalance - (3 << BITRES);
     }
 }
 
-// quant_all_bands(encode = 1, start 0, end 21, LM 3)  (bands.c:1337-1502)
-CA_DEVFN void quant_all_bands_wave(FrameLds &F, RangeEnc &ec, int C, int shortBlocks, int spread, int dual_stereo,
-                                   int intensity, i32 total_bits, i32 balance, int codedBands)
+// quant_all_bands(encode = 1, start 0, end 21, LM 3)  (bands.c:1337-1502) with quant_band_stereo
+// (bands.c:1176-1335) folded in: per band up to two quant_band jobs (mid/side or L/R) run through ONE
+// call site, the second with the re-balanced budget.
+CA_DEV void quant_all_bands_wave(FrameLds &F, RangeEnc &ec, int C, int shortBlocks, int spread, int dual_stereo,
+                                 int intensity, i32 total_bits, i32 balance, int codedBands)
 {
     const int LM = LM3, M = M8;
     const int B = shortBlocks ? M : 1;
@@ -691,13 +706,52 @@ CA_DEVFN void quant_all_bands_wave(FrameLds &F, RangeEnc &ec, int C, int shortBl
         }
         ctx.tf_change = F.tf_res[i];
         if (dual_stereo && i == intensity) dual_stereo = 0;
+
+        // plan the jobs
+        int njobs = 0, rebal = 0, allow2 = 0;
+        i16 *jx0 = X, *jx1 = Y;
+        int jb0 = b, jb1 = 0;
         if (dual_stereo) {
-            quant_band_wave(F, ec, ctx, X, N, b / 2, B, LM);
-            quant_band_wave(F, ec, ctx, Y, N, b / 2, B, LM);
+            njobs = 2; jb0 = b / 2; jb1 = b / 2;
         } else if (Y) {
-            quant_band_stereo_wave(F, ec, ctx, X, Y, N, b, B, LM);
+            if (N == 1) {
+                quant_band_n1_wave(ec, ctx, X, Y);
+            } else {
+                SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B, LM, 1);
+                const int itheta = sc.itheta;
+                if (N == 2) {
+                    int mbits = b, sbits = 0;
+                    if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
+                    mbits -= sbits;
+                    const int c = itheta > 8192;
+                    ctx.remaining_bits -= sc.qalloc + sbits;
+                    i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
+                    if (sbits) {
+                        int sign = ((i32)x2[0] * y2[1] - (i32)x2[1] * y2[0]) < 0;
+                        ec_enc_bits(ec, (u32)sign, 1);
+                    }
+                    njobs = 1; jx0 = x2; jb0 = mbits;
+                } else {
+                    int mbits = imax(0, imin(b, (b - sc.delta) / 2));
+                    int sbits = b - mbits;
+                    ctx.remaining_bits -= sc.qalloc;
+                    njobs = 2; rebal = 1;
+                    if (mbits >= sbits) { jx0 = X; jb0 = mbits; jx1 = Y; jb1 = sbits; allow2 = itheta != 0; }
+                    else { jx0 = Y; jb0 = sbits; jx1 = X; jb1 = mbits; allow2 = itheta != 16384; }
+                }
+            }
         } else {
-            quant_band_wave(F, ec, ctx, X, N, b, B, LM);
+            njobs = 1;
+        }
+        const i32 rebalance0 = ctx.remaining_bits;
+        for (int j = 0; j < njobs; j++) {
+            i16 *jx = j == 0 ? jx0 : jx1;
+            int jb = j == 0 ? jb0 : jb1;
+            if (j == 1 && rebal) {
+                i32 rebalance = jb0 - (rebalance0 - ctx.remaining_bits);
+                if (rebalance > 3 << BITRES && allow2) jb += rebalance - (3 << BITRES);
+            }
+            quant_band_wave(F, ec, ctx, jx, N, jb, B, LM);
         }
         balance += F.pulses[i] + tell;
     }

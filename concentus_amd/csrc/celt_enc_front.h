@@ -21,10 +21,13 @@
 
 namespace ca {
 
+// Everything is inlined into the frame kernel: a non-inlined device call on gfx9 saves/restores the live
+// VGPRs through scratch and forces by-reference state (the range coder) into memory -- measured as
+// ~60 GB of scratch traffic per 65 536-frame launch in the first version (profiles/r01_celt_first).
 #if defined(CA_HOST_EMU)
-#define CA_DEVFN static
+#define CA_DEVFN static inline
 #else
-#define CA_DEVFN __device__ __noinline__
+#define CA_DEVFN __device__ __forceinline__
 #endif
 
 enum { NB = 21, OVL = 120, FRAME = 960, MAXP = 1024, MINP = 15, LM3 = 3, M8 = 8 };
@@ -57,6 +60,7 @@ struct __attribute__((aligned(16))) FrameLds {
     i32 bits1[NB], bits2[NB], thresh[NB], trim_offset[NB];
     i32 metric[NB], path0[NB], path1[NB];
     i32 scal[16];                  // scalar hand-off slots (lane-local results published to the wave)
+    i32 pstack[4][8];              // parked second children of split partitions (quant_band_wave)
 };
 
 CA_DEV i16 *frame_X(FrameLds &F) { return reinterpret_cast<i16 *>(&F.in[0][0]); }      // X[c*960 + j]

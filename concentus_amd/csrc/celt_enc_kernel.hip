@@ -12,7 +12,7 @@
 
 namespace ca {
 
-__global__ __launch_bounds__(64) void celt_encode_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+__global__ __launch_bounds__(64, 2) void celt_encode_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
                                                          const i16 *__restrict__ pcm, u8 *__restrict__ out, int out_stride,
                                                          int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
 {

@@ -74,7 +74,7 @@ CA_DEVFN int tf_analysis_wave(FrameLds &F, int isTransient, int lambda, i32 tf_e
     }
     // Viterbi over the 21 bands: uniform scalar code
     const i8 *tab = CLT_tf_select_table + LM * 8;
-    int tf_select = 0, selcost[2];
+    int tf_select = 0, selcost0 = 0, selcost1 = 0;
     for (int sel = 0; sel < 2; sel++) {
         int cost0 = 0, cost1 = isTransient ? 0 : lambda;
         for (int i = 1; i < len; i++) {
@@ -82,9 +82,9 @@ CA_DEVFN int tf_analysis_wave(FrameLds &F, int isTransient, int lambda, i32 tf_e
             cost0 = curr0 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * sel + 0]);
             cost1 = curr1 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * sel + 1]);
         }
-        selcost[sel] = imin(cost0, cost1);
+        if (sel == 0) selcost0 = imin(cost0, cost1); else selcost1 = imin(cost0, cost1);
     }
-    if (selcost[1] < selcost[0] && isTransient) tf_select = 1;
+    if (selcost1 < selcost0 && isTransient) tf_select = 1;
     int cost0 = 0, cost1 = isTransient ? 0 : lambda;
     for (int i = 1; i < len; i++) {
         int curr0, curr1, from0 = cost0, from1 = cost1 + lambda;
@@ -115,17 +115,18 @@ CA_DEVFN void tf_encode_wave(FrameLds &F, RangeEnc &enc, int isTransient, int tf
     int tf_select_rsv = LM > 0 && tell + logp + 1 <= budget;
     budget -= tf_select_rsv;
     int curr = 0, tf_changed = 0;
-    i32 res[NB];
+    i32 *res = F.path0;                               // scratch copy of the (possibly overridden) decisions
     for (int i = 0; i < NB; i++) {
-        res[i] = F.tf_res[i];
+        int r = F.tf_res[i];
         if (tell + logp <= budget) {
-            ec_enc_bit_logp(enc, res[i] ^ curr, logp);
+            ec_enc_bit_logp(enc, r ^ curr, logp);
             tell = (u32)ec_tell(enc);
-            curr = res[i];
+            curr = r;
             tf_changed |= curr;
         } else {
-            res[i] = curr;
+            r = curr;
         }
+        st0(&res[i], r);
         logp = isTransient ? 4 : 5;
     }
     const i8 *tab = CLT_tf_select_table + LM * 8;
@@ -134,7 +135,7 @@ CA_DEVFN void tf_encode_wave(FrameLds &F, RangeEnc &enc, int isTransient, int tf
     else
         tf_select = 0;
     wave_sync();
-    for (int i = 0; i < NB; i++) st0(&F.tf_res[i], (i32)tab[4 * isTransient + 2 * tf_select + res[i]]);
+    for (int i = lane(); i < NB; i += LANES) F.tf_res[i] = (i32)tab[4 * isTransient + 2 * tf_select + res[i]];
     wave_sync();
 }
 
@@ -145,7 +146,7 @@ CA_DEVFN int coarse_energy_impl(const i16 *eBands, i16 *oldE, i16 *err, RangeEnc
 {
     const int LM = LM3;
     int badness = 0;
-    i32 prev[2] = {0, 0};
+    i32 prev0 = 0, prev1 = 0;
     i32 coef, beta;
     if (tell + 3 <= budget) ec_enc_bit_logp(enc, intra, 3);
     if (intra) { coef = 0; beta = 4915; }
@@ -155,7 +156,8 @@ CA_DEVFN int coarse_energy_impl(const i16 *eBands, i16 *oldE, i16 *err, RangeEnc
             i32 x = eBands[i + c * NB];
             i32 oldraw = oldE[i + c * NB];
             i32 oldEc = imax(-9216, oldraw);                                      // -QCONST16(9.f,DB_SHIFT)
-            i32 f = sub32(sub32(shl32(x, 7), pshr32(mul16_16(coef, oldEc), 8)), prev[c]);
+            const i32 prevc = c == 0 ? prev0 : prev1;
+            i32 f = sub32(sub32(shl32(x, 7), pshr32(mul16_16(coef, oldEc), 8)), prevc);
             int qi = add32(f, 65536) >> 17;                                       // QCONST32(.5f,DB_SHIFT+7)
             i32 decay_bound = (i16)imax(-28672, sub32(oldraw, max_decay));
             if (qi < 0 && x < decay_bound) {
@@ -184,10 +186,11 @@ CA_DEVFN int coarse_energy_impl(const i16 *eBands, i16 *oldE, i16 *err, RangeEnc
             st0(&err[i + c * NB], (i16)(pshr32(f, 7) - shl16(qi, 10)));
             badness += iabs(qi0 - qi);
             i32 q = shl32(qi, 10);
-            i32 tmp = add32(add32(pshr32(mul16_16(coef, oldEc), 8), prev[c]), shl32(q, 7));
+            i32 tmp = add32(add32(pshr32(mul16_16(coef, oldEc), 8), prevc), shl32(q, 7));
             tmp = imax(-3670016, tmp);                                            // -QCONST32(28.f,DB_SHIFT+7)
             st0(&oldE[i + c * NB], (i16)pshr32(tmp, 7));
-            prev[c] = sub32(add32(prev[c], shl32(q, 7)), mul16_16(beta, pshr32(q, 8)));
+            const i32 pn = sub32(add32(prevc, shl32(q, 7)), mul16_16(beta, pshr32(q, 8)));
+            if (c == 0) prev0 = pn; else prev1 = pn;
         }
     }
     return badness;
@@ -216,23 +219,30 @@ CA_DEVFN void quant_coarse_energy_wave(FrameLds &F, FrameCtx &fc, RangeEnc &enc,
     RangeEnc enc_start = enc;
     for (int k = lane(); k < C * NB; k += LANES) F.oldE_intra[k] = F.oldBandE[k];
     wave_sync();
-    int badness1 = 0;
-    if (two_pass || intra)
-        badness1 = coarse_energy_impl(F.bandLogE, F.oldE_intra, F.error_intra, enc, (i32)budget, (i32)tell,
-                                      CLT_e_prob_model + (LM * 2 + 1) * 42, C, 1, max_decay);
-    wave_sync();
-    if (!intra) {
-        i32 tell_intra = (i32)ec_tell_frac(enc);
-        RangeEnc enc_intra = enc;
-        u32 nstart_bytes = enc_start.offs, nintra_bytes = enc_intra.offs;
-        u32 save_bytes = nintra_bytes - nstart_bytes;
-        // save the bytes the intra pass emitted (256 bytes hold 42 symbols of <= 15+ bits with margin)
-        for (u32 k = lane(); k < save_bytes && k < 256; k += LANES) F.coarse_save[k] = enc.buf[nstart_bytes + k];
+    // Two trips through ONE inlined copy of the coder loop: pass 0 = intra (when two_pass || intra),
+    // pass 1 = inter (when !intra), with the coder snapshot/restore of quant_bands.c:304-357 in between.
+    int badness1 = 0, badness2 = 0;
+    i32 tell_intra = 0;
+    RangeEnc enc_intra = enc;
+    u32 nstart_bytes = enc_start.offs, save_bytes = 0;
+    const int force_intra = intra;
+    for (int pass = (two_pass || intra) ? 0 : 1; pass < (force_intra ? 1 : 2); pass++) {
+        if (pass == 1) {
+            tell_intra = (i32)ec_tell_frac(enc);
+            enc_intra = enc;
+            save_bytes = enc_intra.offs - nstart_bytes;
+            // save the bytes the intra pass emitted (256 bytes hold 42 symbols with margin)
+            for (u32 k = lane(); k < save_bytes && k < 256; k += LANES) F.coarse_save[k] = enc.buf[nstart_bytes + k];
+            wave_sync();
+            enc = enc_start;
+        }
+        int bad = coarse_energy_impl(F.bandLogE, pass == 0 ? F.oldE_intra : F.oldBandE, pass == 0 ? F.error_intra : F.error,
+                                     enc, (i32)budget, (i32)tell, CLT_e_prob_model + (LM * 2 + (pass == 0 ? 1 : 0)) * 42,
+                                     C, pass == 0, max_decay);
+        if (pass == 0) badness1 = bad; else badness2 = bad;
         wave_sync();
-        enc = enc_start;
-        int badness2 = coarse_energy_impl(F.bandLogE, F.oldBandE, F.error, enc, (i32)budget, (i32)tell,
-                                          CLT_e_prob_model + (LM * 2 + intra) * 42, C, 0, max_decay);
-        wave_sync();
+    }
+    if (!force_intra) {
         if (two_pass && (badness1 < badness2 || (badness1 == badness2 && (i32)ec_tell_frac(enc) + intra_bias > tell_intra))) {
             enc = enc_intra;
             for (u32 k = lane(); k < save_bytes && k < 256; k += LANES) enc.buf[nstart_bytes + k] = F.coarse_save[k];

@@ -41,6 +41,18 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 #define CA_TAP(name, p, bytes) do {} while (0)
 #endif
 
+// Stage stamps: only in the diagnostic kernel build (-DCA_STAGE_TIMING, celt_enc_kernel_diag.hip); the
+// stamp values go to a buffer of their own and feed no output (cdna_hip_programming.md, "In-kernel stamps").
+#if defined(CA_STAGE_TIMING) && !defined(CA_HOST_EMU)
+namespace ca { struct StageClock { unsigned long long *acc; unsigned long long last; }; }
+#define CA_STAMP_DECL ca::StageClock *stage_clock
+#define CA_STAMP(k) do { if (stage_clock && stage_clock->acc) { unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); stage_clock->acc[k] += _t - stage_clock->last; stage_clock->last = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+namespace ca { struct StageClock; }
+#define CA_STAMP(k) do {} while (0)
+#endif
+
 namespace ca {
 
 #if defined(CA_HOST_EMU)
@@ -64,27 +76,40 @@ template <class T> CA_DEV T shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); 
 template <class T> CA_DEV T bcast(T v, int src) { return __shfl(v, src, 64); }
 #endif
 
-// All-lanes reductions (result valid in every lane).
-CA_DEV int32_t wave_add(int32_t v)
-{
-    for (int m = LANES >> 1; m > 0; m >>= 1) v = (int32_t)((uint32_t)v + (uint32_t)shfl_xor(v, m));
-    return v;
-}
-CA_DEV int32_t wave_max(int32_t v)
-{
-    for (int m = LANES >> 1; m > 0; m >>= 1) { int32_t o = shfl_xor(v, m); v = o > v ? o : v; }
-    return v;
-}
-CA_DEV int32_t wave_min(int32_t v)
-{
-    for (int m = LANES >> 1; m > 0; m >>= 1) { int32_t o = shfl_xor(v, m); v = o < v ? o : v; }
-    return v;
-}
-CA_DEV uint32_t wave_or(uint32_t v)
-{
-    for (int m = LANES >> 1; m > 0; m >>= 1) v |= shfl_xor(v, m);
-    return v;
-}
+// ---- all-lanes reductions (result valid, and identical, in every lane) -----------------------------
+#if defined(CA_HOST_EMU)
+CA_DEV int32_t wave_add(int32_t v) { return v; }
+CA_DEV int32_t wave_max(int32_t v) { return v; }
+CA_DEV int32_t wave_min(int32_t v) { return v; }
+CA_DEV uint32_t wave_or(uint32_t v) { return v; }
+CA_DEV int64_t wave_add64(int64_t v) { return v; }
+CA_DEV int32_t uni(int32_t v) { return v; }
+CA_DEV uint32_t uni(uint32_t v) { return v; }
+#else
+// DPP row operations instead of ds_bpermute shuffles: an inclusive scan over the 64 lanes in six VALU
+// steps (row_shr 1/2/4/8 inside each row of 16, row_bcast15 into rows 1/3, row_bcast31 into the upper
+// half), after which lane 63 holds the reduction; v_readlane_b32 returns it as a wave-uniform SGPR.
+// (gfx9 DPP controls: row_shr:n = 0x110+n, row_bcast15 = 0x142, row_bcast31 = 0x143.)
+#define CA_DPP(old, v, ctrl, rowmask) __builtin_amdgcn_update_dpp((old), (v), (ctrl), (rowmask), 0xf, false)
+#define CA_WAVE_REDUCE(v, IDENT, OP)                         \
+    do {                                                      \
+        int32_t _t;                                           \
+        _t = CA_DPP(IDENT, v, 0x111, 0xf); v = OP(v, _t);     \
+        _t = CA_DPP(IDENT, v, 0x112, 0xf); v = OP(v, _t);     \
+        _t = CA_DPP(IDENT, v, 0x114, 0xf); v = OP(v, _t);     \
+        _t = CA_DPP(IDENT, v, 0x118, 0xf); v = OP(v, _t);     \
+        _t = CA_DPP(IDENT, v, 0x142, 0xa); v = OP(v, _t);     \
+        _t = CA_DPP(IDENT, v, 0x143, 0xc); v = OP(v, _t);     \
+        v = __builtin_amdgcn_readlane(v, 63);                 \
+    } while (0)
+#define CA_OP_ADD(a, b) ((int32_t)((uint32_t)(a) + (uint32_t)(b)))
+#define CA_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define CA_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define CA_OP_OR(a, b) ((a) | (b))
+CA_DEV int32_t wave_add(int32_t v) { CA_WAVE_REDUCE(v, 0, CA_OP_ADD); return v; }
+CA_DEV int32_t wave_max(int32_t v) { CA_WAVE_REDUCE(v, (int32_t)0x80000000, CA_OP_MAX); return v; }
+CA_DEV int32_t wave_min(int32_t v) { CA_WAVE_REDUCE(v, 0x7fffffff, CA_OP_MIN); return v; }
+CA_DEV uint32_t wave_or(uint32_t u) { int32_t v = (int32_t)u; CA_WAVE_REDUCE(v, 0, CA_OP_OR); return (uint32_t)v; }
 CA_DEV int64_t wave_add64(int64_t v)
 {
     for (int m = LANES >> 1; m > 0; m >>= 1) {
@@ -93,5 +118,10 @@ CA_DEV int64_t wave_add64(int64_t v)
     }
     return v;
 }
+// Assert to the compiler that a value is wave-uniform (it then lives in an SGPR and feeds scalar
+// branches / scalar loads).
+CA_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+CA_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); }
+#endif
 
 }  // namespace ca

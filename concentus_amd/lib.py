@@ -23,6 +23,7 @@ SYMBOLS = [
     ("opusgpu_celt_state_size", _i, []),
     ("opusgpu_celt_state_init", _i, [_vp, _i, _vp]),
     ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
 ]
 
 _lib = None

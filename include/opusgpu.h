@@ -111,6 +111,12 @@ int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const i
                          unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
                          int n_frames, void *hip_stream);
 
+/* Diagnostic only (never used for reported throughput): the same frame kernel with in-kernel stage
+ * stamps; d_stamps = uint64 [grid][16] cycle totals per stage, returns the grid size used. */
+int opusgpu_encode_batch_diag(const opusgpu_celt_config *cfg, const int16_t *d_pcm, unsigned char *d_out,
+                              int out_stride, int32_t *d_out_len, uint32_t *d_out_rng, int n_frames,
+                              unsigned long long *d_stamps, int max_grid, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Per-stage cycle shares of the frame kernel (diagnostic build with s_memtime stamps). GPU only."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import concentus_amd as ca
+
+NAMES = ["load+dc_reject+rate", "silence", "preemph", "prefilter(pitch)", "transient", "mdct+energies+patch", "normalise",
+         "tf_analysis", "coarse_energy", "tf_enc+spread+dynalloc+trim", "vbr", "allocation", "fine_energy", "PVQ",
+         "finalise", "done+store"]
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+kind = sys.argv[2] if len(sys.argv) > 2 else "noise"
+rng = np.random.default_rng(3)
+if kind == "noise":
+    pcm = rng.integers(-8192, 8192, size=(n, 960, 2), dtype=np.int16)
+else:
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import encode_cases as ec
+    pcm = ec.golden_module().synth_pcm("music", n, 4)
+d = torch.from_numpy(pcm).cuda()
+cfg = ca.default_config()
+stride = ca.encoder.out_stride_for(cfg)
+out = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
+lens = torch.zeros(n, dtype=torch.int32, device="cuda")
+rg = torch.zeros(n, dtype=torch.int32, device="cuda")
+grid_max = 1536
+st = torch.zeros((grid_max, 16), dtype=torch.int64, device="cuda")
+L = ca.lib.load()
+g = L.opusgpu_encode_batch_diag(C.byref(cfg), d.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
+                                st.data_ptr(), grid_max, None)
+torch.cuda.synchronize()
+assert g > 0, g
+tot = st[:g].sum(0).cpu().numpy().astype(np.float64)
+per_frame = tot / n
+res = {NAMES[k]: round(per_frame[k]) for k in range(16)}
+res["_total_cycles_per_frame"] = round(per_frame.sum())
+print(json.dumps(res, indent=1))
+print("shares %:", {NAMES[k]: round(100 * per_frame[k] / per_frame.sum(), 1) for k in range(16)})
