@@ -11,7 +11,8 @@ namespace ca {
 
 struct FrameResult { int bytes; u32 final_range; };
 
-CA_DEV void load_state(FrameCtx &fc, FrameLds &F, const opusgpu_celt_state *st, int C)
+template <class L>
+CA_DEV void load_state(FrameCtx &fc, L &F, const opusgpu_celt_state *st, int C)
 {
     fc.C = C;
     if (st) {
@@ -75,13 +76,13 @@ CA_DEV void load_state(FrameCtx &fc, FrameLds &F, const opusgpu_celt_state *st, 
 
 // Writes the stream state back (st_out may equal the input state: everything read from it -- the
 // prefilter history in particular -- has been consumed by the time this runs).
-CA_DEV void store_state(const FrameCtx &fc, FrameLds &F, opusgpu_celt_state *st, const opusgpu_celt_state *st_in)
+template <class L>
+CA_DEV void store_state(const FrameCtx &fc, L &F, opusgpu_celt_state *st)
 {
     const int C = fc.C;
     // prefilter_mem <- last 1024 samples of [history | unfiltered new]  (celt_encoder.c:1179-1187):
     // new[j] = j < 64 ? old[960 + j] : xf_unfiltered[j - 64]. The unfiltered samples were overwritten by the
     // MDCT output, so the kernel keeps them in HBM: see celt_encode_frame (hist_new).
-    (void)st_in;
     if (lane() == 0) {
         for (int k = 0; k < 4; k++) st->hp_mem[k] = fc.hp_mem[k];
         st->rng = fc.rng;
@@ -113,12 +114,40 @@ CA_DEV void store_state(const FrameCtx &fc, FrameLds &F, opusgpu_celt_state *st,
     }
 }
 
-// One frame. pcm: 960*C interleaved int16 (global). out: packet bytes (global, >= max packet size).
-// st_in == nullptr: independent first frame. st_out may be nullptr (state discarded) or == st_in.
-CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
-                                       opusgpu_celt_state *st_out, const i16 *pcm, u8 *out, StageClock *stage_clock = nullptr)
+// ---- hand-off record between the two kernels (HBM, one per frame in flight, pointer-free) ----------
+struct FrameMid {
+    // range coder state at the hand-off (RangeEnc without its buffer pointer) + the bytes emitted so far
+    u32 ec_storage, ec_end_offs, ec_end_window, ec_offs, ec_rng, ec_val, ec_ext;
+    i32 ec_nend_bits, ec_nbits_total, ec_rem, ec_error;
+    // frame-level decisions and budgets
+    i32 max_data_bytes, nbCompressedBytes, nbAvailableBytes, vbr_rate, effectiveBytes, equiv_rate, total_bits;
+    i32 silence, pitch_index, gain1, pf_on, prefilter_tapset;
+    i32 isTransient, shortBlocks, tf_chan, tf_estimate, transient_got_disabled, temporal_vbr;
+    // stream state scalars as of the hand-off (FrameCtx)
+    i32 hp_mem[4];
+    u32 rng;
+    i32 spread_decision, delayedIntra, tonal_average, lastCodedBands, hf_average, tapset_decision;
+    i32 prefilter_period, prefilter_gain, prefilter_tapset_state, consec_transient;
+    i32 preemph_memE[2];
+    i32 vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max, stereo_saving, intensity, spec_avg;
+    i32 pad[3];
+    u8 packet_head[32];
+    i32 bandE[2 * NB];
+    i16 bandLogE[2 * NB], bandLogE2[2 * NB], oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
+    i16 pad16[2];
+    i16 X[2 * FRAME];
+};
+
+// Phase 1: PCM -> FrameMid (steps 0-10 of SURVEY 3.2). pcm: 960*C interleaved int16 (global).
+// st_in == nullptr: independent first frame. st_out may be nullptr or == st_in; this phase stores the
+// time-domain part of the stream state (in_mem, prefilter_mem), phase 2 stores the rest.
+template <class L>
+CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
+                                opusgpu_celt_state *st_out, const i16 *pcm, FrameMid *mid, StageClock *stage_clock = nullptr)
 {
     (void)stage_clock;
+    if (lane() == 0) F.diag = (void *)stage_clock;
+    wave_sync();
     const int C = cfg.channels, N = FRAME, LM = LM3, M = M8, end = NB;
     FrameCtx fc;
     load_state(fc, F, st_in, C);
@@ -348,6 +377,101 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
 
     CA_TAP("X", F.in, 2 * FRAME * 2);
     CA_STAMP(6);
+    // ---- hand-off ----
+    {
+        const i16 *X = frame_X(F);
+        for (int k = lane(); k < 2 * FRAME; k += LANES) mid->X[k] = X[k];
+        for (int k = lane(); k < 2 * NB; k += LANES) {
+            mid->bandE[k] = F.bandE[k];
+            mid->bandLogE[k] = F.bandLogE[k];
+            mid->bandLogE2[k] = F.bandLogE2[k];
+            mid->oldBandE[k] = F.oldBandE[k];
+            mid->oldLogE[k] = F.oldLogE[k];
+            mid->oldLogE2[k] = F.oldLogE2[k];
+        }
+        for (int k = lane(); k < 32; k += LANES) mid->packet_head[k] = F.packet[1 + k];
+        if (lane() == 0) {
+            mid->ec_storage = enc.storage; mid->ec_end_offs = enc.end_offs; mid->ec_end_window = enc.end_window;
+            mid->ec_offs = enc.offs; mid->ec_rng = enc.rng; mid->ec_val = enc.val; mid->ec_ext = enc.ext;
+            mid->ec_nend_bits = enc.nend_bits; mid->ec_nbits_total = enc.nbits_total; mid->ec_rem = enc.rem;
+            mid->ec_error = (enc.offs > 32 || enc.end_offs > 0) ? -1 : enc.error;
+            mid->max_data_bytes = max_data_bytes; mid->nbCompressedBytes = nbCompressedBytes;
+            mid->nbAvailableBytes = nbAvailableBytes; mid->vbr_rate = vbr_rate; mid->effectiveBytes = effectiveBytes;
+            mid->equiv_rate = equiv_rate; mid->total_bits = total_bits;
+            mid->silence = silence; mid->pitch_index = pitch_index; mid->gain1 = gain1; mid->pf_on = pf_on;
+            mid->prefilter_tapset = prefilter_tapset;
+            mid->isTransient = isTransient; mid->shortBlocks = shortBlocks; mid->tf_chan = tf_chan;
+            mid->tf_estimate = tf_estimate; mid->transient_got_disabled = transient_got_disabled;
+            mid->temporal_vbr = temporal_vbr;
+            for (int k = 0; k < 4; k++) mid->hp_mem[k] = fc.hp_mem[k];
+            mid->rng = fc.rng; mid->spread_decision = fc.spread_decision; mid->delayedIntra = fc.delayedIntra;
+            mid->tonal_average = fc.tonal_average; mid->lastCodedBands = fc.lastCodedBands; mid->hf_average = fc.hf_average;
+            mid->tapset_decision = fc.tapset_decision; mid->prefilter_period = fc.prefilter_period;
+            mid->prefilter_gain = fc.prefilter_gain; mid->prefilter_tapset_state = fc.prefilter_tapset;
+            mid->consec_transient = fc.consec_transient;
+            mid->preemph_memE[0] = fc.preemph_memE[0]; mid->preemph_memE[1] = fc.preemph_memE[1];
+            mid->vbr_reservoir = fc.vbr_reservoir; mid->vbr_drift = fc.vbr_drift; mid->vbr_offset = fc.vbr_offset;
+            mid->vbr_count = fc.vbr_count; mid->overlap_max = fc.overlap_max; mid->stereo_saving = fc.stereo_saving;
+            mid->intensity = fc.intensity; mid->spec_avg = fc.spec_avg;
+        }
+    }
+}
+
+// Phase 2: FrameMid -> packet (steps 11-19). out: packet bytes (global, >= max packet size).
+template <class L>
+CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, const FrameMid *mid, opusgpu_celt_state *st_out,
+                                      u8 *out, StageClock *stage_clock = nullptr)
+{
+    (void)stage_clock;
+    if (lane() == 0) F.diag = (void *)stage_clock;
+    const int C = cfg.channels, LM = LM3, end = NB;
+    const int celt_vbr = cfg.vbr, constrained_vbr = cfg.constrained_vbr;
+    const int nbFilledBytes = 0;
+    FrameCtx fc;
+    fc.C = C;
+    fc.hist = nullptr;
+    for (int k = 0; k < 4; k++) fc.hp_mem[k] = uni(mid->hp_mem[k]);
+    fc.rng = uni(mid->rng); fc.spread_decision = uni(mid->spread_decision); fc.delayedIntra = uni(mid->delayedIntra);
+    fc.tonal_average = uni(mid->tonal_average); fc.lastCodedBands = uni(mid->lastCodedBands); fc.hf_average = uni(mid->hf_average);
+    fc.tapset_decision = uni(mid->tapset_decision); fc.prefilter_period = uni(mid->prefilter_period);
+    fc.prefilter_gain = uni(mid->prefilter_gain); fc.prefilter_tapset = uni(mid->prefilter_tapset_state);
+    fc.consec_transient = uni(mid->consec_transient);
+    fc.preemph_memE[0] = uni(mid->preemph_memE[0]); fc.preemph_memE[1] = uni(mid->preemph_memE[1]);
+    fc.vbr_reservoir = uni(mid->vbr_reservoir); fc.vbr_drift = uni(mid->vbr_drift); fc.vbr_offset = uni(mid->vbr_offset);
+    fc.vbr_count = uni(mid->vbr_count); fc.overlap_max = uni(mid->overlap_max); fc.stereo_saving = uni(mid->stereo_saving);
+    fc.intensity = uni(mid->intensity); fc.spec_avg = uni(mid->spec_avg);
+    const int max_data_bytes = uni(mid->max_data_bytes);
+    int nbCompressedBytes = uni(mid->nbCompressedBytes), nbAvailableBytes = uni(mid->nbAvailableBytes);
+    const i32 vbr_rate = uni(mid->vbr_rate), equiv_rate = uni(mid->equiv_rate);
+    int effectiveBytes = uni(mid->effectiveBytes);
+    i32 total_bits = uni(mid->total_bits);
+    const int silence = uni(mid->silence), pitch_index = uni(mid->pitch_index), pf_on = uni(mid->pf_on);
+    const i32 gain1 = uni(mid->gain1);
+    const int prefilter_tapset = uni(mid->prefilter_tapset);
+    const int isTransient = uni(mid->isTransient), shortBlocks = uni(mid->shortBlocks), tf_chan = uni(mid->tf_chan);
+    const i32 tf_estimate = uni(mid->tf_estimate), temporal_vbr = uni(mid->temporal_vbr);
+    const int transient_got_disabled = uni(mid->transient_got_disabled);
+    RangeEnc enc;
+    enc.buf = F.packet + 1;
+    enc.storage = uni(mid->ec_storage); enc.end_offs = uni(mid->ec_end_offs); enc.end_window = uni(mid->ec_end_window);
+    enc.offs = uni(mid->ec_offs); enc.rng = uni(mid->ec_rng); enc.val = uni(mid->ec_val); enc.ext = uni(mid->ec_ext);
+    enc.nend_bits = uni(mid->ec_nend_bits); enc.nbits_total = uni(mid->ec_nbits_total); enc.rem = uni(mid->ec_rem);
+    enc.error = uni(mid->ec_error);
+    {
+        i16 *X = frame_X(F);
+        for (int k = lane(); k < 2 * FRAME; k += LANES) X[k] = mid->X[k];
+        for (int k = lane(); k < 2 * NB; k += LANES) {
+            F.bandE[k] = mid->bandE[k];
+            F.bandLogE[k] = mid->bandLogE[k];
+            F.bandLogE2[k] = mid->bandLogE2[k];
+            F.oldBandE[k] = mid->oldBandE[k];
+            F.oldLogE[k] = mid->oldLogE[k];
+            F.oldLogE2[k] = mid->oldLogE2[k];
+        }
+        for (int k = lane(); k < 32; k += LANES) F.packet[1 + k] = mid->packet_head[k];
+    }
+    i32 tell;
+    wave_sync();
     // 11. TF resolution
     int tf_select;
     if (effectiveBytes >= 15 * C && cfg.complexity >= 2) {
@@ -529,7 +653,7 @@ CA_DEVFN FrameResult celt_encode_frame(FrameLds &F, const opusgpu_celt_config &c
         // opus_packet_pad to max_data_bytes: a CELT CBR packet already has that size (ret == max_data_bytes)
         if (ret != max_data_bytes) enc.error = -1;
     }
-    if (st_out) store_state(fc, F, st_out, st_in);
+    if (st_out) store_state(fc, F, st_out);
     if (lane() == 0)
         for (int k = ret; k < ((ret + 3) & ~3); k++) F.packet[k] = 0;               // deterministic pad bytes
     wave_sync();

@@ -51,7 +51,8 @@ CA_DEV u32 pvq_u(int n, int k)                                                  
 // ---- compute_allocation (rate.c:527-639 + :248-525), start 0, end 21, LM 3, encode 1 ---------------
 struct AllocOut { int codedBands; i32 balance; int intensity; int dual_stereo; };
 
-CA_DEVFN AllocOut compute_allocation_wave(FrameLds &F, RangeEnc &ec, int C, int alloc_trim, int intensity_in,
+template <class L>
+CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_trim, int intensity_in,
                                           int dual_stereo_in, i32 total, int prev, int signalBandwidth)
 {
     const int LM = LM3, end = NB, start = 0, len = NB;
@@ -233,7 +234,8 @@ CA_DEVFN AllocOut compute_allocation_wave(FrameLds &F, RangeEnc &ec, int C, int 
     return out;
 }
 
-CA_DEVFN void quant_fine_energy_wave(FrameLds &F, RangeEnc &enc, int C)                    // quant_bands.c:369-404
+template <class L>
+CA_DEVFN void quant_fine_energy_wave(L &F, RangeEnc &enc, int C)                    // quant_bands.c:369-404
 {
     for (int i = 0; i < NB; i++) {
         int fq = F.fine_quant[i];
@@ -252,7 +254,8 @@ CA_DEVFN void quant_fine_energy_wave(FrameLds &F, RangeEnc &enc, int C)         
     wave_sync();
 }
 
-CA_DEVFN void quant_energy_finalise_wave(FrameLds &F, RangeEnc &enc, int bits_left, int C)   // quant_bands.c:406-439
+template <class L>
+CA_DEVFN void quant_energy_finalise_wave(L &F, RangeEnc &enc, int bits_left, int C)   // quant_bands.c:406-439
 {
     for (int prio = 0; prio < 2; prio++) {
         for (int i = 0; i < NB && bits_left >= C; i++) {
@@ -332,7 +335,8 @@ CA_DEV void exp_rotation_wave(i16 *X, int len, int stride, int K, int spread)   
 }
 
 // encode_pulses(iy, N, K) = ec_enc_uint(icwrs(N, iy), V(N,K))  (cwrs.c:440-460)
-CA_DEVFN void encode_pulses_wave(FrameLds &F, RangeEnc &ec, int N, int K)
+template <class L>
+CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
 {
     const i32 *y = F.s.pvq.iy;
     // suffix sums k_j = sum_{t>=j} |y_t| are produced serially (cheap), the table look-ups in parallel
@@ -379,11 +383,14 @@ CA_DEV void pvq_argmax(i32 &num, i32 &den, int &id)
 #endif
 
 // alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build
-CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
+template <class L>
+CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
 {
     i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
     i32 *iy = F.s.pvq.iy;
+    CA_STAMP_F(F, 22);
     exp_rotation_wave(X, N, B, K, spread);
+    CA_STAMP_F(F, 17);
     for (int j = lane(); j < N; j += LANES) {
         i32 v = X[j];
         xa[j] = (i16)(v > 0 ? v : -v);
@@ -426,6 +433,7 @@ CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, in
         pulsesLeft = 0;
         wave_sync();
     }
+    CA_STAMP_F(F, 18);
     for (int i = 0; i < pulsesLeft; i++) {
         const int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
         yy = (i16)add32(yy, 1);
@@ -444,10 +452,12 @@ CA_DEVFN void alg_quant_wave(FrameLds &F, RangeEnc &ec, i16 *X, int N, int K, in
         if (lane() == (best_id & (LANES - 1))) { y[best_id] = (i16)(y[best_id] + 2); iy[best_id] = iy[best_id] + 1; }
         wave_sync();
     }
+    CA_STAMP_F(F, 19);
     for (int j = lane(); j < N; j += LANES)
         if (X[j] <= 0) iy[j] = -iy[j];                                            // signx[j] < 0  <=>  X[j] <= 0
     wave_sync();
     encode_pulses_wave(F, ec, N, K);
+    CA_STAMP_F(F, 20);
 }
 
 CA_DEV int stereo_itheta_wave(const i16 *X, const i16 *Y, int stereo, int N)               // vq.c:376-408
@@ -482,13 +492,15 @@ CA_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)      
 struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
 
 // compute_theta (bands.c:645-817), encode = 1
-CA_DEVFN SplitCtx compute_theta_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int *b, int B,
+template <class L>
+CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int *b, int B,
                                      int B0, int LM, int stereo)
 {
     (void)B;
     SplitCtx sc;
     const int i = ctx.i;
     int inv = 0;
+    CA_STAMP_F(F, 22);
     int pulse_cap = CLT_logN400[i] + LM * (1 << BITRES);
     int offset = (pulse_cap >> 1) - (stereo && N == 2 ? QTHETA_OFFSET_TWOPHASE : QTHETA_OFFSET);
     int qn = compute_qn(N, *b, offset, pulse_cap, stereo);
@@ -558,6 +570,7 @@ CA_DEVFN SplitCtx compute_theta_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i1
         iside = bitexact_cos((i16)(16384 - itheta));
         delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
     }
+    CA_STAMP_F(F, 16);
     sc.inv = inv; sc.imid = imid; sc.iside = iside; sc.delta = delta; sc.itheta = itheta; sc.qalloc = qalloc;
     return sc;
 }
@@ -574,7 +587,8 @@ CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i
     }
 }
 
-CA_DEV void deinterleave_hadamard_wave(FrameLds &F, i16 *X, int N0, int stride, int hadamard)   // bands.c:524-549
+template <class L>
+CA_DEV void deinterleave_hadamard_wave(L &F, i16 *X, int N0, int stride, int hadamard)   // bands.c:524-549
 {
     i16 *tmp = F.s.pvq.xabs;
     const int N = N0 * stride;
@@ -593,8 +607,10 @@ CA_DEV void deinterleave_hadamard_wave(FrameLds &F, i16 *X, int N0, int stride, 
 // the recursion is an explicit depth-first walk: when a node splits, its second child is parked in a
 // 4-entry LDS stack (F.pstack) and revived -- with the re-balanced bit budget, bands.c:961-981 -- once the
 // first child's subtree has been coded. One call site of alg_quant, no device-side recursion.
-CA_DEV void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N, int b, int B, int LM)
+template <class L>
+CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N, int b, int B, int LM)
 {
+    CA_STAMP_F(F, 22);
     int N_B = (int)((u32)N / (u32)B);
     const int longBlocks = B == 1;
     int tf_change = ctx.tf_change;
@@ -611,6 +627,7 @@ CA_DEV void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband,
     }
     const int B0band = B;
     if (B0band > 1) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
+    CA_STAMP_F(F, 21);
 
     int sp = 0;
     int xoff = 0;
@@ -679,7 +696,8 @@ CA_DEV void quant_band_wave(FrameLds &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband,
 // quant_all_bands(encode = 1, start 0, end 21, LM 3)  (bands.c:1337-1502) with quant_band_stereo
 // (bands.c:1176-1335) folded in: per band up to two quant_band jobs (mid/side or L/R) run through ONE
 // call site, the second with the re-balanced budget.
-CA_DEV void quant_all_bands_wave(FrameLds &F, RangeEnc &ec, int C, int shortBlocks, int spread, int dual_stereo,
+template <class L>
+CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int spread, int dual_stereo,
                                  int intensity, i32 total_bits, i32 balance, int codedBands)
 {
     const int LM = LM3, M = M8;

@@ -35,15 +35,36 @@ enum { SPREAD_NONE = 0, SPREAD_LIGHT = 1, SPREAD_NORMAL = 2, SPREAD_AGGRESSIVE =
 
 template <class T> CA_DEV void st0(T *p, T v) { if (lane() == 0) *p = v; }
 
-// ---- per-frame LDS working set (one per wavefront) -------------------------------------------------
-struct __attribute__((aligned(16))) FrameLds {
-    i32 in[2][FRAME + OVL];        // overlap + pre-emphasised (then comb-filtered) signal; later X[2][960] (i16)
+// ---- per-frame LDS working sets (one per wavefront) --------------------------------------------------
+// The frame is encoded by two kernels so that each phase keeps only what it needs in LDS:
+//   front (PCM -> normalised bands X + band energies + the first coded flags): the time-domain buffers
+//         dominate (~23 KB per wave);
+//   back  (TF analysis ... PVQ ... range-coder flush): X, a small scratch and the packet (~9.5 KB per
+//         wave), which lets 16 waves share a CU and overlap their serial, latency-bound chains.
+// The hand-off between them is the pointer-free FrameMid record in HBM (celt_enc.h).
+struct __attribute__((aligned(16))) FrontLds {
+    i32 in[2][FRAME + OVL];        // overlap + pre-emphasised (then comb-filtered) signal; finally X[2][960] (i16)
     i32 xf[2][FRAME];              // dc-rejected PCM (i16) -> unfiltered pre-emphasised samples -> MDCT coefficients
     union {
         i16 raw_pcm[2 * FRAME];                                     // interleaved input
         struct { i16 buf[992]; i16 xlp4[240]; i16 ylp4[484]; i32 xcorr[520]; } pitch;
         i16 trans[2][FRAME + OVL];
         int2 f2[480];
+    } s;
+    u8 packet[64];                 // only the first few range-coder bytes are produced in this phase
+    i32 bandE[2 * NB];
+    i16 bandLogE[2 * NB], bandLogE2[2 * NB];
+    i16 oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
+    i16 follower[2 * NB];
+    i16 normg[2 * NB];
+    i8 normshift[2 * NB];
+    i32 scal[16];                  // scalar hand-off slots (lane-local results published to the wave)
+    void *diag;                    // StageClock* in the diagnostic build, unused otherwise
+};
+
+struct __attribute__((aligned(16))) BackLds {
+    i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
+    union {
         struct { i16 tmp[176]; i16 tmp1[176]; } tf;
         struct { i16 y[176]; i32 iy[176]; i16 xabs[176]; } pvq;
     } s;
@@ -53,18 +74,18 @@ struct __attribute__((aligned(16))) FrameLds {
     i16 oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
     i16 oldE_intra[2 * NB], error_intra[2 * NB];
     i16 follower[2 * NB], noise_floor[NB];
-    i16 normg[2 * NB];
-    i8 normshift[2 * NB];
     u8 coarse_save[256];
     i32 offsets[NB], cap[NB], pulses[NB], fine_quant[NB], fine_priority[NB], tf_res[NB];
     i32 bits1[NB], bits2[NB], thresh[NB], trim_offset[NB];
     i32 metric[NB], path0[NB], path1[NB];
-    i32 scal[16];                  // scalar hand-off slots (lane-local results published to the wave)
+    i32 scal[16];
+    void *diag;
     i32 pstack[4][8];              // parked second children of split partitions (quant_band_wave)
 };
 
-CA_DEV i16 *frame_X(FrameLds &F) { return reinterpret_cast<i16 *>(&F.in[0][0]); }      // X[c*960 + j]
-CA_DEV i16 *frame_pcmf(FrameLds &F) { return reinterpret_cast<i16 *>(&F.xf[0][0]); }   // pcmf[c*960 + i]
+CA_DEV i16 *frame_X(FrontLds &F) { return reinterpret_cast<i16 *>(&F.in[0][0]); }      // X[c*960 + j]
+CA_DEV i16 *frame_X(BackLds &F) { return F.x16; }
+CA_DEV i16 *frame_pcmf(FrontLds &F) { return reinterpret_cast<i16 *>(&F.xf[0][0]); }   // pcmf[c*960 + i]
 
 // Uniform per-frame scalars (identical in every lane).
 struct FrameCtx {
@@ -83,7 +104,8 @@ struct FrameCtx {
 
 // ---- dc_reject (src/opus_encoder.c:362-384) + celt_maxabs16 ------------------------------------------
 // Serial per channel: lane c filters channel c. cutoff 3 Hz @ 48 kHz -> shift = ilog2(48000/9) = 12.
-CA_DEV void dc_reject_wave(FrameLds &F, FrameCtx &fc)
+template <class L>
+CA_DEV void dc_reject_wave(L &F, FrameCtx &fc)
 {
     const int C = fc.C;
     i16 *pcmf = frame_pcmf(F);
@@ -108,7 +130,8 @@ CA_DEV void dc_reject_wave(FrameLds &F, FrameCtx &fc)
 }
 
 // celt_maxabs16 over samples [i0, i1) of all channels (mathops.h:47-58)
-CA_DEV i32 maxabs_pcm(FrameLds &F, int C, int i0, int i1)
+template <class L>
+CA_DEV i32 maxabs_pcm(L &F, int C, int i0, int i1)
 {
     const i16 *pcmf = frame_pcmf(F);
     i32 mx = 0, mn = 0;
@@ -124,7 +147,8 @@ CA_DEV i32 maxabs_pcm(FrameLds &F, int C, int i0, int i1)
 }
 
 // ---- celt_preemphasis, fast path (celt_encoder.c:476-488): coef0 = 27853, SIG_SHIFT = 12 -----------
-CA_DEV void preemphasis_wave(FrameLds &F, FrameCtx &fc)
+template <class L>
+CA_DEV void preemphasis_wave(L &F, FrameCtx &fc)
 {
     const i16 *pcmf = frame_pcmf(F);
     for (int c = 0; c < fc.C; c++) {
@@ -140,13 +164,15 @@ CA_DEV void preemphasis_wave(FrameLds &F, FrameCtx &fc)
 
 // ---- pitch analysis --------------------------------------------------------------------------------
 // pre[c][k], k in [0, 1984): 1024 samples of history (stream state, HBM) followed by the 960 new ones.
-CA_DEV i32 pre_at(const FrameLds &F, const FrameCtx &fc, int c, int k)
+template <class L>
+CA_DEV i32 pre_at(const L &F, const FrameCtx &fc, int c, int k)
 {
     if (k >= MAXP) return F.xf[c][k - MAXP];
     return fc.hist ? fc.hist[c * MAXP + k] : 0;
 }
 
-CA_DEVFN void pitch_downsample_wave(FrameLds &F, const FrameCtx &fc)              // pitch.c:147-223
+template <class L>
+CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pitch.c:147-223
 {
     const int C = fc.C, len = MAXP + FRAME;
     i16 *x_lp = F.s.pitch.buf;
@@ -302,7 +328,8 @@ CA_DEV void find_best_pitch_uniform(const i32 *xcorr, const i16 *y, int len, int
 }
 
 // pitch_search(x_lp = buf+512, y = buf, len = 960, max_pitch = 979)  (pitch.c:260-369)
-CA_DEVFN int pitch_search_wave(FrameLds &F)
+template <class L>
+CA_DEVFN int pitch_search_wave(L &F)
 {
     const int len = FRAME, max_pitch = MAXP - 3 * MINP, lag = len + max_pitch;
     const i16 *y = F.s.pitch.buf, *x_lp = F.s.pitch.buf + (MAXP >> 1);
@@ -380,7 +407,8 @@ CA_DEV i32 pitch_gain_from(i32 xy, i32 xx, i32 yy, bool halve)                  
 }
 
 // remove_doubling(x = buf, maxperiod 1024, minperiod 15, N 960, &T0, prev_period, prev_gain)  (pitch.c:372-503)
-CA_DEVFN i32 remove_doubling_wave(FrameLds &F, int *T0_, int prev_period, i32 prev_gain)
+template <class L>
+CA_DEVFN i32 remove_doubling_wave(L &F, int *T0_, int prev_period, i32 prev_gain)
 {
     const int minperiod0 = MINP, maxperiod = MAXP / 2, minperiod = MINP / 2, N = FRAME / 2;
     const i16 *x = F.s.pitch.buf + maxperiod;
@@ -450,7 +478,8 @@ CA_DEVFN i32 remove_doubling_wave(FrameLds &F, int *T0_, int prev_period, i32 pr
 // comb_filter(y = in[c]+OVL, x = pre[c]+1024, T0, T1, N = 960, g0, g1, tapset0, tapset1, window, 120)
 // (celt.c:183-237; the x86 build uses the plain comb_filter_const_c, celt.c:156-181). Pure FIR on the
 // unfiltered signal, so every output sample is independent.
-CA_DEVFN void comb_filter_wave(FrameLds &F, const FrameCtx &fc, int c, int T0, int T1, i32 g0, i32 g1,
+template <class L>
+CA_DEVFN void comb_filter_wave(L &F, const FrameCtx &fc, int c, int T0, int T1, i32 g0, i32 g1,
                                int tapset0, int tapset1)
 {
     if (g0 == 0 && g1 == 0) {
@@ -493,7 +522,8 @@ CA_DEVFN void comb_filter_wave(FrameLds &F, const FrameCtx &fc, int c, int T0, i
 struct PrefilterOut { int pf_on, pitch_index, qg; i32 gain1; };
 
 // run_prefilter (celt_encoder.c:1067-1193). `in_mem` = previous frame's last 120 filtered samples (or zero).
-CA_DEVFN PrefilterOut run_prefilter_wave(FrameLds &F, FrameCtx &fc, const i32 *in_mem, int prefilter_tapset,
+template <class L>
+CA_DEVFN PrefilterOut run_prefilter_wave(L &F, FrameCtx &fc, const i32 *in_mem, int prefilter_tapset,
                                          int enabled, int nbAvailableBytes, int loss_rate)
 {
     const int C = fc.C;
@@ -558,7 +588,8 @@ CA_DEVFN PrefilterOut run_prefilter_wave(FrameLds &F, FrameCtx &fc, const i32 *i
 // ---- transient_analysis (celt_encoder.c:227-377), len = 1080 ---------------------------------------
 struct TransientOut { int is_transient, tf_chan; i32 tf_estimate; };
 
-CA_DEVFN TransientOut transient_analysis_wave(FrameLds &F, const FrameCtx &fc)
+template <class L>
+CA_DEVFN TransientOut transient_analysis_wave(L &F, const FrameCtx &fc)
 {
     const int C = fc.C, len = FRAME + OVL, len2 = len / 2;
     // serial IIR/followers: lane c owns channel c
@@ -622,7 +653,8 @@ CA_DEVFN TransientOut transient_analysis_wave(FrameLds &F, const FrameCtx &fc)
 }
 
 // ---- MDCTs of one frame (compute_mdcts, celt_encoder.c:418-461): in -> xf (as freq) ------------------
-CA_DEVFN void compute_mdcts_wave(FrameLds &F, const FrameCtx &fc, int shortBlocks)
+template <class L>
+CA_DEVFN void compute_mdcts_wave(L &F, const FrameCtx &fc, int shortBlocks)
 {
     for (int c = 0; c < fc.C; c++) {
         if (shortBlocks) {
@@ -636,7 +668,8 @@ CA_DEVFN void compute_mdcts_wave(FrameLds &F, const FrameCtx &fc, int shortBlock
 }
 
 // ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
-CA_DEVFN void band_energies_wave(FrameLds &F, const FrameCtx &fc, i16 *bandLogE)
+template <class L>
+CA_DEVFN void band_energies_wave(L &F, const FrameCtx &fc, i16 *bandLogE)
 {
     for (int c = 0; c < fc.C; c++) {
         for (int b = 0; b < NB; b++) {
@@ -664,7 +697,8 @@ CA_DEVFN void band_energies_wave(FrameLds &F, const FrameCtx &fc, i16 *bandLogE)
 }
 
 // ---- normalise_bands (bands.c:146-168): xf (freq) -> X (int16, aliases `in`) ------------------------
-CA_DEVFN void normalise_bands_wave(FrameLds &F, const FrameCtx &fc)
+template <class L>
+CA_DEVFN void normalise_bands_wave(L &F, const FrameCtx &fc)
 {
     i16 *X = frame_X(F);
     for (int k = lane(); k < fc.C * NB; k += LANES) {

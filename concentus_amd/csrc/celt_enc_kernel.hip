@@ -1,9 +1,14 @@
 // celt_enc_kernel.hip -- batched Opus CELT-only encode for gfx950 (BASELINE config #3).
 //
-// One 64-lane wavefront encodes one 20 ms frame end to end (PCM -> packet): workgroup = one wave, its
-// whole working set (FrameLds, ~26 KB) in LDS, grid-stride over the frames of the batch. Frames are
-// independent units (streams advance one frame per launch), so the batch shards across workgroups,
-// CUs and GPUs with no communication.
+// One 64-lane wavefront encodes one 20 ms frame (workgroup = one wave), in two kernels so that each
+// phase keeps only its own working set in LDS (see FrontLds / BackLds in celt_enc_front.h):
+//   celt_front_kernel  PCM -> FrameMid   (dc_reject, pre-emphasis, pitch pre-filter, transient analysis,
+//                                         MDCT, band energies, normalisation): ~23 KB LDS, 6 waves/CU
+//   celt_back_kernel   FrameMid -> packet (TF, coarse/fine energy, allocation, PVQ, range coder):
+//                                         ~9.6 KB LDS, 16 waves/CU -- the serial, latency-bound 70 %
+// FrameMid records live in a caller-provided HBM workspace; batches larger than the workspace are
+// processed in chunks on the same stream. Frames are independent units (streams advance one frame per
+// call), so the batch shards across workgroups, CUs and GPUs with no communication.
 //
 // Replaces, for 48 kHz / 20 ms / restricted-lowdelay / fullband: opus_encode() (opus-fix/src/opus_encoder.c:2007)
 // -> opus_encode_native (:938) -> celt_encode_with_ec (opus-fix/celt/celt_encoder.c:1379).
@@ -12,14 +17,25 @@
 
 namespace ca {
 
-__global__ __launch_bounds__(64, 2) void celt_encode_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
-                                                         const i16 *__restrict__ pcm, u8 *__restrict__ out, int out_stride,
-                                                         int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+__global__ __launch_bounds__(64, 2) void celt_front_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+                                                           const i16 *__restrict__ pcm, FrameMid *__restrict__ mid, int nframes)
 {
-    __shared__ FrameLds F;
+    __shared__ FrontLds F;
     for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
         opusgpu_celt_state *st = states ? states + n : nullptr;
-        FrameResult r = celt_encode_frame(F, cfg, st, st, pcm + (size_t)n * FRAME * cfg.channels, out + (size_t)n * out_stride);
+        celt_encode_front(F, cfg, st, st, pcm + (size_t)n * FRAME * cfg.channels, mid + n);
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64, 4) void celt_back_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+                                                          const FrameMid *__restrict__ mid, u8 *__restrict__ out, int out_stride,
+                                                          int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+{
+    __shared__ BackLds F;
+    for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
+        opusgpu_celt_state *st = states ? states + n : nullptr;
+        FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
         if (lane() == 0) {
             out_len[n] = r.bytes;
             out_rng[n] = r.final_range;
@@ -79,20 +95,36 @@ extern "C" int opusgpu_celt_state_init(void *d_states, int n_streams, void *stre
     return opusgpu_check_launch();
 }
 
+extern "C" size_t opusgpu_encode_workspace_bytes(int n_frames)
+{
+    return n_frames <= 0 ? 0 : (size_t)n_frames * sizeof(FrameMid);
+}
+
 extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const int16_t *d_pcm,
                                     unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
-                                    int n_frames, void *stream)
+                                    int n_frames, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     int rc = config_ok(cfg);
     if (rc != OPUSGPU_OK) return rc;
     if (n_frames < 0) return OPUSGPU_BAD_ARG;
     if (n_frames == 0) return OPUSGPU_OK;
-    if (!d_pcm || !d_out || !d_out_len || !d_out_rng) return OPUSGPU_BAD_ARG;
+    if (!d_pcm || !d_out || !d_out_len || !d_out_rng || !d_workspace) return OPUSGPU_BAD_ARG;
     int maxbytes = cfg->max_data_bytes < 1276 ? cfg->max_data_bytes : 1276;
     if (out_stride < ((maxbytes + 3) & ~3) || (out_stride & 3)) return OPUSGPU_BUFFER_TOO_SMALL;
-    int cap = opusgpu_num_cus() * 6;               // ~26 KB LDS per workgroup -> 6 resident per CU
-    int grid = n_frames < cap ? n_frames : cap;
-    hipLaunchKernelGGL(celt_encode_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, *cfg,
-                       (opusgpu_celt_state *)d_states, d_pcm, d_out, out_stride, d_out_len, d_out_rng, n_frames);
+    size_t chunk = workspace_bytes / sizeof(FrameMid);
+    if (chunk == 0) return OPUSGPU_BUFFER_TOO_SMALL;
+    const int cus = opusgpu_num_cus();
+    opusgpu_celt_state *st = (opusgpu_celt_state *)d_states;
+    FrameMid *mid = (FrameMid *)d_workspace;
+    hipStream_t s = (hipStream_t)stream;
+    for (size_t first = 0; first < (size_t)n_frames; first += chunk) {
+        int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
+        int g1 = n < cus * 6 ? n : cus * 6;          // ~23 KB LDS per workgroup -> 6 resident per CU
+        int g2 = n < cus * 16 ? n : cus * 16;        // ~9.6 KB LDS per workgroup -> 16 resident per CU
+        hipLaunchKernelGGL(celt_front_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr,
+                           d_pcm + first * FRAME * cfg->channels, mid, n);
+        hipLaunchKernelGGL(celt_back_kernel, dim3(g2), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid,
+                           d_out + first * (size_t)out_stride, out_stride, d_out_len + first, d_out_rng + first, n);
+    }
     return opusgpu_check_launch();
 }

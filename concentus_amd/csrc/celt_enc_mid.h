@@ -40,7 +40,8 @@ CA_DEV i32 l1_metric_wave(const i16 *tmp, int N, int LM, i32 bias)              
 }
 
 // tf_analysis(m, len = 21, isTransient, tf_res, lambda, X, N0 = 960, LM = 3, &tf_sum, tf_estimate, tf_chan)
-CA_DEVFN int tf_analysis_wave(FrameLds &F, int isTransient, int lambda, i32 tf_estimate, int tf_chan)
+template <class L>
+CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate, int tf_chan)
 {
     const int len = NB, LM = LM3;
     const i16 *X = frame_X(F);
@@ -106,7 +107,8 @@ CA_DEVFN int tf_analysis_wave(FrameLds &F, int isTransient, int lambda, i32 tf_e
     return tf_select;
 }
 
-CA_DEVFN void tf_encode_wave(FrameLds &F, RangeEnc &enc, int isTransient, int tf_select)   // celt_encoder.c:715-754
+template <class L>
+CA_DEVFN void tf_encode_wave(L &F, RangeEnc &enc, int isTransient, int tf_select)   // celt_encoder.c:715-754
 {
     const int LM = LM3;
     u32 budget = enc.storage * 8;
@@ -197,7 +199,8 @@ CA_DEVFN int coarse_energy_impl(const i16 *eBands, i16 *oldE, i16 *err, RangeEnc
 }
 
 // quant_coarse_energy (quant_bands.c:269-367) with start 0, end = effEnd = 21, force_intra 0, lfe 0.
-CA_DEVFN void quant_coarse_energy_wave(FrameLds &F, FrameCtx &fc, RangeEnc &enc, u32 budget, int nbAvailableBytes,
+template <class L>
+CA_DEVFN void quant_coarse_energy_wave(L &F, FrameCtx &fc, RangeEnc &enc, u32 budget, int nbAvailableBytes,
                                        int two_pass, int loss_rate)
 {
     const int C = fc.C, LM = LM3;
@@ -259,7 +262,8 @@ CA_DEVFN void quant_coarse_energy_wave(FrameLds &F, FrameCtx &fc, RangeEnc &enc,
 }
 
 // spreading_decision (bands.c:428-510) with end = 21, M = 8
-CA_DEVFN int spreading_decision_wave(FrameLds &F, FrameCtx &fc, int update_hf)
+template <class L>
+CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
 {
     const int C = fc.C, M = M8, end = NB;
     const i16 *X = frame_X(F);
@@ -326,7 +330,8 @@ CA_DEV i32 median_of_3(const i16 *x)                                            
 
 // dynalloc_analysis (celt_encoder.c:932-1065), start 0, end 21, lfe 0, surround_dynalloc all zero.
 // Small sequential recurrences over 21 bands: run on lane 0, results published through LDS.
-CA_DEVFN i32 dynalloc_analysis_wave(FrameLds &F, const FrameCtx &fc, int lsb_depth, int isTransient, int vbr,
+template <class L>
+CA_DEVFN i32 dynalloc_analysis_wave(L &F, const FrameCtx &fc, int lsb_depth, int isTransient, int vbr,
                                     int constrained_vbr, int effectiveBytes, i32 *tot_boost_)
 {
     const int C = fc.C, LM = LM3, end = NB;
@@ -411,15 +416,16 @@ CA_DEVFN i32 dynalloc_analysis_wave(FrameLds &F, const FrameCtx &fc, int lsb_dep
 }
 
 // stereo_analysis (celt_encoder.c:840-873), LM = 3
-CA_DEVFN int stereo_analysis_wave(FrameLds &F)
+template <class L>
+CA_DEVFN int stereo_analysis_wave(L &F)
 {
     const i16 *X = frame_X(F);
     i32 pLR = 0, pMS = 0;
     const int jend = CLT_eband5ms[13] << LM3;
     for (int j = lane(); j < jend; j += LANES) {
-        i32 L = X[j], R = X[FRAME + j];
-        i32 Mi = add32(L, R), S = sub32(L, R);
-        pLR = add32(pLR, add32(L < 0 ? -L : L, R < 0 ? -R : R));
+        i32 Lv = X[j], R = X[FRAME + j];
+        i32 Mi = add32(Lv, R), S = sub32(Lv, R);
+        pLR = add32(pLR, add32(Lv < 0 ? -Lv : Lv, R < 0 ? -R : R));
         pMS = add32(pMS, add32(Mi < 0 ? -Mi : Mi, S < 0 ? -S : S));
     }
     i32 sumLR = add32(1, wave_add(pLR)), sumMS = add32(1, wave_add(pMS));
@@ -440,7 +446,8 @@ CA_DEV int hysteresis_decision(i32 val, const i16 *thresholds, const i16 *hyster
 }
 
 // alloc_trim_analysis (celt_encoder.c:756-838), end 21, LM 3, no float analysis, surround_trim 0
-CA_DEVFN int alloc_trim_analysis_wave(FrameLds &F, FrameCtx &fc, i32 tf_estimate, int intensity)
+template <class L>
+CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int intensity)
 {
     const int C = fc.C, LM = LM3, end = NB;
     const i16 *X = frame_X(F);

@@ -54,6 +54,22 @@ def _check_pcm(pcm, channels):
         raise ValueError("pcm must have shape [frames][960][%d]" % channels)
 
 
+_WORKSPACE = {}
+WORKSPACE_FRAMES = 32768      # hand-off records kept in HBM at once (larger batches are chunked by the library)
+
+
+def _workspace(device, n_frames):
+    """Per-device scratch for the hand-off between the two kernels (allocated once, reused)."""
+    import torch
+    L = _lib.load()
+    need = L.opusgpu_encode_workspace_bytes(min(max(n_frames, 1), WORKSPACE_FRAMES))
+    ws = _WORKSPACE.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((need,), dtype=torch.uint8, device=device)
+        _WORKSPACE[device] = ws
+    return ws
+
+
 def _encode(cfg, states_ptr, pcm):
     import torch
     _check_pcm(pcm, cfg.channels)
@@ -62,8 +78,10 @@ def _encode(cfg, states_ptr, pcm):
     out = torch.zeros((n, stride), dtype=torch.uint8, device=pcm.device)
     lens = torch.empty((n,), dtype=torch.int32, device=pcm.device)
     rng = torch.empty((n,), dtype=torch.int32, device=pcm.device)     # uint32 bit pattern
+    ws = _workspace(pcm.device, n)
     rc = _lib.load().opusgpu_encode_batch(C.byref(cfg), states_ptr, pcm.data_ptr(), out.data_ptr(), stride,
-                                          lens.data_ptr(), rng.data_ptr(), n, _lib.current_stream_handle())
+                                          lens.data_ptr(), rng.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                          _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_encode_batch")
     return out, lens, rng
 

@@ -22,8 +22,9 @@ SYMBOLS = [
     ("opusgpu_clt_mdct_backward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_celt_state_size", _i, []),
     ("opusgpu_celt_state_init", _i, [_vp, _i, _vp]),
-    ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
-    ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    ("opusgpu_encode_workspace_bytes", C.c_size_t, [_i]),
+    ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
+    ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
 
 _lib = None

@@ -14,6 +14,7 @@
  */
 #ifndef OPUSGPU_H
 #define OPUSGPU_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,17 +106,21 @@ int opusgpu_celt_state_init(void *d_states, int n_streams, void *hip_stream);
  *   d_out_len  device, int32 [n_frames]: packet length, or a negative OPUSGPU_* code for that frame
  *              (opus_encode's return value).
  *   d_out_rng  device, uint32 [n_frames]: OPUS_GET_FINAL_RANGE after the frame.
- * Asynchronous on hip_stream. Returns OPUSGPU_UNIMPLEMENTED for configurations outside the
- * stereo/fullband CELT-only operating region. */
+ *   d_workspace  device scratch for the hand-off between the two kernels of the path; size it with
+ *              opusgpu_encode_workspace_bytes(n). A smaller workspace is legal: the batch is then processed
+ *              in chunks of workspace_bytes / opusgpu_encode_workspace_bytes(1) frames.
+ * Asynchronous on hip_stream (no allocation, no synchronisation inside: graph-capturable). Returns
+ * OPUSGPU_UNIMPLEMENTED for configurations outside the stereo/fullband CELT-only operating region. */
+size_t opusgpu_encode_workspace_bytes(int n_frames);
 int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const int16_t *d_pcm,
                          unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
-                         int n_frames, void *hip_stream);
+                         int n_frames, void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
-/* Diagnostic only (never used for reported throughput): the same frame kernel with in-kernel stage
- * stamps; d_stamps = uint64 [grid][16] cycle totals per stage, returns the grid size used. */
+/* Diagnostic only (never used for reported throughput): the same kernels with in-kernel stage stamps;
+ * d_stamps = zero-initialised uint64 [4096][24] cycle totals per stage and workgroup. */
 int opusgpu_encode_batch_diag(const opusgpu_celt_config *cfg, const int16_t *d_pcm, unsigned char *d_out,
                               int out_stride, int32_t *d_out_len, uint32_t *d_out_rng, int n_frames,
-                              unsigned long long *d_stamps, int max_grid, void *hip_stream);
+                              void *d_workspace, size_t workspace_bytes, unsigned long long *d_stamps, void *hip_stream);
 
 #ifdef __cplusplus
 }

@@ -28,22 +28,30 @@ extern "C" int emu_celt_encode_frames(const opusgpu_celt_config *cfg, opusgpu_ce
                                       const int16_t *pcm, int nframes, int frames_per_stream,
                                       unsigned char *out, int out_stride, int *out_len, uint32_t *out_rng)
 {
-    // frames are laid out stream-major: frame f of stream s at index s*frames_per_stream + f
-    FrameLds *F = (FrameLds *)aligned_alloc(64, sizeof(FrameLds));
+    // frames are laid out stream-major: frame f of stream s at index s*frames_per_stream + f.
+    // Runs the same two phases as the GPU kernels (front -> FrameMid -> back).
+    FrontLds *F1 = (FrontLds *)aligned_alloc(64, sizeof(FrontLds) + 64);
+    BackLds *F2 = (BackLds *)aligned_alloc(64, sizeof(BackLds) + 64);
+    FrameMid *mid = (FrameMid *)aligned_alloc(64, sizeof(FrameMid) + 64);
     const int C = cfg->channels;
     for (int n = 0; n < nframes; n++) {
-        memset(F, 0xAB, sizeof(FrameLds));      // poison: catch reads of never-written LDS
+        memset(F1, 0xAB, sizeof(FrontLds));     // poison: catch reads of never-written LDS
+        memset(F2, 0xAB, sizeof(BackLds));
+        memset(mid, 0xCD, sizeof(FrameMid));
         opusgpu_celt_state *st = states ? &states[n / frames_per_stream] : NULL;
-        FrameResult r = celt_encode_frame(*F, *cfg, st, st, pcm + (size_t)n * 960 * C, out + (size_t)n * out_stride);
+        celt_encode_front(*F1, *cfg, st, st, pcm + (size_t)n * 960 * C, mid);
+        FrameResult r = celt_encode_back(*F2, *cfg, mid, st, out + (size_t)n * out_stride);
         out_len[n] = r.bytes;
         out_rng[n] = r.final_range;
     }
-    free(F);
+    free(F1);
+    free(F2);
+    free(mid);
     return 0;
 }
 
 extern "C" int emu_sizeof_state(void) { return (int)sizeof(opusgpu_celt_state); }
-extern "C" int emu_sizeof_frame_lds(void) { return (int)sizeof(FrameLds); }
+extern "C" int emu_sizeof_frame_lds(void) { return (int)(sizeof(FrontLds) * 100000 + sizeof(BackLds)); }
 
 // MDCT device functions under emulation (same sources as the MDCT-only kernels)
 extern "C" void emu_mdct_forward(const int32_t *in, int32_t *out, int shift)

@@ -13,7 +13,9 @@ import concentus_amd as ca
 
 NAMES = ["load+dc_reject+rate", "silence", "preemph", "prefilter(pitch)", "transient", "mdct+energies+patch", "normalise",
          "tf_analysis", "coarse_energy", "tf_enc+spread+dynalloc+trim", "vbr", "allocation", "fine_energy", "PVQ",
-         "finalise", "done+store"]
+         "finalise", "done+store",
+         "pvq:theta", "pvq:exp_rotation", "pvq:presearch", "pvq:greedy", "pvq:encode_pulses", "pvq:band_setup", "pvq:other", "-"]
+NS = 24
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 kind = sys.argv[2] if len(sys.argv) > 2 else "noise"
@@ -30,16 +32,16 @@ stride = ca.encoder.out_stride_for(cfg)
 out = torch.zeros((n, stride), dtype=torch.uint8, device="cuda")
 lens = torch.zeros(n, dtype=torch.int32, device="cuda")
 rg = torch.zeros(n, dtype=torch.int32, device="cuda")
-grid_max = 1536
-st = torch.zeros((grid_max, 16), dtype=torch.int64, device="cuda")
+st = torch.zeros((4096, NS), dtype=torch.int64, device="cuda")
 L = ca.lib.load()
+ws = torch.empty((L.opusgpu_encode_workspace_bytes(n),), dtype=torch.uint8, device="cuda")
 g = L.opusgpu_encode_batch_diag(C.byref(cfg), d.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
-                                st.data_ptr(), grid_max, None)
+                                ws.data_ptr(), ws.numel(), st.data_ptr(), None)
 torch.cuda.synchronize()
-assert g > 0, g
-tot = st[:g].sum(0).cpu().numpy().astype(np.float64)
+assert g == 0, g
+tot = st.sum(0).cpu().numpy().astype(np.float64)
 per_frame = tot / n
-res = {NAMES[k]: round(per_frame[k]) for k in range(16)}
+res = {NAMES[k]: round(per_frame[k]) for k in range(NS)}
 res["_total_cycles_per_frame"] = round(per_frame.sum())
 print(json.dumps(res, indent=1))
-print("shares %:", {NAMES[k]: round(100 * per_frame[k] / per_frame.sum(), 1) for k in range(16)})
+print("shares %:", {NAMES[k]: round(100 * per_frame[k] / per_frame.sum(), 1) for k in range(NS)})
