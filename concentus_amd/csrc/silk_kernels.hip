@@ -1,0 +1,527 @@
+// silk_kernels.hip -- the two SILK fixed-point inner loops named by the north star, batched over
+// function-boundary records (BASELINE config #4).
+//
+//   silk_burg_kernel  <- silk_burg_modified_c        opus-fix/silk/fixed/burg_modified_FIX.c:45-275
+//   silk_nsq_kernel   <- silk_NSQ_c                  opus-fix/silk/NSQ.c:74-180
+//                        silk_noise_shape_quantizer  opus-fix/silk/NSQ.c:183-421
+//                        silk_nsq_scale_states       opus-fix/silk/NSQ.c:423-496
+//                        silk_LPC_analysis_filter    opus-fix/silk/LPC_analysis_filter.c:47-108 (FIXED_POINT branch)
+//
+// Mapping: both loops are recurrences that are serial in their own index (Burg: order n depends on
+// order n-1; NSQ: sample i feeds back into sample i+1 through four filters), with only ~16-wide inner
+// products. A wavefront per record would leave 48 lanes idle and pay a cross-lane reduction per
+// sample, so here ONE LANE owns ONE record and a wavefront advances 64 independent records in
+// lock-step: the loop trip counts (order, subframe length) are the same for every record of a batch, so
+// the wave stays converged, per-lane temporaries are indexed uniformly (scratch accesses coalesce), the
+// short filter states (sAR2, the last 16 sLPC samples) live in registers, and the only divergent
+// addresses are the pitch-lag taps.
+//
+// Arithmetic: the reference's x86-64 build uses the 64-bit macro forms (OPUS_FAST_INT64, silk/macros.h:47-102);
+// 16x32 products are evaluated on split halves (full-rate 24-bit multiplier), 32x32 ones as 64-bit.
+#include "fixmath.h"
+#include "opusgpu_internal.h"
+#include "../../include/opusgpu_silk.h"
+
+namespace ca {
+
+CA_DEV i32 s_smulwb(i32 a, i32 b16) { b16 = (i16)b16; return (i32)((u32)__mul24(a >> 16, b16) + (u32)(__mul24((i32)(a & 0xffff), b16) >> 16)); }
+CA_DEV i32 s_smlawb(i32 a, i32 b, i32 c16) { return (i32)((u32)a + (u32)s_smulwb(b, c16)); }
+CA_DEV i32 s_smlawt(i32 a, i32 b, i32 c) { return (i32)((u32)a + (u32)s_smulwb(b, c >> 16)); }
+CA_DEV i32 s_smulww(i32 a, i32 b) { return (i32)(((i64)a * b) >> 16); }
+CA_DEV i32 s_smlaww(i32 a, i32 b, i32 c) { return (i32)((u32)a + (u32)s_smulww(b, c)); }
+CA_DEV i32 s_smulbb(i32 a, i32 b) { return __mul24((i32)(i16)a, (i32)(i16)b); }
+CA_DEV i32 s_smmul(i32 a, i32 b) { return (i32)(((i64)a * b) >> 32); }
+CA_DEV i32 s_rshift_round(i32 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : ((a >> (s - 1)) + 1) >> 1; }
+CA_DEV i32 s_abs(i32 a) { return a > 0 ? a : (i32)(0u - (u32)a); }
+CA_DEV int s_clz32(i32 x) { return x ? __clz(x) : 32; }
+CA_DEV i32 s_limit(i32 a, i32 l1, i32 l2) { return l1 > l2 ? (a > l1 ? l1 : (a < l2 ? l2 : a)) : (a > l2 ? l2 : (a < l1 ? l1 : a)); }
+CA_DEV i32 s_lshift_sat32(i32 a, int s) { return shl32(s_limit(a, (i32)0x80000000 >> s, 0x7FFFFFFF >> s), s); }
+CA_DEV i32 s_addw(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+CA_DEV i32 s_subw(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
+
+CA_DEV i32 s_div32_varq(i32 a32, i32 b32, int Qres)                 // Inlines.h:96-139
+{
+    int a_headrm = s_clz32(s_abs(a32)) - 1;
+    i32 a32_nrm = shl32(a32, a_headrm);
+    int b_headrm = s_clz32(s_abs(b32)) - 1;
+    i32 b32_nrm = shl32(b32, b_headrm);
+    i32 b32_inv = (0x7FFFFFFF >> 2) / (b32_nrm >> 16);
+    i32 result = s_smulwb(a32_nrm, b32_inv);
+    a32_nrm = (i32)((u32)a32_nrm - ((u32)s_smmul(b32_nrm, result) << 3));
+    result = s_smlawb(result, a32_nrm, b32_inv);
+    int lshift = 29 + a_headrm - b_headrm - Qres;
+    if (lshift < 0) return s_lshift_sat32(result, -lshift);
+    return lshift < 32 ? result >> lshift : 0;
+}
+
+CA_DEV i32 s_inverse32_varq(i32 b32, int Qres)                      // Inlines.h:142-186
+{
+    int b_headrm = s_clz32(s_abs(b32)) - 1;
+    i32 b32_nrm = shl32(b32, b_headrm);
+    i32 b32_inv = (0x7FFFFFFF >> 2) / (b32_nrm >> 16);
+    i32 result = shl32(b32_inv, 16);
+    i32 err_Q32 = shl32(((i32)1 << 29) - s_smulwb(b32_nrm, b32_inv), 3);
+    result = s_smlaww(result, err_Q32, b32_inv);
+    int lshift = 61 - b_headrm - Qres;
+    if (lshift <= 0) return s_lshift_sat32(result, -lshift);
+    return lshift < 32 ? result >> lshift : 0;
+}
+
+CA_DEV i32 s_sqrt_approx(i32 x)                                     // Inlines.h:68-93
+{
+    if (x <= 0) return 0;
+    int lz = s_clz32(x);
+    int rot = 24 - lz;
+    u32 ux = (u32)x;
+    u32 rr = rot == 0 ? ux : rot < 0 ? ((ux << (u32)-rot) | (ux >> (32 - (u32)-rot))) : ((ux << (32 - rot)) | (ux >> rot));
+    i32 frac_Q7 = (i32)(rr & 0x7f);
+    i32 y = (lz & 1) ? 32768 : 46214;
+    y >>= (lz >> 1);
+    return s_smlawb(y, y, s_smulbb(213, frac_Q7));
+}
+
+enum { QA = 25, COND_FAC_Q32 = 42950 };                              // SILK_FIX_CONST(FIND_LPC_COND_FAC = 1e-5f, 32)
+
+// ---- silk_burg_modified: one lane per record --------------------------------------------------------
+__global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__restrict__ recs, opusgpu_burg_out *__restrict__ outs, int n_rec)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_burg_in &in = recs[r];
+    const i16 *x = in.x;
+    const int subfr_length = in.subfr_length, nb_subfr = in.nb_subfr, D = in.D;
+    const i32 minInvGain_Q30 = in.minInvGain_Q30;
+    i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
+    i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
+    int k, n, s, lz, rshifts, reached_max_gain;
+    i64 C0_64 = 0;
+    for (k = 0; k < subfr_length * nb_subfr; k++) C0_64 += __mul24(x[k], x[k]);
+    {
+        i32 hi = (i32)(C0_64 >> 32);
+        lz = hi == 0 ? 32 + s_clz32((i32)C0_64) : s_clz32(hi);
+    }
+    rshifts = 32 + 1 + 2 - lz;
+    if (rshifts > 32 - QA) rshifts = 32 - QA;
+    if (rshifts < -16) rshifts = -16;
+    C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
+    CAb[0] = CAf[0] = s_addw(s_addw(C0, s_smmul(COND_FAC_Q32, C0)), 1);
+    for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
+    if (rshifts > 0) {
+        for (s = 0; s < nb_subfr; s++) {
+            const i16 *xp = x + s * subfr_length;
+            for (n = 1; n < D + 1; n++) {
+                i64 acc = 0;
+                for (k = 0; k < subfr_length - n; k++) acc += __mul24(xp[k], xp[k + n]);
+                C_first_row[n - 1] = s_addw(C_first_row[n - 1], (i32)(acc >> rshifts));
+            }
+        }
+    } else {
+        for (s = 0; s < nb_subfr; s++) {
+            const i16 *xp = x + s * subfr_length;
+            for (n = 1; n < D + 1; n++) {
+                i32 d = 0;           // celt_pitch_xcorr + tail loop = the full lag-n product, 32-bit wrap-around
+                for (k = n; k < subfr_length; k++) d = s_addw(d, __mul24(xp[k], xp[k - n]));
+                C_first_row[n - 1] = s_addw(C_first_row[n - 1], shl32(d, -rshifts));
+            }
+        }
+    }
+    for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
+    invGain_Q30 = (i32)1 << 30;
+    reached_max_gain = 0;
+    for (n = 0; n < D; n++) {
+        if (rshifts > -2) {
+            for (s = 0; s < nb_subfr; s++) {
+                const i16 *xp = x + s * subfr_length;
+                x1 = (i32)(0u - (u32)shl32(xp[n], 16 - rshifts));
+                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], 16 - rshifts));
+                tmp1 = shl32(xp[n], QA - 16);
+                tmp2 = shl32(xp[subfr_length - n - 1], QA - 16);
+                for (k = 0; k < n; k++) {
+                    C_first_row[k] = s_smlawb(C_first_row[k], x1, xp[n - k - 1]);
+                    C_last_row[k] = s_smlawb(C_last_row[k], x2, xp[subfr_length - n + k]);
+                    Atmp_QA = Af_QA[k];
+                    tmp1 = s_smlawb(tmp1, Atmp_QA, xp[n - k - 1]);
+                    tmp2 = s_smlawb(tmp2, Atmp_QA, xp[subfr_length - n + k]);
+                }
+                tmp1 = shl32((i32)(0u - (u32)tmp1), 32 - QA - rshifts);
+                tmp2 = shl32((i32)(0u - (u32)tmp2), 32 - QA - rshifts);
+                for (k = 0; k <= n; k++) {
+                    CAf[k] = s_smlawb(CAf[k], tmp1, xp[n - k]);
+                    CAb[k] = s_smlawb(CAb[k], tmp2, xp[subfr_length - n + k - 1]);
+                }
+            }
+        } else {
+            for (s = 0; s < nb_subfr; s++) {
+                const i16 *xp = x + s * subfr_length;
+                x1 = (i32)(0u - (u32)shl32(xp[n], -rshifts));
+                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], -rshifts));
+                tmp1 = shl32(xp[n], 17);
+                tmp2 = shl32(xp[subfr_length - n - 1], 17);
+                for (k = 0; k < n; k++) {
+                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)(i32)xp[n - k - 1]);
+                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)(i32)xp[subfr_length - n + k]);
+                    Atmp1 = s_rshift_round(Af_QA[k], QA - 17);
+                    tmp1 = (i32)((u32)tmp1 + (u32)(i32)xp[n - k - 1] * (u32)Atmp1);
+                    tmp2 = (i32)((u32)tmp2 + (u32)(i32)xp[subfr_length - n + k] * (u32)Atmp1);
+                }
+                tmp1 = (i32)(0u - (u32)tmp1);
+                tmp2 = (i32)(0u - (u32)tmp2);
+                for (k = 0; k <= n; k++) {
+                    CAf[k] = s_smlaww(CAf[k], tmp1, shl32(xp[n - k], -rshifts - 1));
+                    CAb[k] = s_smlaww(CAb[k], tmp2, shl32(xp[subfr_length - n + k - 1], -rshifts - 1));
+                }
+            }
+        }
+        tmp1 = C_first_row[n];
+        tmp2 = C_last_row[n];
+        num = 0;
+        nrg = s_addw(CAb[0], CAf[0]);
+        for (k = 0; k < n; k++) {
+            Atmp_QA = Af_QA[k];
+            lz = s_clz32(s_abs(Atmp_QA)) - 1;
+            if (lz > 32 - QA) lz = 32 - QA;
+            Atmp1 = shl32(Atmp_QA, lz);
+            tmp1 = s_addw(tmp1, shl32(s_smmul(C_last_row[n - k - 1], Atmp1), 32 - QA - lz));
+            tmp2 = s_addw(tmp2, shl32(s_smmul(C_first_row[n - k - 1], Atmp1), 32 - QA - lz));
+            num = s_addw(num, shl32(s_smmul(CAb[n - k], Atmp1), 32 - QA - lz));
+            nrg = s_addw(nrg, shl32(s_smmul(s_addw(CAb[k + 1], CAf[k + 1]), Atmp1), 32 - QA - lz));
+        }
+        CAf[n + 1] = tmp1;
+        CAb[n + 1] = tmp2;
+        num = s_addw(num, tmp2);
+        num = shl32((i32)(0u - (u32)num), 1);
+        if (s_abs(num) < nrg) rc_Q31 = s_div32_varq(num, nrg, 31);
+        else rc_Q31 = (num > 0) ? 0x7FFFFFFF : (i32)0x80000000;
+        tmp1 = s_subw((i32)1 << 30, s_smmul(rc_Q31, rc_Q31));
+        tmp1 = shl32(s_smmul(invGain_Q30, tmp1), 2);
+        if (tmp1 <= minInvGain_Q30) {
+            tmp2 = s_subw((i32)1 << 30, s_div32_varq(minInvGain_Q30, invGain_Q30, 30));
+            rc_Q31 = s_sqrt_approx(tmp2);
+            rc_Q31 = s_addw(rc_Q31, tmp2 / rc_Q31) >> 1;
+            rc_Q31 = shl32(rc_Q31, 16);
+            if (num < 0) rc_Q31 = (i32)(0u - (u32)rc_Q31);
+            invGain_Q30 = minInvGain_Q30;
+            reached_max_gain = 1;
+        } else {
+            invGain_Q30 = tmp1;
+        }
+        for (k = 0; k < (n + 1) >> 1; k++) {
+            tmp1 = Af_QA[k];
+            tmp2 = Af_QA[n - k - 1];
+            Af_QA[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
+            Af_QA[n - k - 1] = s_addw(tmp2, shl32(s_smmul(tmp1, rc_Q31), 1));
+        }
+        Af_QA[n] = rc_Q31 >> (31 - QA);
+        if (reached_max_gain) {
+            for (k = n + 1; k < D; k++) Af_QA[k] = 0;
+            break;
+        }
+        for (k = 0; k <= n + 1; k++) {
+            tmp1 = CAf[k];
+            tmp2 = CAb[n - k + 1];
+            CAf[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
+            CAb[n - k + 1] = s_addw(tmp2, shl32(s_smmul(tmp1, rc_Q31), 1));
+        }
+    }
+    opusgpu_burg_out &out = outs[r];
+    if (reached_max_gain) {
+        for (k = 0; k < D; k++) out.A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
+        if (rshifts > 0) {
+            for (s = 0; s < nb_subfr; s++) {
+                const i16 *xp = x + s * subfr_length;
+                i64 acc = 0;
+                for (k = 0; k < D; k++) acc += __mul24(xp[k], xp[k]);
+                C0 = s_subw(C0, (i32)(acc >> rshifts));
+            }
+        } else {
+            for (s = 0; s < nb_subfr; s++) {
+                const i16 *xp = x + s * subfr_length;
+                i32 acc = 0;
+                for (k = 0; k < D; k++) acc = s_addw(acc, __mul24(xp[k], xp[k]));
+                C0 = s_subw(C0, shl32(acc, -rshifts));
+            }
+        }
+        out.res_nrg = shl32(s_smmul(invGain_Q30, C0), 2);
+        out.res_nrg_Q = -rshifts;
+    } else {
+        nrg = CAf[0];
+        tmp1 = (i32)1 << 16;
+        for (k = 0; k < D; k++) {
+            Atmp1 = s_rshift_round(Af_QA[k], QA - 16);
+            nrg = s_smlaww(nrg, CAf[k + 1], Atmp1);
+            tmp1 = s_smlaww(tmp1, Atmp1, Atmp1);
+            out.A_Q16[k] = (i32)(0u - (u32)Atmp1);
+        }
+        out.res_nrg = s_smlaww(nrg, s_smmul(COND_FAC_Q32, C0), (i32)(0u - (u32)tmp1));
+        out.res_nrg_Q = -rshifts;
+    }
+    for (k = D; k < 16; k++) out.A_Q16[k] = 0;
+}
+
+// ---- silk_NSQ: one lane per record ---------------------------------------------------------------------
+// ws: per-record scratch in HBM for the two re-whitening buffers: int32 sLTP_Q15[640] then int16 sLTP[640].
+struct NsqScratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
+
+__global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__restrict__ recs, opusgpu_nsq_state *__restrict__ states,
+                                                      opusgpu_nsq_out *__restrict__ outs, NsqScratch *__restrict__ ws, int n_rec)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_nsq_in &in = recs[r];
+    opusgpu_nsq_state &NSQ = states[r];
+    i32 *sLTP_Q15 = ws[r].sLTP_Q15;
+    i16 *sLTP = ws[r].sLTP;
+    const int nb_subfr = in.nb_subfr, subfr_length = in.subfr_length, frame_length = in.frame_length;
+    const int ltp_mem_length = in.ltp_mem_length, predictLPCOrder = in.predictLPCOrder, shapingLPCOrder = in.shapingLPCOrder;
+    const int signalType = in.signalType;
+    const int voiced = signalType == 2;
+    i8 *pulses = outs[r].pulses;
+    i32 rand_seed = in.Seed;
+    int lag = NSQ.lagPrev;
+    const int offset_Q10 = voiced ? (in.quantOffsetType ? 100 : 32) : (in.quantOffsetType ? 240 : 100);   // silk/tables_other.c:95-97
+    const int LSF_interpolation_flag = in.NLSFInterpCoef_Q2 == 4 ? 0 : 1;
+    int sLTP_shp_buf_idx = ltp_mem_length, sLTP_buf_idx = ltp_mem_length;
+    i32 prev_gain_Q16 = NSQ.prev_gain_Q16;
+    i32 sLF_AR_shp_Q14 = NSQ.sLF_AR_shp_Q14;
+    int rewhite_flag = 0;
+    // short filter states in registers: sAR2_Q14[16] and the last 16 sLPC_Q14 samples (lp[0] = newest)
+    i32 ar[16], lp[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { ar[j] = NSQ.sAR2_Q14[j]; lp[j] = NSQ.sLPC_Q14[31 - j]; }
+    i32 lpc_old[16];                  // sLPC_Q14[0..16): the older half of the 32-sample history (state output only)
+#pragma unroll
+    for (int j = 0; j < 16; j++) lpc_old[j] = NSQ.sLPC_Q14[j];
+
+    for (int k = 0; k < nb_subfr; k++) {
+        const i16 *A_Q12 = &in.PredCoef_Q12[((k >> 1) | (1 - LSF_interpolation_flag)) * 16];
+        const i16 *B_Q14 = &in.LTPCoef_Q14[k * 5];
+        const i16 *AR_shp_Q13 = &in.AR2_Q13[k * 16];
+        i32 HarmShapeFIRPacked_Q14 = in.HarmShapeGain_Q14[k] >> 2;
+        HarmShapeFIRPacked_Q14 |= shl32(in.HarmShapeGain_Q14[k] >> 1, 16);
+        rewhite_flag = 0;
+        if (voiced) {
+            lag = in.pitchL[k];
+            if ((k & (3 - (LSF_interpolation_flag << 1))) == 0) {
+                const int start_idx = ltp_mem_length - lag - predictLPCOrder - 5 / 2;
+                // silk_LPC_analysis_filter (celt_fir form): out = SAT16(in + PSHR32(-sum B[m] in[ix-1-m], 12))
+                const i16 *inp = &NSQ.xq[start_idx + k * subfr_length];
+                i16 *outp = &sLTP[start_idx];
+                const int len = ltp_mem_length - start_idx;
+                for (int ix = predictLPCOrder; ix < len; ix++) {
+                    i32 sum = 0;
+                    for (int m = 0; m < predictLPCOrder; m++) sum = s_addw(sum, __mul24((i32)(i16)(-A_Q12[m]), (i32)inp[ix - 1 - m]));
+                    i32 v = (i32)inp[ix] + pshr32(sum, 12);
+                    outp[ix] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+                }
+                for (int j = 0; j < predictLPCOrder; j++) outp[j] = 0;
+                rewhite_flag = 1;
+                sLTP_buf_idx = ltp_mem_length;
+            }
+        }
+        // ---- silk_nsq_scale_states (NSQ.c:423-496) ----
+        const i32 gain = in.Gains_Q16[k];
+        i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
+        const i32 gain_adj_Q16 = gain != prev_gain_Q16 ? s_div32_varq(prev_gain_Q16, gain, 16) : (i32)1 << 16;
+        const i32 inv_gain_Q23 = s_rshift_round(inv_gain_Q31, 8);
+        prev_gain_Q16 = gain;
+        {
+            const int lg = in.pitchL[k];
+            if (rewhite_flag) {
+                if (k == 0) inv_gain_Q31 = shl32(s_smulwb(inv_gain_Q31, in.LTP_scale_Q14), 2);
+                for (int i = sLTP_buf_idx - lg - 5 / 2; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
+            }
+            if (gain_adj_Q16 != (i32)1 << 16) {
+                for (int i = sLTP_shp_buf_idx - ltp_mem_length; i < sLTP_shp_buf_idx; i++)
+                    NSQ.sLTP_shp_Q14[i] = s_smulww(gain_adj_Q16, NSQ.sLTP_shp_Q14[i]);
+                if (voiced && rewhite_flag == 0)
+                    for (int i = sLTP_buf_idx - lg - 5 / 2; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulww(gain_adj_Q16, sLTP_Q15[i]);
+                sLF_AR_shp_Q14 = s_smulww(gain_adj_Q16, sLF_AR_shp_Q14);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    lp[j] = s_smulww(gain_adj_Q16, lp[j]);
+                    lpc_old[j] = s_smulww(gain_adj_Q16, lpc_old[j]);
+                    ar[j] = s_smulww(gain_adj_Q16, ar[j]);
+                }
+            }
+        }
+        // ---- silk_noise_shape_quantizer (NSQ.c:183-421) ----
+        const i32 Gain_Q10 = gain >> 6;
+        const int Tilt_Q14 = in.Tilt_Q14[k], Lambda_Q10 = in.Lambda_Q10;
+        const i32 LF_shp_Q14 = in.LF_shp_Q14[k];
+        int shp_lag = sLTP_shp_buf_idx - lag + 3 / 2;          // index of shp_lag_ptr[0]
+        int pred_lag = sLTP_buf_idx - lag + 5 / 2;             // index of pred_lag_ptr[0]
+        i32 shp_prev = NSQ.sLTP_shp_Q14[sLTP_shp_buf_idx - 1]; // sLTP_shp_Q14[idx-1], carried in a register
+        i32 a12[16], ar13[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { a12[j] = A_Q12[j]; ar13[j] = AR_shp_Q13[j]; }
+        const i32 b0 = B_Q14[0], b1 = B_Q14[1], b2 = B_Q14[2], b3 = B_Q14[3], b4 = B_Q14[4];
+        const i32 *x_Q3 = in.x_Q3 + k * subfr_length;
+        i16 *pxq = &NSQ.xq[ltp_mem_length + k * subfr_length];
+        for (int i = 0; i < subfr_length; i++) {
+            rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
+            i32 LPC_pred_Q10 = predictLPCOrder >> 1;
+#pragma unroll
+            for (int j = 0; j < 10; j++) LPC_pred_Q10 = s_smlawb(LPC_pred_Q10, lp[j], a12[j]);
+            if (predictLPCOrder == 16) {
+#pragma unroll
+                for (int j = 10; j < 16; j++) LPC_pred_Q10 = s_smlawb(LPC_pred_Q10, lp[j], a12[j]);
+            }
+            i32 LTP_pred_Q13 = 0;
+            if (voiced) {
+                LTP_pred_Q13 = 2;
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag], b0);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 1], b1);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 2], b2);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 3], b3);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 4], b4);
+                pred_lag++;
+            }
+            // noise shape feedback: the sAR2 delay line shifts by one (NSQ.c:262-279)
+            i32 tmp2 = lp[0], tmp1 = ar[0];
+            ar[0] = tmp2;
+            i32 n_AR_Q12 = shapingLPCOrder >> 1;
+            n_AR_Q12 = s_smlawb(n_AR_Q12, tmp2, ar13[0]);
+#pragma unroll
+            for (int j = 2; j < 16; j += 2) {
+                if (j < shapingLPCOrder) {
+                    tmp2 = ar[j - 1];
+                    ar[j - 1] = tmp1;
+                    n_AR_Q12 = s_smlawb(n_AR_Q12, tmp1, ar13[j - 1]);
+                    tmp1 = ar[j];
+                    ar[j] = tmp2;
+                    n_AR_Q12 = s_smlawb(n_AR_Q12, tmp2, ar13[j]);
+                }
+            }
+            {
+                // ar[shapingLPCOrder-1] = tmp1 with a uniform (batch-wide) order: 10 or 16 in practice
+                i32 last_coef = 0;
+#pragma unroll
+                for (int j = 1; j < 16; j += 2)
+                    if (j == shapingLPCOrder - 1) { ar[j] = tmp1; last_coef = ar13[j]; }
+                n_AR_Q12 = s_smlawb(n_AR_Q12, tmp1, last_coef);
+            }
+            n_AR_Q12 = shl32(n_AR_Q12, 1);
+            n_AR_Q12 = s_smlawb(n_AR_Q12, sLF_AR_shp_Q14, Tilt_Q14);
+            i32 n_LF_Q12 = s_smulwb(shp_prev, LF_shp_Q14);
+            n_LF_Q12 = s_smlawt(n_LF_Q12, sLF_AR_shp_Q14, LF_shp_Q14);
+            tmp1 = s_subw(shl32(LPC_pred_Q10, 2), n_AR_Q12);
+            tmp1 = s_subw(tmp1, n_LF_Q12);
+            if (lag > 0) {
+                i32 n_LTP_Q13 = s_smulwb(s_addw(NSQ.sLTP_shp_Q14[shp_lag], NSQ.sLTP_shp_Q14[shp_lag - 2]), HarmShapeFIRPacked_Q14);
+                n_LTP_Q13 = s_smlawt(n_LTP_Q13, NSQ.sLTP_shp_Q14[shp_lag - 1], HarmShapeFIRPacked_Q14);
+                n_LTP_Q13 = shl32(n_LTP_Q13, 1);
+                shp_lag++;
+                tmp2 = s_subw(LTP_pred_Q13, n_LTP_Q13);
+                tmp1 = s_addw(tmp2, shl32(tmp1, 1));
+                tmp1 = s_rshift_round(tmp1, 3);
+            } else {
+                tmp1 = s_rshift_round(tmp1, 2);
+            }
+            i32 r_Q10 = s_subw(s_smulww(x_Q3[i], inv_gain_Q23), tmp1);
+            if (rand_seed < 0) r_Q10 = (i32)(0u - (u32)r_Q10);
+            r_Q10 = s_limit(r_Q10, -(31 << 10), 30 << 10);
+            i32 q1_Q10 = r_Q10 - offset_Q10, q2_Q10, rd1_Q20, rd2_Q20;
+            const i32 q1_Q0 = q1_Q10 >> 10;
+            if (q1_Q0 > 0) {
+                q1_Q10 = shl32(q1_Q0, 10) - 80 + offset_Q10;
+                q2_Q10 = q1_Q10 + 1024;
+                rd1_Q20 = s_smulbb(q1_Q10, Lambda_Q10);
+                rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else if (q1_Q0 == 0) {
+                q1_Q10 = offset_Q10;
+                q2_Q10 = q1_Q10 + (1024 - 80);
+                rd1_Q20 = s_smulbb(q1_Q10, Lambda_Q10);
+                rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else if (q1_Q0 == -1) {
+                q2_Q10 = offset_Q10;
+                q1_Q10 = q2_Q10 - (1024 - 80);
+                rd1_Q20 = s_smulbb(-q1_Q10, Lambda_Q10);
+                rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else {
+                q1_Q10 = shl32(q1_Q0, 10) + 80 + offset_Q10;
+                q2_Q10 = q1_Q10 + 1024;
+                rd1_Q20 = s_smulbb(-q1_Q10, Lambda_Q10);
+                rd2_Q20 = s_smulbb(-q2_Q10, Lambda_Q10);
+            }
+            i32 rr_Q10 = r_Q10 - q1_Q10;
+            rd1_Q20 = s_addw(rd1_Q20, s_smulbb(rr_Q10, rr_Q10));
+            rr_Q10 = r_Q10 - q2_Q10;
+            rd2_Q20 = s_addw(rd2_Q20, s_smulbb(rr_Q10, rr_Q10));
+            if (rd2_Q20 < rd1_Q20) q1_Q10 = q2_Q10;
+            const i32 pulse = (i8)s_rshift_round(q1_Q10, 10);
+            pulses[k * subfr_length + i] = (i8)pulse;
+            i32 exc_Q14 = shl32(q1_Q10, 4);
+            if (rand_seed < 0) exc_Q14 = (i32)(0u - (u32)exc_Q14);
+            const i32 LPC_exc_Q14 = s_addw(exc_Q14, shl32(LTP_pred_Q13, 1));
+            const i32 xq_Q14 = s_addw(LPC_exc_Q14, shl32(LPC_pred_Q10, 4));
+            {   // silk_SAT16(silk_RSHIFT_ROUND(silk_SMULWW(xq_Q14, Gain_Q10), 8)) in 64 bits
+                i64 t = ((i64)xq_Q14 * Gain_Q10) >> 16;
+                t = ((t >> 7) + 1) >> 1;
+                pxq[i] = (i16)(t > 32767 ? 32767 : (t < -32768 ? -32768 : t));
+            }
+            // slide the LPC history (register shift) and record the sample in the state buffer
+            {
+                // the 32-sample history is [lpc_old (older 16) | lp (newer 16)]: the sample leaving lp enters lpc_old
+                i32 leaving = lp[15];
+#pragma unroll
+                for (int j = 0; j < 15; j++) lpc_old[j] = lpc_old[j + 1];
+                lpc_old[15] = leaving;
+#pragma unroll
+                for (int j = 15; j > 0; j--) lp[j] = lp[j - 1];
+                lp[0] = xq_Q14;
+            }
+            NSQ.sLPC_Q14[32 + i] = xq_Q14;
+            sLF_AR_shp_Q14 = s_subw(xq_Q14, shl32(n_AR_Q12, 2));
+            shp_prev = s_subw(sLF_AR_shp_Q14, shl32(n_LF_Q12, 2));
+            NSQ.sLTP_shp_Q14[sLTP_shp_buf_idx] = shp_prev;
+            sLTP_Q15[sLTP_buf_idx] = shl32(LPC_exc_Q14, 1);
+            sLTP_shp_buf_idx++;
+            sLTP_buf_idx++;
+            rand_seed = (i32)((u32)rand_seed + (u32)pulse);
+        }
+    }
+    // ---- state write-back ----
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        NSQ.sAR2_Q14[j] = ar[j];
+        NSQ.sLPC_Q14[j] = lpc_old[j];
+        NSQ.sLPC_Q14[31 - j] = lp[j];
+    }
+    NSQ.sLF_AR_shp_Q14 = sLF_AR_shp_Q14;
+    NSQ.lagPrev = in.pitchL[nb_subfr - 1];
+    NSQ.sLTP_buf_idx = sLTP_buf_idx;
+    NSQ.sLTP_shp_buf_idx = sLTP_shp_buf_idx;
+    NSQ.rand_seed = rand_seed;
+    NSQ.prev_gain_Q16 = prev_gain_Q16;
+    NSQ.rewhite_flag = rewhite_flag;
+    // silk_memmove of the histories (NSQ.c:176-177): ascending copy is safe (dst < src)
+    for (int i = 0; i < ltp_mem_length; i++) NSQ.xq[i] = NSQ.xq[i + frame_length];
+    for (int i = 0; i < ltp_mem_length; i++) NSQ.sLTP_shp_Q14[i] = NSQ.sLTP_shp_Q14[i + frame_length];
+}
+
+}  // namespace ca
+
+using namespace ca;
+
+extern "C" int opusgpu_silk_burg_modified_batch(const opusgpu_burg_in *d_in, opusgpu_burg_out *d_out, int n, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
+    hipLaunchKernelGGL(silk_burg_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n);
+    return opusgpu_check_launch();
+}
+
+extern "C" size_t opusgpu_silk_nsq_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * sizeof(NsqScratch); }
+
+extern "C" int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, int n,
+                                      void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_state || !d_out || !d_workspace) return OPUSGPU_BAD_ARG;
+    if (workspace_bytes < (size_t)n * sizeof(NsqScratch)) return OPUSGPU_BUFFER_TOO_SMALL;
+    hipLaunchKernelGGL(silk_nsq_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
+                       (NsqScratch *)d_workspace, n);
+    return opusgpu_check_launch();
+}

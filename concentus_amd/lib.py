@@ -24,6 +24,9 @@ SYMBOLS = [
     ("opusgpu_celt_state_init", _i, [_vp, _i, _vp]),
     ("opusgpu_encode_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
+    ("opusgpu_silk_burg_modified_batch", _i, [_vp, _vp, _i, _vp]),
+    ("opusgpu_silk_nsq_workspace_bytes", C.c_size_t, [_i]),
+    ("opusgpu_silk_nsq_batch", _i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
 

@@ -1,0 +1,78 @@
+"""Host-side mirror of the two SILK operators on the hot path (BASELINE config #4):
+silk_burg_modified() (opus-fix/silk/SigProc_FIX.h:601, fixed/burg_modified_FIX.c:45) and silk_NSQ()
+(opus-fix/silk/main.h:245-268, NSQ.c:74), over batches of function-boundary records held in device
+tensors (byte tensors with the layouts of include/opusgpu_silk.h)."""
+import ctypes as C
+
+from . import lib as _lib
+
+
+class BurgIn(C.Structure):
+    _fields_ = [("x", C.c_int16 * 384), ("minInvGain_Q30", C.c_int32), ("subfr_length", C.c_int32),
+                ("nb_subfr", C.c_int32), ("D", C.c_int32)]
+
+
+class BurgOut(C.Structure):
+    _fields_ = [("res_nrg", C.c_int32), ("res_nrg_Q", C.c_int32), ("A_Q16", C.c_int32 * 16)]
+
+
+class NsqState(C.Structure):
+    _fields_ = [("xq", C.c_int16 * 640), ("sLTP_shp_Q14", C.c_int32 * 640), ("sLPC_Q14", C.c_int32 * 112),
+                ("sAR2_Q14", C.c_int32 * 16), ("sLF_AR_shp_Q14", C.c_int32), ("lagPrev", C.c_int32),
+                ("sLTP_buf_idx", C.c_int32), ("sLTP_shp_buf_idx", C.c_int32), ("rand_seed", C.c_int32),
+                ("prev_gain_Q16", C.c_int32), ("rewhite_flag", C.c_int32)]
+
+
+class NsqIn(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("nb_subfr", "subfr_length", "frame_length", "ltp_mem_length", "predictLPCOrder",
+                                         "shapingLPCOrder", "signalType", "quantOffsetType", "NLSFInterpCoef_Q2", "Seed",
+                                         "Lambda_Q10", "LTP_scale_Q14")] + \
+               [("HarmShapeGain_Q14", C.c_int32 * 4), ("Tilt_Q14", C.c_int32 * 4), ("LF_shp_Q14", C.c_int32 * 4),
+                ("Gains_Q16", C.c_int32 * 4), ("pitchL", C.c_int32 * 4), ("x_Q3", C.c_int32 * 320),
+                ("PredCoef_Q12", C.c_int16 * 32), ("LTPCoef_Q14", C.c_int16 * 20), ("AR2_Q13", C.c_int16 * 64)]
+
+
+SIZES = {"burg_in": C.sizeof(BurgIn), "burg_out": C.sizeof(BurgOut), "nsq_in": C.sizeof(NsqIn),
+         "nsq_state": C.sizeof(NsqState), "nsq_out": 320}
+
+
+def _check(t, rec_bytes, name):
+    import torch
+    if not (t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous() and t.dim() == 2 and t.shape[1] == rec_bytes):
+        raise ValueError("%s must be a contiguous uint8 CUDA tensor [records][%d]" % (name, rec_bytes))
+
+
+def silk_burg_modified(burg_in, burg_out=None):
+    """burg_in uint8 [N][784] (opusgpu_burg_in records) -> uint8 [N][72] (opusgpu_burg_out)."""
+    import torch
+    _check(burg_in, SIZES["burg_in"], "burg_in")
+    n = burg_in.shape[0]
+    if burg_out is None:
+        burg_out = torch.empty((n, SIZES["burg_out"]), dtype=torch.uint8, device=burg_in.device)
+    _check(burg_out, SIZES["burg_out"], "burg_out")
+    rc = _lib.load().opusgpu_silk_burg_modified_batch(burg_in.data_ptr(), burg_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_burg_modified_batch")
+    return burg_out
+
+
+_WS = {}
+
+
+def silk_NSQ(nsq_in, nsq_state, pulses=None):
+    """nsq_in uint8 [N][1640], nsq_state uint8 [N][4380] (updated in place) -> pulses int8 [N][320]."""
+    import torch
+    _check(nsq_in, SIZES["nsq_in"], "nsq_in")
+    _check(nsq_state, SIZES["nsq_state"], "nsq_state")
+    n = nsq_in.shape[0]
+    if pulses is None:
+        pulses = torch.zeros((n, 320), dtype=torch.int8, device=nsq_in.device)
+    L = _lib.load()
+    need = L.opusgpu_silk_nsq_workspace_bytes(n)
+    ws = _WS.get(nsq_in.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=nsq_in.device)
+        _WS[nsq_in.device] = ws
+    rc = L.opusgpu_silk_nsq_batch(nsq_in.data_ptr(), nsq_state.data_ptr(), pulses.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                  _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_nsq_batch")
+    return pulses

@@ -1,0 +1,80 @@
+/* opusgpu_silk.h -- C-ABI records of the SILK function-level kernels (BASELINE config #4).
+ *
+ * The north star names only the two fixed-point inner loops of the SILK encoder:
+ *   silk_burg_modified_c   opus-fix/silk/fixed/burg_modified_FIX.c:45-275   (macro silk_burg_modified, silk/SigProc_FIX.h:601)
+ *   silk_NSQ_c             opus-fix/silk/NSQ.c:74-180 (+ silk_noise_shape_quantizer :183-421, silk_nsq_scale_states :423-496)
+ * Their inputs are produced by SILK analysis code that is out of scope, so the batched
+ * entry points take "function-boundary records": flat, pointer-free copies of the arguments of one call,
+ * exactly what the reference passes at silk/fixed/find_LPC_FIX.c:63,69 and silk/fixed/encode_frame_FIX.c:317.
+ */
+#ifndef OPUSGPU_SILK_H
+#define OPUSGPU_SILK_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPUSGPU_SILK_MAX_ORDER 16
+#define OPUSGPU_SILK_BURG_MAX_X 384          /* MAX_FRAME_SIZE, burg_modified_FIX.c:36 */
+#define OPUSGPU_SILK_MAX_FRAME 320           /* MAX_FRAME_LENGTH = 20 ms @ 16 kHz (silk/define.h:92) */
+
+/* one silk_burg_modified() call */
+typedef struct opusgpu_burg_in {
+    int16_t x[OPUSGPU_SILK_BURG_MAX_X];      /* nb_subfr * subfr_length samples */
+    int32_t minInvGain_Q30;
+    int32_t subfr_length;                    /* incl. D preceding samples */
+    int32_t nb_subfr;
+    int32_t D;                               /* order (<= 16) */
+} opusgpu_burg_in;
+
+typedef struct opusgpu_burg_out {
+    int32_t res_nrg;
+    int32_t res_nrg_Q;
+    int32_t A_Q16[OPUSGPU_SILK_MAX_ORDER];
+} opusgpu_burg_out;
+
+/* silk_nsq_state (opus-fix/silk/structs.h), identical layout */
+typedef struct opusgpu_nsq_state {
+    int16_t xq[2 * OPUSGPU_SILK_MAX_FRAME];
+    int32_t sLTP_shp_Q14[2 * OPUSGPU_SILK_MAX_FRAME];
+    int32_t sLPC_Q14[80 + 32];               /* MAX_SUB_FRAME_LENGTH + NSQ_LPC_BUF_LENGTH */
+    int32_t sAR2_Q14[16];
+    int32_t sLF_AR_shp_Q14;
+    int32_t lagPrev;
+    int32_t sLTP_buf_idx;
+    int32_t sLTP_shp_buf_idx;
+    int32_t rand_seed;
+    int32_t prev_gain_Q16;
+    int32_t rewhite_flag;
+} opusgpu_nsq_state;
+
+/* one silk_NSQ() call: the fields of psEncC / psIndices it reads, then its array arguments */
+typedef struct opusgpu_nsq_in {
+    int32_t nb_subfr, subfr_length, frame_length, ltp_mem_length, predictLPCOrder, shapingLPCOrder;
+    int32_t signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed;
+    int32_t Lambda_Q10, LTP_scale_Q14;
+    int32_t HarmShapeGain_Q14[4], Tilt_Q14[4], LF_shp_Q14[4], Gains_Q16[4], pitchL[4];
+    int32_t x_Q3[OPUSGPU_SILK_MAX_FRAME];
+    int16_t PredCoef_Q12[2 * 16];
+    int16_t LTPCoef_Q14[5 * 4];
+    int16_t AR2_Q13[4 * 16];
+} opusgpu_nsq_in;
+
+typedef struct opusgpu_nsq_out {
+    int8_t pulses[OPUSGPU_SILK_MAX_FRAME];
+} opusgpu_nsq_out;
+
+/* Batched entry points (device pointers, asynchronous on hip_stream). One record per call of the
+ * reference function; NSQ states are updated in place, as the reference updates *NSQ.
+ * d_workspace: device scratch of opusgpu_silk_nsq_workspace_bytes(n) bytes (the re-whitening buffers
+ * sLTP / sLTP_Q15 that the reference allocates on its stack, silk/NSQ.c:117-120). */
+int opusgpu_silk_burg_modified_batch(const opusgpu_burg_in *d_in, opusgpu_burg_out *d_out, int n, void *hip_stream);
+size_t opusgpu_silk_nsq_workspace_bytes(int n);
+int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, int n,
+                           void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

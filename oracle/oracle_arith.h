@@ -13,6 +13,7 @@ typedef int16_t i16;
 typedef int32_t i32;
 typedef uint32_t u32;
 typedef int64_t i64;
+typedef int8_t i8;
 
 /* fixed_generic.h:46  MULT16_32_Q15(a,b): 16x32 -> >>15, evaluated on the split halves of b.
  * The split form equals ((int64)a*b)>>15 truncated to 32 bits; it is written the reference's way so

@@ -1,0 +1,95 @@
+/* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c into a capture variant of the compiled
+ * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
+ * path is forwarded to the real reference code and its arguments / results are recorded as the flat
+ * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
+ * technique). Compiled against the reference's own headers where they lie; nothing is copied. */
+#include <stdlib.h>
+#include <string.h>
+#include "main.h"                      /* opus-fix/silk/main.h (via -I) */
+#include "../include/opusgpu_silk.h"
+
+typedef char nsq_state_layout_check[sizeof(silk_nsq_state) == sizeof(opusgpu_nsq_state) ? 1 : -1];
+
+static opusgpu_burg_in *g_bin; static opusgpu_burg_out *g_bout; static int g_nb, g_capb;
+static opusgpu_nsq_in *g_nin; static opusgpu_nsq_state *g_nst_in, *g_nst_out; static opusgpu_nsq_out *g_nout;
+static int g_nn, g_capn, g_on;
+
+void refcap_start(int max_records)
+{
+    g_capb = g_capn = max_records; g_nb = g_nn = 0; g_on = 1;
+    g_bin = (opusgpu_burg_in *)calloc(max_records, sizeof(*g_bin));
+    g_bout = (opusgpu_burg_out *)calloc(max_records, sizeof(*g_bout));
+    g_nin = (opusgpu_nsq_in *)calloc(max_records, sizeof(*g_nin));
+    g_nst_in = (opusgpu_nsq_state *)calloc(max_records, sizeof(*g_nst_in));
+    g_nst_out = (opusgpu_nsq_state *)calloc(max_records, sizeof(*g_nst_out));
+    g_nout = (opusgpu_nsq_out *)calloc(max_records, sizeof(*g_nout));
+}
+int refcap_count_burg(void) { return g_nb; }
+int refcap_count_nsq(void) { return g_nn; }
+void refcap_get(void *bin, void *bout, void *nin, void *nst_in, void *nst_out, void *nout)
+{
+    memcpy(bin, g_bin, (size_t)g_nb * sizeof(*g_bin)); memcpy(bout, g_bout, (size_t)g_nb * sizeof(*g_bout));
+    memcpy(nin, g_nin, (size_t)g_nn * sizeof(*g_nin)); memcpy(nst_in, g_nst_in, (size_t)g_nn * sizeof(*g_nst_in));
+    memcpy(nst_out, g_nst_out, (size_t)g_nn * sizeof(*g_nst_out)); memcpy(nout, g_nout, (size_t)g_nn * sizeof(*g_nout));
+}
+int refcap_sizes(int which)
+{
+    switch (which) { case 0: return sizeof(opusgpu_burg_in); case 1: return sizeof(opusgpu_burg_out);
+    case 2: return sizeof(opusgpu_nsq_in); case 3: return sizeof(opusgpu_nsq_state); default: return sizeof(opusgpu_nsq_out); }
+}
+
+void __real_silk_burg_modified_c(opus_int32 *res_nrg, opus_int *res_nrg_Q, opus_int32 A_Q16[], const opus_int16 x[],
+                                 const opus_int32 minInvGain_Q30, const opus_int subfr_length, const opus_int nb_subfr,
+                                 const opus_int D, int arch);
+void __wrap_silk_burg_modified_c(opus_int32 *res_nrg, opus_int *res_nrg_Q, opus_int32 A_Q16[], const opus_int16 x[],
+                                 const opus_int32 minInvGain_Q30, const opus_int subfr_length, const opus_int nb_subfr,
+                                 const opus_int D, int arch)
+{
+    __real_silk_burg_modified_c(res_nrg, res_nrg_Q, A_Q16, x, minInvGain_Q30, subfr_length, nb_subfr, D, arch);
+    if (g_on && g_nb < g_capb && subfr_length * nb_subfr <= OPUSGPU_SILK_BURG_MAX_X) {
+        opusgpu_burg_in *r = &g_bin[g_nb];
+        memcpy(r->x, x, sizeof(opus_int16) * subfr_length * nb_subfr);
+        r->minInvGain_Q30 = minInvGain_Q30; r->subfr_length = subfr_length; r->nb_subfr = nb_subfr; r->D = D;
+        g_bout[g_nb].res_nrg = *res_nrg; g_bout[g_nb].res_nrg_Q = *res_nrg_Q;
+        memcpy(g_bout[g_nb].A_Q16, A_Q16, sizeof(opus_int32) * D);
+        g_nb++;
+    }
+}
+
+void __real_silk_NSQ_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, SideInfoIndices *psIndices, const opus_int32 x_Q3[],
+                       opus_int8 pulses[], const opus_int16 PredCoef_Q12[], const opus_int16 LTPCoef_Q14[], const opus_int16 AR2_Q13[],
+                       const opus_int HarmShapeGain_Q14[], const opus_int Tilt_Q14[], const opus_int32 LF_shp_Q14[],
+                       const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14);
+void __wrap_silk_NSQ_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, SideInfoIndices *psIndices, const opus_int32 x_Q3[],
+                       opus_int8 pulses[], const opus_int16 PredCoef_Q12[], const opus_int16 LTPCoef_Q14[], const opus_int16 AR2_Q13[],
+                       const opus_int HarmShapeGain_Q14[], const opus_int Tilt_Q14[], const opus_int32 LF_shp_Q14[],
+                       const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14)
+{
+    int rec = (g_on && g_nn < g_capn && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nn : -1;
+    if (rec >= 0) {
+        opusgpu_nsq_in *r = &g_nin[rec];
+        r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
+        r->ltp_mem_length = psEncC->ltp_mem_length; r->predictLPCOrder = psEncC->predictLPCOrder;
+        r->shapingLPCOrder = psEncC->shapingLPCOrder;
+        r->signalType = psIndices->signalType; r->quantOffsetType = psIndices->quantOffsetType;
+        r->NLSFInterpCoef_Q2 = psIndices->NLSFInterpCoef_Q2; r->Seed = psIndices->Seed;
+        r->Lambda_Q10 = Lambda_Q10; r->LTP_scale_Q14 = LTP_scale_Q14;
+        for (int k = 0; k < 4; k++) {
+            r->HarmShapeGain_Q14[k] = HarmShapeGain_Q14[k]; r->Tilt_Q14[k] = Tilt_Q14[k]; r->LF_shp_Q14[k] = LF_shp_Q14[k];
+            r->Gains_Q16[k] = Gains_Q16[k]; r->pitchL[k] = pitchL[k];
+        }
+        memcpy(r->x_Q3, x_Q3, sizeof(opus_int32) * psEncC->frame_length);
+        memcpy(r->PredCoef_Q12, PredCoef_Q12, sizeof(r->PredCoef_Q12));
+        memcpy(r->LTPCoef_Q14, LTPCoef_Q14, sizeof(r->LTPCoef_Q14));
+        memcpy(r->AR2_Q13, AR2_Q13, sizeof(r->AR2_Q13));
+        memcpy(&g_nst_in[rec], NSQ, sizeof(*NSQ));
+    }
+    __real_silk_NSQ_c(psEncC, NSQ, psIndices, x_Q3, pulses, PredCoef_Q12, LTPCoef_Q14, AR2_Q13, HarmShapeGain_Q14, Tilt_Q14,
+                      LF_shp_Q14, Gains_Q16, pitchL, Lambda_Q10, LTP_scale_Q14);
+    if (rec >= 0) {
+        memcpy(&g_nst_out[rec], NSQ, sizeof(*NSQ));
+        memcpy(g_nout[rec].pulses, pulses, psEncC->frame_length);
+        g_nn++;
+    }
+}

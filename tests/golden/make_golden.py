@@ -135,3 +135,75 @@ def encode_vectors():
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "encode_golden.npz"), **encode_vectors())
     print("wrote encode_golden.npz")
+
+
+# ---- SILK function-boundary records (BASELINE config #4) ---------------------------------------------
+def synth_voice(nsamples, seed, fs=16000):
+    """Synthetic voiced/unvoiced speech-like mono int16 signal: glottal pulse train with slowly varying pitch
+    through three formant resonators, alternating with noise bursts and short pauses."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(nsamples)
+    f0 = 110 + 40 * np.sin(2 * np.pi * t / (fs * 1.7)) + 15 * np.sin(2 * np.pi * t / (fs * 0.31))
+    phase = np.cumsum(f0 / fs)
+    pulses = (np.diff(np.floor(phase), prepend=0) > 0).astype(np.float64)
+    voiced_env = (np.sin(2 * np.pi * t / (fs * 0.9)) > -0.3).astype(np.float64)
+    exc = pulses * voiced_env * 8000 + rng.normal(0, 300, nsamples) * (1 - voiced_env) * 3 + rng.normal(0, 20, nsamples)
+    y = exc
+    for fc, bw in ((700, 130), (1220, 70), (2600, 160)):
+        r = np.exp(-np.pi * bw / fs)
+        a1, a2 = -2 * r * np.cos(2 * np.pi * fc / fs), r * r
+        out = np.zeros(nsamples)
+        for n in range(nsamples):
+            out[n] = y[n] - a1 * (out[n - 1] if n > 0 else 0) - a2 * (out[n - 2] if n > 1 else 0)
+        y = out * (1 - r)
+    pause = ((t // (fs // 2)) % 7 == 6)
+    y = np.where(pause, 0, y)
+    y = y / (np.abs(y).max() + 1e-9) * 20000
+    return y.astype(np.int16)
+
+
+def silk_capture(pcm16k, max_records=200000, complexity=3, bitrate=32000):
+    """Run the reference SILK encoder (opus_encode, OPUS_APPLICATION_VOIP, 16 kHz mono, 20 ms) over pcm16k with the
+    capture variant of the library and return the recorded silk_burg_modified / silk_NSQ calls as raw byte arrays."""
+    lib = C.CDLL(os.path.join(os.path.dirname(HERE), "..", "oracle", "_ref", "libopus_ref_silkcap.so"))
+    lib.opus_encoder_create.restype = C.c_void_p
+    lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.refcap_start(max_records)
+    err = C.c_int()
+    enc = C.c_void_p(lib.opus_encoder_create(16000, 1, 2048, C.byref(err)))
+    for req, v in ((4002, bitrate), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
+        lib.opus_encoder_ctl(enc, req, v)
+    out = (C.c_ubyte * 1500)()
+    nfr = len(pcm16k) // 320
+    for f in range(nfr):
+        fr = np.ascontiguousarray(pcm16k[f * 320:(f + 1) * 320])
+        r = lib.opus_encode(enc, fr.ctypes.data_as(C.c_void_p), 320, out, 1500)
+        assert r > 0
+    nb, nn = lib.refcap_count_burg(), lib.refcap_count_nsq()
+    sz = [lib.refcap_sizes(i) for i in range(5)]
+    bufs = [np.zeros((nb, sz[0]), np.uint8), np.zeros((nb, sz[1]), np.uint8), np.zeros((nn, sz[2]), np.uint8),
+            np.zeros((nn, sz[3]), np.uint8), np.zeros((nn, sz[3]), np.uint8), np.zeros((nn, sz[4]), np.uint8)]
+    lib.refcap_get(*[_p(b) for b in bufs])
+    return dict(burg_in=bufs[0], burg_out=bufs[1], nsq_in=bufs[2], nsq_state_in=bufs[3], nsq_state_out=bufs[4], nsq_out=bufs[5])
+
+
+def silk_vectors():
+    parts = []
+    parts.append(silk_capture(synth_voice(16000 * 6, 41)))
+    raw = "/root/reference/Java/ConcentusTestConsole/src/main/resources/AudioData/16Khz Mono.raw"
+    if os.path.exists(raw):   # real speech shipped with the reference's Java test console (first 6 s)
+        parts.append(silk_capture(np.fromfile(raw, dtype="<i2")[:16000 * 6]))
+    out = {}
+    for k in parts[0]:
+        sel = []
+        for p in parts:
+            n = p[k].shape[0]
+            idx = np.linspace(0, n - 1, 40).astype(int)          # 40 records per source, spread over the signal
+            sel.append(p[k][idx])
+        out["silk_" + k] = np.concatenate(sel)
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "silk_golden.npz"), **silk_vectors())
+    print("wrote silk_golden.npz")

@@ -10,9 +10,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, "include", "opusgpu.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(opusgpu_\w+)\s*\(", src)))
+    names = set()
+    for h in ("opusgpu.h", "opusgpu_silk.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(opusgpu_\w+)\s*\(", src))
+    return sorted(names)
 
 
 def _ensure_built():

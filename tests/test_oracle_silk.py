@@ -1,0 +1,46 @@
+"""Pin the CPU restatement of silk_burg_modified / silk_NSQ (oracle/oracle_silk.c) bit-exact against
+function-boundary records captured from the compiled reference (tests/golden/silk_golden.npz: 40 records of
+synthetic voice + 40 of the real speech file shipped with the reference's Java test console), and -- where
+the capture library is present -- against a fresh, larger capture."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "silk_golden.npz")
+
+
+def _check(rec):
+    orc = oraclelib.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    bi = np.ascontiguousarray(rec["burg_in"])
+    bo = np.zeros_like(rec["burg_out"])
+    orc.orc_silk_burg_batch(p(bi), p(bo), bi.shape[0])
+    assert np.array_equal(bo, rec["burg_out"]), np.nonzero((bo != rec["burg_out"]).any(1))[0][:8]
+    ni = np.ascontiguousarray(rec["nsq_in"])
+    st = np.ascontiguousarray(rec["nsq_state_in"]).copy()
+    no = np.zeros_like(rec["nsq_out"])
+    orc.orc_silk_nsq_batch(p(ni), p(st), p(no), ni.shape[0])
+    bad = np.nonzero((no != rec["nsq_out"]).any(1))[0]
+    assert bad.size == 0, ("pulses differ in records", bad[:8])
+    bad = np.nonzero((st != rec["nsq_state_out"]).any(1))[0]
+    assert bad.size == 0, ("NSQ state differs in records", bad[:8])
+
+
+def test_oracle_silk_matches_golden_records():
+    g = np.load(GOLD)
+    _check({k[5:]: g[k] for k in g.files})
+
+
+@pytest.mark.ref
+def test_oracle_silk_matches_fresh_capture():
+    import encode_cases as ec
+    gm = ec.golden_module()
+    if not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "..", "oracle", "_ref", "libopus_ref_silkcap.so")):
+        pytest.skip("capture library not built")
+    rec = gm.silk_capture(gm.synth_voice(16000 * 3, 99))
+    assert rec["nsq_in"].shape[0] >= 100
+    _check(rec)

@@ -1,0 +1,95 @@
+"""GPU parity tests for the SILK function-level kernels (config #4), through the C-ABI: bit-exact against
+records captured from the compiled reference (golden), against the CPU oracle on tiled/perturbed records
+at the full 65 536-record size, and against a fresh capture when the capture library travelled."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oraclelib
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "silk_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import torch
+    assert torch.cuda.is_available()
+    import concentus_amd
+    concentus_amd.lib.load()
+    return concentus_amd
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _run_gpu(ca, rec):
+    import torch
+    bo = ca.silk_burg_modified(_dev(rec["burg_in"]))
+    st = _dev(rec["nsq_state_in"])
+    pulses = ca.silk_NSQ(_dev(rec["nsq_in"]), st)
+    torch.cuda.synchronize()
+    return bo.cpu().numpy(), pulses.cpu().numpy().view(np.uint8), st.cpu().numpy()
+
+
+def test_silk_kernels_match_golden_records(ca):
+    g = np.load(GOLD)
+    rec = {k[5:]: g[k] for k in g.files}
+    bo, pulses, st = _run_gpu(ca, rec)
+    assert np.array_equal(bo, rec["burg_out"]), np.nonzero((bo != rec["burg_out"]).any(1))[0][:8]
+    assert np.array_equal(pulses, rec["nsq_out"]), np.nonzero((pulses != rec["nsq_out"]).any(1))[0][:8]
+    bad = np.nonzero((st != rec["nsq_state_out"]).any(1))[0]
+    assert bad.size == 0, ("NSQ state differs", bad[:8], [np.nonzero(st[b] != rec["nsq_state_out"][b])[0][:6] for b in bad[:3]])
+
+
+def test_silk_kernels_full_size_vs_oracle(ca):
+    """65 536 records (config #4): the 80 captured records tiled, with the NSQ dither seed and the Burg
+    input perturbed per record so that records differ; checked against the CPU oracle on a 2 048-record sample
+    and for batch-position independence."""
+    g = np.load(GOLD)
+    rec = {k[5:]: g[k] for k in g.files}
+    n = 65536
+    rng = np.random.default_rng(4)
+    reps = n // 80 + 1
+    bi = np.tile(rec["burg_in"], (reps, 1))[:n].copy()
+    x = bi[:, :768].view(np.int16)
+    x += rng.integers(-3, 4, size=x.shape, dtype=np.int16)
+    ni = np.tile(rec["nsq_in"], (reps, 1))[:n].copy()
+    ni[:, 36:40].view(np.int32)[:, 0] = rng.integers(0, 4, size=n)          # Seed (2 bits in SILK)
+    st0 = np.tile(rec["nsq_state_in"], (reps, 1))[:n].copy()
+    bo, pulses, st = _run_gpu(ca, dict(burg_in=bi, nsq_in=ni, nsq_state_in=st0))
+    idx = rng.choice(n, 2048, replace=False)
+    orc = oraclelib.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    sbi = np.ascontiguousarray(bi[idx]); sbo = np.zeros((2048, 72), np.uint8)
+    orc.orc_silk_burg_batch(p(sbi), p(sbo), 2048)
+    assert np.array_equal(bo[idx], sbo)
+    sni = np.ascontiguousarray(ni[idx]); sst = np.ascontiguousarray(st0[idx]).copy(); sno = np.zeros((2048, 320), np.uint8)
+    orc.orc_silk_nsq_batch(p(sni), p(sst), p(sno), 2048)
+    assert np.array_equal(pulses[idx], sno)
+    assert np.array_equal(st[idx], sst)
+
+
+def test_silk_kernels_match_fresh_capture_if_present(ca):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libopus_ref_silkcap.so")):
+        pytest.skip("capture library did not travel")
+    import encode_cases as ec
+    gm = ec.golden_module()
+    rec = gm.silk_capture(gm.synth_voice(16000 * 4, 77))
+    bo, pulses, st = _run_gpu(ca, rec)
+    assert np.array_equal(bo, rec["burg_out"])
+    assert np.array_equal(pulses, rec["nsq_out"])
+    assert np.array_equal(st, rec["nsq_state_out"])
+
+
+def test_silk_empty_and_bad_args(ca):
+    import torch
+    out = ca.silk_burg_modified(torch.zeros((0, 784), dtype=torch.uint8, device="cuda"))
+    assert out.shape == (0, 72)
+    with pytest.raises(ValueError):
+        ca.silk_burg_modified(torch.zeros((4, 100), dtype=torch.uint8, device="cuda"))
