@@ -10,6 +10,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
                   PVQ quant_all_bands, range coder) at 96 kb/s VBR complexity 10 -- the configuration the
                   metric "frames encoded/sec" is quoted on. Algorithmic bytes: 3 840 B PCM in + packet
                   (~255 B) + 8 B (len, rng) per frame (~4 090 B/frame).
+  silk            BASELINE.json configs[3]: 65 536 function-boundary records, silk_burg_modified + silk_NSQ
+                  (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   mdct            BASELINE.json configs[1]: 4 096 frames, clt_mdct_forward + clt_mdct_backward only
                   (33 600 algorithmic bytes per stereo frame) -- the HBM-bound slice.
 
@@ -45,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="celt", choices=["celt", "mdct"])
+    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk"])
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL packet gather (N > 1)")
@@ -141,6 +143,38 @@ def cpu_baseline_celt(pcm_sample, cfgvals):
                       "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
 
 
+def cpu_baseline_silk(rec, n):
+    """CPU baseline for the SILK records: our C restatement (oracle/oracle_silk.c, kind "port"; the reference's
+    silk_NSQ_c needs its whole encoder state struct, so it is not driven directly), chunks on a thread pool."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    from concurrent.futures import ThreadPoolExecutor
+    orc = oraclelib.lib()
+    cores = host_threads()
+    bi = np.ascontiguousarray(np.tile(rec["burg_in"], (n // 80 + 1, 1))[:n])
+    ni = np.ascontiguousarray(np.tile(rec["nsq_in"], (n // 80 + 1, 1))[:n])
+    st0 = np.ascontiguousarray(np.tile(rec["nsq_state_in"], (n // 80 + 1, 1))[:n])
+    bo = np.zeros((n, 72), np.uint8)
+    no = np.zeros((n, 320), np.uint8)
+
+    def work(lo, hi):
+        st = st0[lo:hi].copy()
+        orc.orc_silk_burg_batch(C.c_void_p(bi.ctypes.data + lo * 784), C.c_void_p(bo.ctypes.data + lo * 72), hi - lo)
+        orc.orc_silk_nsq_batch(C.c_void_p(ni.ctypes.data + lo * 1640), _p(st), C.c_void_p(no.ctypes.data + lo * 320), hi - lo)
+
+    def run(threads):
+        if threads == 1:
+            work(0, n)
+            return
+        per = (n + threads - 1) // threads
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port",
+            "sample": "%d records (silk_burg_modified + silk_NSQ each) per pass through oracle/oracle_silk.c, repeated ~8 s on "
+                      "%d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
+
+
 def main():
     a = parse()
     import torch
@@ -206,6 +240,48 @@ def main():
         dtype = "int32"
         extra = {"other_kernel_ms": round(bwd_ms if kname.startswith("mdct_forward") else fwd_ms, 5)}
         cpu = (lambda: cpu_baseline_mdct(host[:256]))
+    elif a.workload == "silk":
+        F = a.frames or 65536
+        steps = a.steps or 20
+        warm = a.warmup if a.warmup is not None else 3
+        g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz"))
+        rec = {k[5:]: g[k] for k in g.files}
+        reps = F // 80 + 1
+        rng = np.random.default_rng(4 + rank)
+        bi_h = np.tile(rec["burg_in"], (reps, 1))[:F].copy()
+        bi_h[:, :768].view(np.int16)[...] += rng.integers(-3, 4, size=(F, 384), dtype=np.int16)
+        ni_h = np.tile(rec["nsq_in"], (reps, 1))[:F].copy()
+        st_h = np.tile(rec["nsq_state_in"], (reps, 1))[:F].copy()
+        bi, ni, st0 = (torch.from_numpy(x).to(dev) for x in (bi_h, ni_h, st_h))
+        st = st0.clone()
+        bo = torch.empty((F, 72), dtype=torch.uint8, device=dev)
+        pulses = torch.empty((F, 320), dtype=torch.int8, device=dev)
+        for _ in range(warm):
+            st.copy_(st0)
+            ca.silk_burg_modified(bi, bo)
+            ca.silk_NSQ(ni, st, pulses)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.silk_burg_modified(bi, bo)
+            ev[k][1].record()
+            ca.silk_NSQ(ni, st, pulses)        # states keep evolving from step to step, as a stream would
+            ev[k][2].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        burg_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        kname = "silk_nsq_kernel"
+        kbytes = F * (1640 + 2 * 4380 + 320)
+        metric = "SILK 16kHz mono 20ms frames/sec (silk_burg_modified + silk_NSQ records, config #4)"
+        workload = ("configs[3]: %d function-boundary records per GPU (80 captured from the reference encoder on "
+                    "16 kHz mono voice at 32 kb/s complexity 3, tiled), silk_burg_modified + silk_NSQ, bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {"burg_kernel_ms": round(burg_ms, 5), "burg_GBps": round(F * 856 / (burg_ms * 1e-3) / 1e9, 2)}
+        cpu = (lambda: cpu_baseline_silk(rec, 8192))
     else:
         F = a.frames or 65536
         steps = a.steps or 10
@@ -260,7 +336,7 @@ def main():
         out_line = {
             "metric": metric,
             "value": round(value, 1),
-            "unit": "frames/s",
+            "unit": "records/s" if a.workload == "silk" else "frames/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": warm,
