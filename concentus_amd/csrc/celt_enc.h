@@ -523,7 +523,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
         int dynalloc_loop_logp = dynalloc_logp;
         int boost = 0, j;
-        const int off_i = F.offsets[i], cap_i = F.cap[i];
+        const int off_i = uni(F.offsets[i]), cap_i = uni(F.cap[i]);
         for (j = 0; tell + (dynalloc_loop_logp << BITRES) < total_bits - total_boost && boost < cap_i; j++) {
             int flag = j < off_i;
             ec_enc_bit_logp(enc, flag, (u32)dynalloc_loop_logp);

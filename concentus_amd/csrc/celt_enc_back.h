@@ -89,9 +89,9 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
         for (int j = end; j-- > start;) {
             int N = eB[j + 1] - eB[j];
             int bitsj = (C * N * CLT_band_allocation[mid * len + j]) << LM >> 2;
-            if (bitsj > 0) bitsj = imax(0, bitsj + F.trim_offset[j]);
-            bitsj += F.offsets[j];
-            if (bitsj >= F.thresh[j] || done) { done = 1; psum += imin(bitsj, F.cap[j]); }
+            if (bitsj > 0) bitsj = imax(0, bitsj + uni(F.trim_offset[j]));
+            bitsj += uni(F.offsets[j]);
+            if (bitsj >= uni(F.thresh[j]) || done) { done = 1; psum += imin(bitsj, uni(F.cap[j])); }
             else if (bitsj >= C << BITRES) psum += C << BITRES;
         }
         if (psum > total) hi = mid - 1; else lo = mid + 1;
@@ -100,12 +100,12 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
     for (int j = start; j < end; j++) {
         int N = eB[j + 1] - eB[j];
         int bits1j = (C * N * CLT_band_allocation[lo * len + j]) << LM >> 2;
-        int bits2j = hi >= 11 ? F.cap[j] : (C * N * CLT_band_allocation[hi * len + j]) << LM >> 2;
-        if (bits1j > 0) bits1j = imax(0, bits1j + F.trim_offset[j]);
-        if (bits2j > 0) bits2j = imax(0, bits2j + F.trim_offset[j]);
-        if (lo > 0) bits1j += F.offsets[j];
-        bits2j += F.offsets[j];
-        if (F.offsets[j] > 0) skip_start = j;
+        int bits2j = hi >= 11 ? uni(F.cap[j]) : (C * N * CLT_band_allocation[hi * len + j]) << LM >> 2;
+        if (bits1j > 0) bits1j = imax(0, bits1j + uni(F.trim_offset[j]));
+        if (bits2j > 0) bits2j = imax(0, bits2j + uni(F.trim_offset[j]));
+        if (lo > 0) bits1j += uni(F.offsets[j]);
+        bits2j += uni(F.offsets[j]);
+        if (uni(F.offsets[j]) > 0) skip_start = j;
         bits2j = imax(0, bits2j - bits1j);
         st0(&F.bits1[j], bits1j);
         st0(&F.bits2[j], bits2j);
@@ -120,8 +120,8 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
         int mid = (lo + hi) >> 1, done = 0;
         psum = 0;
         for (int j = end; j-- > start;) {
-            int tmp = F.bits1[j] + ((mid * (i32)F.bits2[j]) >> ALLOC_STEPS);
-            if (tmp >= F.thresh[j] || done) { done = 1; psum += imin(tmp, F.cap[j]); }
+            int tmp = uni(F.bits1[j]) + ((mid * (i32)uni(F.bits2[j])) >> ALLOC_STEPS);
+            if (tmp >= uni(F.thresh[j]) || done) { done = 1; psum += imin(tmp, uni(F.cap[j])); }
             else if (tmp >= alloc_floor) psum += alloc_floor;
         }
         if (psum > total) hi = mid; else lo = mid;
@@ -130,10 +130,10 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
     {
         int done = 0;
         for (int j = end; j-- > start;) {
-            int tmp = F.bits1[j] + ((lo * F.bits2[j]) >> ALLOC_STEPS);
-            if (tmp < F.thresh[j] && !done) tmp = tmp >= alloc_floor ? alloc_floor : 0;
+            int tmp = uni(F.bits1[j]) + ((lo * uni(F.bits2[j])) >> ALLOC_STEPS);
+            if (tmp < uni(F.thresh[j]) && !done) tmp = tmp >= alloc_floor ? alloc_floor : 0;
             else done = 1;
-            tmp = imin(tmp, F.cap[j]);
+            tmp = imin(tmp, uni(F.cap[j]));
             st0(&bits[j], tmp);
             psum += tmp;
         }
@@ -148,8 +148,8 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
         left -= (eB[codedBands] - eB[start]) * percoeff;
         int rem = imax(left - (eB[j] - eB[start]), 0);
         int band_width = eB[codedBands] - eB[j];
-        int band_bits = (int)(bits[j] + percoeff * band_width + rem);
-        if (band_bits >= imax(F.thresh[j], alloc_floor + (1 << BITRES))) {
+        int band_bits = (int)(uni(bits[j]) + percoeff * band_width + rem);
+        if (band_bits >= imax(uni(F.thresh[j]), alloc_floor + (1 << BITRES))) {
             if (codedBands <= start + 2 || (band_bits > (((j < prev ? 7 : 9) * band_width) << LM << BITRES) >> 4 && j <= signalBandwidth)) {
                 ec_enc_bit_logp(ec, 1, 1);
                 break;
@@ -158,7 +158,7 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
             psum += 1 << BITRES;
             band_bits -= 1 << BITRES;
         }
-        psum -= bits[j] + intensity_rsv;
+        psum -= uni(bits[j]) + intensity_rsv;
         if (intensity_rsv > 0) intensity_rsv = CLT_log2_frac_table[j - start];
         psum += intensity_rsv;
         if (band_bits >= alloc_floor) { psum += alloc_floor; st0(&bits[j], (i32)alloc_floor); }
@@ -177,20 +177,20 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
     i32 left = total - psum;
     i32 percoeff = (u32)left / (u32)(eB[codedBands] - eB[start]);
     left -= (eB[codedBands] - eB[start]) * percoeff;
-    for (int j = start; j < codedBands; j++) st0(&bits[j], bits[j] + (int)percoeff * (eB[j + 1] - eB[j]));
+    for (int j = start; j < codedBands; j++) st0(&bits[j], uni(bits[j]) + (int)percoeff * (eB[j + 1] - eB[j]));
     for (int j = start; j < codedBands; j++) {
         int tmp = (int)imin(left, eB[j + 1] - eB[j]);
-        st0(&bits[j], bits[j] + tmp);
+        st0(&bits[j], uni(bits[j]) + tmp);
         left -= tmp;
     }
     i32 balance = 0;
     int j;
     for (j = start; j < codedBands; j++) {
         int N0 = eB[j + 1] - eB[j], N = N0 << LM;
-        i32 bit = (i32)bits[j] + balance, excess;
+        i32 bit = (i32)uni(bits[j]) + balance, excess;
         i32 bj, ej, fp;
         if (N > 1) {
-            excess = imax(bit - F.cap[j], 0);
+            excess = imax(bit - uni(F.cap[j]), 0);
             bj = bit - excess;
             int den = C * N + ((C == 2 && N > 2 && !out.dual_stereo && j < out.intensity) ? 1 : 0);
             int NClogN = den * (CLT_logN400[j] + logM);
@@ -224,7 +224,7 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
     }
     out.balance = balance;
     for (; j < end; j++) {
-        i32 e = bits[j] >> stereo >> BITRES;
+        i32 e = uni(bits[j]) >> stereo >> BITRES;
         st0(&ebits[j], e);
         st0(&bits[j], 0);
         st0(&fine_priority[j], (i32)(e < 1));
@@ -238,17 +238,17 @@ template <class L>
 CA_DEVFN void quant_fine_energy_wave(L &F, RangeEnc &enc, int C)                    // quant_bands.c:369-404
 {
     for (int i = 0; i < NB; i++) {
-        int fq = F.fine_quant[i];
+        int fq = uni((i32)F.fine_quant[i]);
         if (fq <= 0) continue;
         i32 frac = (i16)(1 << fq);
         for (int c = 0; c < C; c++) {
-            int q2 = (F.error[i + c * NB] + 512) >> (10 - fq);
+            int q2 = (uni((i32)F.error[i + c * NB]) + 512) >> (10 - fq);
             if (q2 > frac - 1) q2 = frac - 1;
             if (q2 < 0) q2 = 0;
             ec_enc_bits(enc, (u32)q2, (u32)fq);
             i32 offset = (i16)sub16((shl32(q2, 10) + 512) >> fq, 512);
-            st0(&F.oldBandE[i + c * NB], (i16)(F.oldBandE[i + c * NB] + offset));
-            st0(&F.error[i + c * NB], (i16)(F.error[i + c * NB] - offset));
+            st0(&F.oldBandE[i + c * NB], (i16)(uni((i32)F.oldBandE[i + c * NB]) + offset));
+            st0(&F.error[i + c * NB], (i16)(uni((i32)F.error[i + c * NB]) - offset));
         }
     }
     wave_sync();
@@ -259,12 +259,12 @@ CA_DEVFN void quant_energy_finalise_wave(L &F, RangeEnc &enc, int bits_left, int
 {
     for (int prio = 0; prio < 2; prio++) {
         for (int i = 0; i < NB && bits_left >= C; i++) {
-            if (F.fine_quant[i] >= MAX_FINE_BITS || F.fine_priority[i] != prio) continue;
+            if (uni((i32)F.fine_quant[i]) >= MAX_FINE_BITS || uni((i32)F.fine_priority[i]) != prio) continue;
             for (int c = 0; c < C; c++) {
-                int q2 = F.error[i + c * NB] < 0 ? 0 : 1;
+                int q2 = uni((i32)F.error[i + c * NB]) < 0 ? 0 : 1;
                 ec_enc_bits(enc, (u32)q2, 1);
-                i32 offset = (i16)((shl16(q2, 10) - 512) >> (F.fine_quant[i] + 1));
-                st0(&F.oldBandE[i + c * NB], (i16)(F.oldBandE[i + c * NB] + offset));
+                i32 offset = (i16)((shl16(q2, 10) - 512) >> (uni((i32)F.fine_quant[i]) + 1));
+                st0(&F.oldBandE[i + c * NB], (i16)(uni((i32)F.oldBandE[i + c * NB]) + offset));
                 bits_left--;
             }
         }
@@ -351,7 +351,7 @@ CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
         p += pvq_u(N - j, suf[j + 1]);
         if (y[j] < 0) p += pvq_u(N - j, suf[j] + 1);
     }
-    u32 idx = (u32)wave_add((i32)p) + (u32)(y[N - 1] < 0);
+    u32 idx = (u32)wave_add((i32)p) + (u32)(uni(y[N - 1]) < 0);
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
     wave_sync();
     ec_enc_uint(ec, idx, V);
@@ -428,8 +428,8 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
     if (pulsesLeft > N + 3) {
         i32 tmp = (i16)pulsesLeft;
         yy = (i16)mac16_16(yy, tmp, tmp);
-        yy = (i16)mac16_16(yy, tmp, y[0]);
-        st0(&iy[0], iy[0] + pulsesLeft);
+        yy = (i16)mac16_16(yy, tmp, uni((i32)y[0]));
+        st0(&iy[0], uni(iy[0]) + pulsesLeft);
         pulsesLeft = 0;
         wave_sync();
     }
@@ -447,8 +447,8 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
         }
         // wave arg-max under the same (exact, cross-multiplied) order; ties go to the lower index
         pvq_argmax(best_num, best_den, best_id);
-        xy = add32(xy, xa[best_id]);
-        yy = add16(yy, y[best_id]);
+        xy = add32(xy, uni((i32)xa[best_id]));
+        yy = add16(yy, uni((i32)y[best_id]));
         if (lane() == (best_id & (LANES - 1))) { y[best_id] = (i16)(y[best_id] + 2); iy[best_id] = iy[best_id] + 1; }
         wave_sync();
     }
@@ -525,7 +525,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
         if (stereo) {
             if (itheta == 0) {
                 // intensity_stereo (bands.c:336-360)
-                i32 bl = F.bandE[i], br = F.bandE[i + NB];
+                i32 bl = uni(F.bandE[i]), br = uni(F.bandE[i + NB]);
                 int shift = celt_zlog2(imax(bl, br)) - 13;
                 i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
                 i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
@@ -547,7 +547,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
             for (int j = lane(); j < N; j += LANES) Y[j] = (i16)(-Y[j]);
         wave_sync();
         {
-            i32 bl = F.bandE[i], br = F.bandE[i + NB];
+            i32 bl = uni(F.bandE[i]), br = uni(F.bandE[i + NB]);
             int shift = celt_zlog2(imax(bl, br)) - 13;
             i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
             i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
@@ -580,7 +580,7 @@ CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i
     const i16 *x = X;
     for (int c = 0; c < (Y ? 2 : 1); c++) {
         if (ctx.remaining_bits >= 1 << BITRES) {
-            ec_enc_bits(ec, (u32)(x[0] < 0), 1);
+            ec_enc_bits(ec, (u32)(uni((i32)x[0]) < 0), 1);
             ctx.remaining_bits -= 1 << BITRES;
         }
         x = Y;
@@ -683,13 +683,13 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
         if (sp == 0) break;
         sp--;
         const i32 *fr = F.pstack[sp];
-        xoff = fr[0];
-        b = fr[1];
-        N = fr[2];
-        B = fr[3];
-        LM = fr[4];
-        i32 rebalance = fr[6] - (fr[5] - ctx.remaining_bits);
-        if (rebalance > 3 << BITRES && fr[7]) b += rebalance - (3 << BITRES);
+        xoff = uni(fr[0]);
+        b = uni(fr[1]);
+        N = uni(fr[2]);
+        B = uni(fr[3]);
+        LM = uni(fr[4]);
+        i32 rebalance = uni(fr[6]) - (uni(fr[5]) - ctx.remaining_bits);
+        if (rebalance > 3 << BITRES && uni(fr[7])) b += rebalance - (3 << BITRES);
     }
 }
 
@@ -718,11 +718,11 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
         int b;
         if (i <= codedBands - 1) {
             i32 curr_balance = balance / imin(3, codedBands - i);
-            b = imax(0, imin(16383, imin(remaining_bits + 1, F.pulses[i] + curr_balance)));
+            b = imax(0, imin(16383, imin(remaining_bits + 1, uni(F.pulses[i]) + curr_balance)));
         } else {
             b = 0;
         }
-        ctx.tf_change = F.tf_res[i];
+        ctx.tf_change = uni(F.tf_res[i]);
         if (dual_stereo && i == intensity) dual_stereo = 0;
 
         // plan the jobs
@@ -745,7 +745,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
                     ctx.remaining_bits -= sc.qalloc + sbits;
                     i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
                     if (sbits) {
-                        int sign = ((i32)x2[0] * y2[1] - (i32)x2[1] * y2[0]) < 0;
+                        int sign = (uni((i32)x2[0]) * uni((i32)y2[1]) - uni((i32)x2[1]) * uni((i32)y2[0])) < 0;
                         ec_enc_bits(ec, (u32)sign, 1);
                     }
                     njobs = 1; jx0 = x2; jb0 = mbits;
@@ -771,7 +771,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
             }
             quant_band_wave(F, ec, ctx, jx, N, jb, B, LM);
         }
-        balance += F.pulses[i] + tell;
+        balance += uni(F.pulses[i]) + tell;
     }
 }
 

@@ -121,10 +121,14 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
         int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
         int g1 = n < cus * 6 ? n : cus * 6;          // ~23 KB LDS per workgroup -> 6 resident per CU
         int g2 = n < cus * 16 ? n : cus * 16;        // ~9.6 KB LDS per workgroup -> 16 resident per CU
+        int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT, s);
         hipLaunchKernelGGL(celt_front_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr,
                            d_pcm + first * FRAME * cfg->channels, mid, n);
+        opusgpu_timing_end(slot, s);
+        slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_BACK, s);
         hipLaunchKernelGGL(celt_back_kernel, dim3(g2), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid,
                            d_out + first * (size_t)out_stride, out_stride, d_out_len + first, d_out_rng + first, n);
+        opusgpu_timing_end(slot, s);
     }
     return opusgpu_check_launch();
 }

@@ -80,8 +80,8 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
         int cost0 = 0, cost1 = isTransient ? 0 : lambda;
         for (int i = 1; i < len; i++) {
             int curr0 = imin(cost0, cost1 + lambda), curr1 = imin(cost0 + lambda, cost1);
-            cost0 = curr0 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * sel + 0]);
-            cost1 = curr1 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * sel + 1]);
+            cost0 = curr0 + iabs(uni(F.metric[i]) - 2 * tab[4 * isTransient + 2 * sel + 0]);
+            cost1 = curr1 + iabs(uni(F.metric[i]) - 2 * tab[4 * isTransient + 2 * sel + 1]);
         }
         if (sel == 0) selcost0 = imin(cost0, cost1); else selcost1 = imin(cost0, cost1);
     }
@@ -93,14 +93,14 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
         from0 = cost0 + lambda;
         from1 = cost1;
         if (from0 < from1) { curr1 = from0; st0(&F.path1[i], 0); } else { curr1 = from1; st0(&F.path1[i], 1); }
-        cost0 = curr0 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * tf_select + 0]);
-        cost1 = curr1 + iabs(F.metric[i] - 2 * tab[4 * isTransient + 2 * tf_select + 1]);
+        cost0 = curr0 + iabs(uni(F.metric[i]) - 2 * tab[4 * isTransient + 2 * tf_select + 0]);
+        cost1 = curr1 + iabs(uni(F.metric[i]) - 2 * tab[4 * isTransient + 2 * tf_select + 1]);
     }
     wave_sync();
     int r = cost0 < cost1 ? 0 : 1;
     st0(&F.tf_res[len - 1], r);
     for (int i = len - 2; i >= 0; i--) {
-        r = r == 1 ? F.path1[i + 1] : F.path0[i + 1];
+        r = r == 1 ? uni(F.path1[i + 1]) : uni(F.path0[i + 1]);
         st0(&F.tf_res[i], r);
     }
     wave_sync();
@@ -119,7 +119,7 @@ CA_DEVFN void tf_encode_wave(L &F, RangeEnc &enc, int isTransient, int tf_select
     int curr = 0, tf_changed = 0;
     i32 *res = F.path0;                               // scratch copy of the (possibly overridden) decisions
     for (int i = 0; i < NB; i++) {
-        int r = F.tf_res[i];
+        int r = uni(F.tf_res[i]);
         if (tell + logp <= budget) {
             ec_enc_bit_logp(enc, r ^ curr, logp);
             tell = (u32)ec_tell(enc);
@@ -155,8 +155,8 @@ CA_DEVFN int coarse_energy_impl(const i16 *eBands, i16 *oldE, i16 *err, RangeEnc
     else { beta = CLT_beta_coef[LM]; coef = CLT_pred_coef[LM]; }
     for (int i = 0; i < NB; i++) {
         for (int c = 0; c < C; c++) {
-            i32 x = eBands[i + c * NB];
-            i32 oldraw = oldE[i + c * NB];
+            i32 x = uni((i32)eBands[i + c * NB]);
+            i32 oldraw = uni((i32)oldE[i + c * NB]);
             i32 oldEc = imax(-9216, oldraw);                                      // -QCONST16(9.f,DB_SHIFT)
             const i32 prevc = c == 0 ? prev0 : prev1;
             i32 f = sub32(sub32(shl32(x, 7), pshr32(mul16_16(coef, oldEc), 8)), prevc);

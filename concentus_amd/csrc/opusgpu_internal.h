@@ -6,3 +6,6 @@
 extern "C" void opusgpu_set_last_error(int err);
 // hipGetLastError() mapped to an OPUSGPU_* code
 extern "C" int opusgpu_check_launch(void);
+// optional per-kernel timing (see opusgpu_kernel_timing_enable); slot -1 = timing off
+extern "C" int opusgpu_timing_begin(int kernel, hipStream_t s);
+extern "C" void opusgpu_timing_end(int slot, hipStream_t s);

@@ -1,5 +1,7 @@
 // runtime.hip -- process-level plumbing of libopusgpu.so: version, error strings, device queries.
 #include <stdio.h>
+#include <mutex>
+#include <vector>
 #include "opusgpu_internal.h"
 
 static thread_local int g_last_error = OPUSGPU_OK;
@@ -36,4 +38,57 @@ extern "C" int opusgpu_num_cus(void)
         cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     }
     return cus;
+}
+
+// ---- optional per-kernel timing (HIP events on the launch stream) ----
+namespace {
+struct TimedLaunch { int kernel; hipEvent_t t0, t1; };
+std::mutex g_tm;
+bool g_timing = false;
+std::vector<TimedLaunch> g_launches;
+}
+
+extern "C" int opusgpu_kernel_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    g_timing = on != 0;
+    return OPUSGPU_OK;
+}
+
+// internal: bracket one launch. begin returns a slot index or -1 when timing is off.
+extern "C" int opusgpu_timing_begin(int kernel, hipStream_t s)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    if (!g_timing) return -1;
+    TimedLaunch t;
+    t.kernel = kernel;
+    if (hipEventCreate(&t.t0) != hipSuccess || hipEventCreate(&t.t1) != hipSuccess) return -1;
+    hipEventRecord(t.t0, s);
+    g_launches.push_back(t);
+    return (int)g_launches.size() - 1;
+}
+
+extern "C" void opusgpu_timing_end(int slot, hipStream_t s)
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_tm);
+    hipEventRecord(g_launches[slot].t1, s);
+}
+
+extern "C" int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_kernels)
+{
+    std::lock_guard<std::mutex> lk(g_tm);
+    if (!ms_sum || !launches || n_kernels < 0) return OPUSGPU_BAD_ARG;
+    for (int k = 0; k < n_kernels; k++) { ms_sum[k] = 0; launches[k] = 0; }
+    int rc = OPUSGPU_OK;
+    for (auto &t : g_launches) {
+        float ms = 0;
+        if (hipEventSynchronize(t.t1) != hipSuccess || hipEventElapsedTime(&ms, t.t0, t.t1) != hipSuccess)
+            rc = OPUSGPU_INTERNAL_ERROR;
+        else if (t.kernel >= 0 && t.kernel < n_kernels) { ms_sum[t.kernel] += ms; launches[t.kernel]++; }
+        hipEventDestroy(t.t0);
+        hipEventDestroy(t.t1);
+    }
+    g_launches.clear();
+    return rc;
 }

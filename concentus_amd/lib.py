@@ -16,6 +16,8 @@ SYMBOLS = [
     ("opusgpu_strerror", C.c_char_p, [_i]),
     ("opusgpu_get_last_error", _i, []),
     ("opusgpu_num_cus", _i, []),
+    ("opusgpu_kernel_timing_enable", _i, [_i]),
+    ("opusgpu_kernel_timing_read", _i, [_vp, _vp, _i]),
     ("opusgpu_mdct_forward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
     ("opusgpu_mdct_backward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
     ("opusgpu_clt_mdct_forward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),

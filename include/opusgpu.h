@@ -40,6 +40,17 @@ int opusgpu_get_last_error(void);
 /* Number of compute units of the current HIP device (256 on MI355X). */
 int opusgpu_num_cus(void);
 
+/* Optional per-kernel timing, the hook bench.py's roofline leg uses: while enabled, every kernel launch
+ * of opusgpu_encode_batch is bracketed by HIP events recorded on the launch stream.
+ * opusgpu_kernel_timing_read waits for the recorded launches, writes the summed duration (ms) and the
+ * launch count per kernel id into ms_sum[0..n_kernels) / launches[0..n_kernels), and forgets them.
+ * No counterpart in the reference (its timing is wall clock in src/opus_demo.c:750-800). */
+#define OPUSGPU_KERNEL_CELT_FRONT 0
+#define OPUSGPU_KERNEL_CELT_BACK  1
+#define OPUSGPU_KERNEL_COUNT      2
+int opusgpu_kernel_timing_enable(int on);
+int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_kernels);
+
 /* ---- CELT MDCT, batched (BASELINE config #2) -----------------------------------------------------
  * Replaces clt_mdct_forward_c / clt_mdct_backward_c (opus-fix/celt/mdct.c:121-259, :263-363) as they
  * are driven per frame by compute_mdcts (celt/celt_encoder.c:418-461) and celt_synthesis
