@@ -308,10 +308,13 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
-        ksum = (ctypes.c_double * 2)()
-        kcnt = (ctypes.c_int * 2)()
-        ca.lib.check(L.opusgpu_kernel_timing_read(ksum, kcnt, 2), "opusgpu_kernel_timing_read")
+        ksum = (ctypes.c_double * 3)()
+        kcnt = (ctypes.c_int * 3)()
+        ca.lib.check(L.opusgpu_kernel_timing_read(ksum, kcnt, 3), "opusgpu_kernel_timing_read")
         L.opusgpu_kernel_timing_enable(0)
+        back_name = "celt_back_lane_kernel" if kcnt[2] else "celt_back_kernel"
+        if kcnt[2]:
+            ksum[1], kcnt[1] = ksum[2], kcnt[2]
         kavg = [ksum[i] / max(kcnt[i], 1) for i in range(2)]
         launches_per_step = kcnt[0] // steps
         lens_h = lens.cpu().numpy()
@@ -324,9 +327,9 @@ def main():
         front_bytes = per_launch * (PCM_BYTES + MID_BYTES)
         back_bytes = per_launch * (MID_BYTES + mean_len + 8)
         if kavg[1] >= kavg[0]:
-            kname, kbytes, kms, other = "celt_back_kernel", int(back_bytes), kavg[1], ("celt_front_kernel", kavg[0], front_bytes)
+            kname, kbytes, kms, other = back_name, int(back_bytes), kavg[1], ("celt_front_kernel", kavg[0], front_bytes)
         else:
-            kname, kbytes, kms, other = "celt_front_kernel", int(front_bytes), kavg[0], ("celt_back_kernel", kavg[1], back_bytes)
+            kname, kbytes, kms, other = "celt_front_kernel", int(front_bytes), kavg[0], (back_name, kavg[1], back_bytes)
         metric = "48kHz stereo 20ms CELT frames encoded/sec"
         workload = ("configs[2]: %d independent 48 kHz stereo 20 ms frames per GPU, full CELT encode "
                     "(MDCT + PVQ + range enc) 96 kb/s VBR complexity 10, packets bit-exact vs FIXED_POINT "

@@ -97,6 +97,7 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
         if (psum > total) hi = mid - 1; else lo = mid + 1;
     } while (lo <= hi);
     hi = lo--;
+#pragma clang loop unroll(disable)
     for (int j = start; j < end; j++) {
         int N = eB[j + 1] - eB[j];
         int bits1j = (C * N * CLT_band_allocation[lo * len + j]) << LM >> 2;
@@ -359,7 +360,7 @@ CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
 
 // Wave arg-max of (num/den) with index tie-break. `o` beats `m` iff m.den*o.num > o.den*m.num, or the
 // cross products are equal and o.id < m.id -- the order the sequential scan of vq.c:277-300 induces.
-#if defined(CA_HOST_EMU)
+#if defined(CA_SINGLE_LANE)
 CA_DEV void pvq_argmax(i32 &, i32 &, int &) {}
 #else
 #define CA_ARGMAX_STEP(ctrl, rowmask)                                                          \
@@ -389,6 +390,10 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
     i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
     i32 *iy = F.s.pvq.iy;
     CA_STAMP_F(F, 22);
+    CA_COUNT("leaf.N", N);
+    CA_COUNT("leaf.K", K);
+    CA_COUNT(2 * K >= N || spread == SPREAD_NONE ? "leaf.norot" : "leaf.rot", N);
+    CA_COUNT(N <= 16 ? "leaf.N<=16" : N <= 32 ? "leaf.N<=32" : N <= 64 ? "leaf.N<=64" : "leaf.N>64", N);
     exp_rotation_wave(X, N, B, K, spread);
     CA_STAMP_F(F, 17);
     for (int j = lane(); j < N; j += LANES) {
@@ -434,6 +439,9 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
         wave_sync();
     }
     CA_STAMP_F(F, 18);
+    CA_COUNT(K > (N >> 1) ? "leaf.presearch" : "leaf.nopresearch", pulsesLeft);
+    CA_COUNT("greedy.pulses", pulsesLeft);
+    CA_COUNT("greedy.pulses*chunks", pulsesLeft * ((N + 63) / 64));
     for (int i = 0; i < pulsesLeft; i++) {
         const int rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
         yy = (i16)add32(yy, 1);
@@ -501,6 +509,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
     const int i = ctx.i;
     int inv = 0;
     CA_STAMP_F(F, 22);
+    CA_COUNT(stereo ? "theta.stereo" : "theta.split", N);
     int pulse_cap = CLT_logN400[i] + LM * (1 << BITRES);
     int offset = (pulse_cap >> 1) - (stereo && N == 2 ? QTHETA_OFFSET_TWOPHASE : QTHETA_OFFSET);
     int qn = compute_qn(N, *b, offset, pulse_cap, stereo);
@@ -611,6 +620,7 @@ template <class L>
 CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N, int b, int B, int LM)
 {
     CA_STAMP_F(F, 22);
+    CA_COUNT("quant_band", N);
     int N_B = (int)((u32)N / (u32)B);
     const int longBlocks = B == 1;
     int tf_change = ctx.tf_change;
@@ -671,6 +681,7 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
         }
         // leaf: the basic no-split case (bands.c:983-1039)
         int q = bits2pulses(ctx.i, LM, b);
+        CA_COUNT(q ? "node.leaf" : "node.leaf_q0", N);
         int curr_bits = pulses2bits(ctx.i, LM, q);
         ctx.remaining_bits -= curr_bits;
         while (ctx.remaining_bits < 0 && q > 0) {

@@ -12,8 +12,11 @@
 //
 // Replaces, for 48 kHz / 20 ms / restricted-lowdelay / fullband: opus_encode() (opus-fix/src/opus_encoder.c:2007)
 // -> opus_encode_native (:938) -> celt_encode_with_ec (opus-fix/celt/celt_encoder.c:1379).
+#include <stdlib.h>
 #include "celt_enc.h"
 #include "opusgpu_internal.h"
+extern "C" void opusgpu_launch_back_lane(const opusgpu_celt_config *cfg, void *states, const void *mid, unsigned char *out,
+                                         int out_stride, int32_t *out_len, uint32_t *out_rng, int n, hipStream_t s);
 
 namespace ca {
 
@@ -121,11 +124,18 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
         int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
         int g1 = n < cus * 6 ? n : cus * 6;          // ~23 KB LDS per workgroup -> 6 resident per CU
         int g2 = n < cus * 16 ? n : cus * 16;        // ~9.6 KB LDS per workgroup -> 16 resident per CU
+        // default: one lane per frame for the serial back phase; OPUSGPU_BACK_WAVE=1 selects the
+        // one-wave-per-frame kernel (kept for the stage-stamp diagnostics and as a cross-check)
+        const bool lane_back = getenv("OPUSGPU_BACK_WAVE") == nullptr;
         int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT, s);
         hipLaunchKernelGGL(celt_front_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr,
                            d_pcm + first * FRAME * cfg->channels, mid, n);
         opusgpu_timing_end(slot, s);
-        slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_BACK, s);
+        slot = opusgpu_timing_begin(lane_back ? OPUSGPU_KERNEL_CELT_BACK_LANE : OPUSGPU_KERNEL_CELT_BACK, s);
+        if (lane_back)
+            opusgpu_launch_back_lane(cfg, st ? st + first : nullptr, mid, d_out + first * (size_t)out_stride, out_stride,
+                                     d_out_len + first, d_out_rng + first, n, s);
+        else
         hipLaunchKernelGGL(celt_back_kernel, dim3(g2), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid,
                            d_out + first * (size_t)out_stride, out_stride, d_out_len + first, d_out_rng + first, n);
         opusgpu_timing_end(slot, s);

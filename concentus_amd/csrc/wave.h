@@ -10,6 +10,12 @@
 #pragma once
 #include <stdint.h>
 
+// CA_LANE_FRAME: device build in which ONE LANE owns one frame (LANES == 1 semantics on the GPU): the
+// same sources, every collective the identity, the per-frame working set in private memory.
+#if defined(CA_HOST_EMU) || defined(CA_LANE_FRAME)
+#define CA_SINGLE_LANE 1
+#endif
+
 #if defined(CA_HOST_EMU)
 #include <stdio.h>
 #if defined(CA_HOST_EMU_TRACE)
@@ -20,6 +26,9 @@
 // debug taps (host emulation only): record a named snapshot of an intermediate array
 extern "C" void emu_tap(const char *name, const void *p, int bytes);
 #define CA_TAP(name, p, bytes) emu_tap(name, p, bytes)
+// workload counters (host emulation only): sizes the per-frame work of a stage for the roofline notes
+extern "C" void emu_count(const char *name, long n);
+#define CA_COUNT(name, n) emu_count(name, (long)(n))
 #define CA_DEV static inline
 #define CA_HOSTDEV static inline
 #define CA_DEVICE_CONST static const
@@ -39,6 +48,7 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 #define CA_DEVICE_CONST static __device__ const
 #define CA_TRACE(...) do {} while (0)
 #define CA_TAP(name, p, bytes) do {} while (0)
+#define CA_COUNT(name, n) do {} while (0)
 #endif
 
 // Stage stamps: only in the diagnostic kernel build (-DCA_STAGE_TIMING, celt_enc_kernel_diag.hip); the
@@ -57,10 +67,12 @@ namespace ca { struct StageClock; }
 
 namespace ca {
 
-#if defined(CA_HOST_EMU)
+#if defined(CA_SINGLE_LANE)
 enum { LANES = 1 };
 CA_DEV int lane() { return 0; }
-CA_DEV void wave_sync() {}
+// still a compiler barrier: the working-set structs are read through differently typed views (unions,
+// i16 views of i32 arrays) and the sources rely on wave_sync() to order those accesses
+CA_DEV void wave_sync() { asm volatile("" ::: "memory"); }
 template <class T> CA_DEV T shfl_xor(T v, int) { return v; }
 template <class T> CA_DEV T bcast(T v, int) { return v; }
 #else
@@ -79,7 +91,7 @@ template <class T> CA_DEV T bcast(T v, int src) { return __shfl(v, src, 64); }
 #endif
 
 // ---- all-lanes reductions (result valid, and identical, in every lane) -----------------------------
-#if defined(CA_HOST_EMU)
+#if defined(CA_SINGLE_LANE)
 CA_DEV int32_t wave_add(int32_t v) { return v; }
 CA_DEV int32_t wave_max(int32_t v) { return v; }
 CA_DEV int32_t wave_min(int32_t v) { return v; }

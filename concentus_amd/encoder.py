@@ -7,6 +7,7 @@ lives in HBM, and `encode_independent` is the stateless form used for BASELINE c
 is the first frame of its own stream). All computation happens in libopusgpu.so.
 """
 import ctypes as C
+import os
 
 from . import lib as _lib
 
@@ -55,7 +56,7 @@ def _check_pcm(pcm, channels):
 
 
 _WORKSPACE = {}
-WORKSPACE_FRAMES = 32768      # hand-off records kept in HBM at once (larger batches are chunked by the library)
+WORKSPACE_FRAMES = int(os.environ.get("CONCENTUS_WS_FRAMES", 262144))      # hand-off records kept in HBM at once (larger batches are chunked by the library)
 
 
 def _workspace(device, n_frames):

@@ -47,7 +47,8 @@ int opusgpu_num_cus(void);
  * No counterpart in the reference (its timing is wall clock in src/opus_demo.c:750-800). */
 #define OPUSGPU_KERNEL_CELT_FRONT 0
 #define OPUSGPU_KERNEL_CELT_BACK  1
-#define OPUSGPU_KERNEL_COUNT      2
+#define OPUSGPU_KERNEL_CELT_BACK_LANE 2
+#define OPUSGPU_KERNEL_COUNT      3
 int opusgpu_kernel_timing_enable(int on);
 int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_kernels);
 

@@ -24,6 +24,25 @@ extern "C" int emu_tap_get(const char *name, void *out, int cap)
 
 using namespace ca;
 
+// ---- workload counters (CA_COUNT) ----
+#include <map>
+#include <string>
+static std::map<std::string, std::pair<long, long>> g_counts;       // name -> (events, sum)
+extern "C" void emu_count(const char *name, long n) { auto &c = g_counts[name]; c.first++; c.second += n; }
+extern "C" void emu_counts_reset(void) { g_counts.clear(); }
+extern "C" int emu_counts_dump(char *buf, int cap)
+{
+    std::string o;
+    for (auto &kv : g_counts) {
+        char line[160];
+        snprintf(line, sizeof line, "%s %ld %ld\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        o += line;
+    }
+    if ((int)o.size() + 1 > cap) return -1;
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return (int)o.size();
+}
+
 extern "C" int emu_celt_encode_frames(const opusgpu_celt_config *cfg, opusgpu_celt_state *states /* or NULL */,
                                       const int16_t *pcm, int nframes, int frames_per_stream,
                                       unsigned char *out, int out_stride, int *out_len, uint32_t *out_rng)
@@ -35,8 +54,9 @@ extern "C" int emu_celt_encode_frames(const opusgpu_celt_config *cfg, opusgpu_ce
     FrameMid *mid = (FrameMid *)aligned_alloc(64, sizeof(FrameMid) + 64);
     const int C = cfg->channels;
     for (int n = 0; n < nframes; n++) {
-        memset(F1, 0xAB, sizeof(FrontLds));     // poison: catch reads of never-written LDS
-        memset(F2, 0xAB, sizeof(BackLds));
+        const int poison = getenv("EMU_POISON") ? atoi(getenv("EMU_POISON")) : 0xAB;
+        memset(F1, poison, sizeof(FrontLds));     // poison: catch reads of never-written LDS
+        memset(F2, poison, sizeof(BackLds));
         memset(mid, 0xCD, sizeof(FrameMid));
         opusgpu_celt_state *st = states ? &states[n / frames_per_stream] : NULL;
         celt_encode_front(*F1, *cfg, st, st, pcm + (size_t)n * 960 * C, mid);

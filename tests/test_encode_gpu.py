@@ -122,3 +122,19 @@ def test_bad_configs_rejected(ca):
         ca.encode_independent(torch.zeros((2, 480, 2), dtype=torch.int16, device="cuda"))
     out, lens, _ = ca.encode_independent(torch.zeros((0, 960, 2), dtype=torch.int16, device="cuda"))
     assert out.shape[0] == 0
+
+
+def test_wave_per_frame_back_kernel_agrees_with_lane_per_frame(ca, monkeypatch):
+    """The library ships two mappings of the back phase (one lane per frame: default; one wave per frame:
+    OPUSGPU_BACK_WAVE=1, also the build the stage-stamp diagnostics use). Same sources, same packets."""
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm("music", 1024, 99)
+    a = _gpu_encode(ca, pcm, 1, (96000, 1, 0, 10))
+    monkeypatch.setenv("OPUSGPU_BACK_WAVE", "1")
+    b = _gpu_encode(ca, pcm, 1, (96000, 1, 0, 10))
+    monkeypatch.delenv("OPUSGPU_BACK_WAVE")
+    ec.assert_packets_equal(a[0], a[1], a[2], b[0], b[1], b[2], "lane vs wave back kernel")
+    pk, ln, rg = ec.load_case("music_vbr_indep")[1:]
+    monkeypatch.setenv("OPUSGPU_BACK_WAVE", "1")
+    w = _gpu_encode(ca, ec.load_case("music_vbr_indep")[0], 1, (96000, 1, 0, 10))
+    ec.assert_packets_equal(w[0], w[1], w[2], pk, ln, rg, "wave back kernel vs golden")
