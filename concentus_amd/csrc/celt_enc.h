@@ -130,7 +130,8 @@ struct FrameMid {
     i32 prefilter_period, prefilter_gain, prefilter_tapset_state, consec_transient;
     i32 preemph_memE[2];
     i32 vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max, stereo_saving, intensity, spec_avg;
-    i32 pad[3];
+    i32 trans_unmask[2];           // per-channel masking metric (transient stage kernel; split pipeline only)
+    i32 pad[4];                    // keeps X 16-byte aligned (it is moved with 128-bit accesses)
     u8 packet_head[32];
     i32 bandE[2 * NB];
     i16 bandLogE[2 * NB], bandLogE2[2 * NB], oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
@@ -138,22 +139,120 @@ struct FrameMid {
     i16 X[2 * FRAME];
 };
 
+// Scalars that travel between the phases next to the range-coder state and the FrameCtx.
+struct MidScalars {
+    int max_data_bytes, nbCompressedBytes, nbAvailableBytes, effectiveBytes;
+    i32 vbr_rate, equiv_rate, total_bits;
+    int silence, pitch_index, pf_on, prefilter_tapset;
+    i32 gain1;
+    int isTransient, shortBlocks, tf_chan, transient_got_disabled;
+    i32 tf_estimate, temporal_vbr;
+};
+
+template <class L>
+CA_DEV void mid_store(L &F, FrameMid *mid, const RangeEnc &enc, const FrameCtx &fc, const MidScalars &m)
+{
+    for (int k = lane(); k < 2 * NB; k += LANES) {
+        mid->bandE[k] = F.bandE[k];
+        mid->bandLogE[k] = F.bandLogE[k];
+        mid->bandLogE2[k] = F.bandLogE2[k];
+        mid->oldBandE[k] = F.oldBandE[k];
+        mid->oldLogE[k] = F.oldLogE[k];
+        mid->oldLogE2[k] = F.oldLogE2[k];
+    }
+    for (int k = lane(); k < 32; k += LANES) mid->packet_head[k] = F.packet[1 + k];
+    if (lane() == 0) {
+        mid->ec_storage = enc.storage; mid->ec_end_offs = enc.end_offs; mid->ec_end_window = enc.end_window;
+        mid->ec_offs = enc.offs; mid->ec_rng = enc.rng; mid->ec_val = enc.val; mid->ec_ext = enc.ext;
+        mid->ec_nend_bits = enc.nend_bits; mid->ec_nbits_total = enc.nbits_total; mid->ec_rem = enc.rem;
+        mid->ec_error = (enc.offs > 32 || enc.end_offs > 0) ? -1 : enc.error;
+        mid->max_data_bytes = m.max_data_bytes; mid->nbCompressedBytes = m.nbCompressedBytes;
+        mid->nbAvailableBytes = m.nbAvailableBytes; mid->vbr_rate = m.vbr_rate; mid->effectiveBytes = m.effectiveBytes;
+        mid->equiv_rate = m.equiv_rate; mid->total_bits = m.total_bits;
+        mid->silence = m.silence; mid->pitch_index = m.pitch_index; mid->gain1 = m.gain1; mid->pf_on = m.pf_on;
+        mid->prefilter_tapset = m.prefilter_tapset;
+        mid->isTransient = m.isTransient; mid->shortBlocks = m.shortBlocks; mid->tf_chan = m.tf_chan;
+        mid->tf_estimate = m.tf_estimate; mid->transient_got_disabled = m.transient_got_disabled;
+        mid->temporal_vbr = m.temporal_vbr;
+        for (int k = 0; k < 4; k++) mid->hp_mem[k] = fc.hp_mem[k];
+        mid->rng = fc.rng; mid->spread_decision = fc.spread_decision; mid->delayedIntra = fc.delayedIntra;
+        mid->tonal_average = fc.tonal_average; mid->lastCodedBands = fc.lastCodedBands; mid->hf_average = fc.hf_average;
+        mid->tapset_decision = fc.tapset_decision; mid->prefilter_period = fc.prefilter_period;
+        mid->prefilter_gain = fc.prefilter_gain; mid->prefilter_tapset_state = fc.prefilter_tapset;
+        mid->consec_transient = fc.consec_transient;
+        mid->preemph_memE[0] = fc.preemph_memE[0]; mid->preemph_memE[1] = fc.preemph_memE[1];
+        mid->vbr_reservoir = fc.vbr_reservoir; mid->vbr_drift = fc.vbr_drift; mid->vbr_offset = fc.vbr_offset;
+        mid->vbr_count = fc.vbr_count; mid->overlap_max = fc.overlap_max; mid->stereo_saving = fc.stereo_saving;
+        mid->intensity = fc.intensity; mid->spec_avg = fc.spec_avg;
+    }
+}
+
+template <class L>
+CA_DEV void mid_load(L &F, const FrameMid *mid, RangeEnc &enc, FrameCtx &fc, MidScalars &m, int C)
+{
+    fc.C = C;
+    fc.hist = nullptr;
+    for (int k = 0; k < 4; k++) fc.hp_mem[k] = uni(mid->hp_mem[k]);
+    fc.rng = uni(mid->rng); fc.spread_decision = uni(mid->spread_decision); fc.delayedIntra = uni(mid->delayedIntra);
+    fc.tonal_average = uni(mid->tonal_average); fc.lastCodedBands = uni(mid->lastCodedBands); fc.hf_average = uni(mid->hf_average);
+    fc.tapset_decision = uni(mid->tapset_decision); fc.prefilter_period = uni(mid->prefilter_period);
+    fc.prefilter_gain = uni(mid->prefilter_gain); fc.prefilter_tapset = uni(mid->prefilter_tapset_state);
+    fc.consec_transient = uni(mid->consec_transient);
+    fc.preemph_memE[0] = uni(mid->preemph_memE[0]); fc.preemph_memE[1] = uni(mid->preemph_memE[1]);
+    fc.vbr_reservoir = uni(mid->vbr_reservoir); fc.vbr_drift = uni(mid->vbr_drift); fc.vbr_offset = uni(mid->vbr_offset);
+    fc.vbr_count = uni(mid->vbr_count); fc.overlap_max = uni(mid->overlap_max); fc.stereo_saving = uni(mid->stereo_saving);
+    fc.intensity = uni(mid->intensity); fc.spec_avg = uni(mid->spec_avg);
+    m.max_data_bytes = uni(mid->max_data_bytes); m.nbCompressedBytes = uni(mid->nbCompressedBytes);
+    m.nbAvailableBytes = uni(mid->nbAvailableBytes); m.vbr_rate = uni(mid->vbr_rate); m.effectiveBytes = uni(mid->effectiveBytes);
+    m.equiv_rate = uni(mid->equiv_rate); m.total_bits = uni(mid->total_bits);
+    m.silence = uni(mid->silence); m.pitch_index = uni(mid->pitch_index); m.gain1 = uni(mid->gain1); m.pf_on = uni(mid->pf_on);
+    m.prefilter_tapset = uni(mid->prefilter_tapset);
+    m.isTransient = uni(mid->isTransient); m.shortBlocks = uni(mid->shortBlocks); m.tf_chan = uni(mid->tf_chan);
+    m.tf_estimate = uni(mid->tf_estimate); m.transient_got_disabled = uni(mid->transient_got_disabled);
+    m.temporal_vbr = uni(mid->temporal_vbr);
+    enc.buf = F.packet + 1;
+    enc.storage = uni(mid->ec_storage); enc.end_offs = uni(mid->ec_end_offs); enc.end_window = uni(mid->ec_end_window);
+    enc.offs = uni(mid->ec_offs); enc.rng = uni(mid->ec_rng); enc.val = uni(mid->ec_val); enc.ext = uni(mid->ec_ext);
+    enc.nend_bits = uni(mid->ec_nend_bits); enc.nbits_total = uni(mid->ec_nbits_total); enc.rem = uni(mid->ec_rem);
+    enc.error = uni(mid->ec_error);
+    for (int k = lane(); k < 2 * NB; k += LANES) {
+        F.bandE[k] = mid->bandE[k];
+        F.bandLogE[k] = mid->bandLogE[k];
+        F.bandLogE2[k] = mid->bandLogE2[k];
+        F.oldBandE[k] = mid->oldBandE[k];
+        F.oldLogE[k] = mid->oldLogE[k];
+        F.oldLogE2[k] = mid->oldLogE2[k];
+    }
+    for (int k = lane(); k < 32; k += LANES) F.packet[1 + k] = mid->packet_head[k];
+    wave_sync();
+}
+
 // Phase 1: PCM -> FrameMid (steps 0-10 of SURVEY 3.2). pcm: 960*C interleaved int16 (global).
 // st_in == nullptr: independent first frame. st_out may be nullptr or == st_in; this phase stores the
 // time-domain part of the stream state (in_mem, prefilter_mem), phase 2 stores the rest.
-template <class L>
-CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
-                                opusgpu_celt_state *st_out, const i16 *pcm, FrameMid *mid, StageClock *stage_clock = nullptr)
+// PHASE 0: the whole phase in one call. The split pipeline runs it as two kernels around the serial
+// stages that have their own lane-per-channel kernels (celt_stage_kernels.hip):
+//   PHASE 1: dc_reject already done (planar int16 in mid->X, filter memory in mid->hp_mem); runs up to the
+//            pitch pre-filter and parks the time signal in in_ws ([2][1080] int32) + the scalars in mid;
+//   PHASE 2: resumes there with the transient metric of mid->trans_unmask.
+template <int PHASE, class L>
+CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
+                                      opusgpu_celt_state *st_out, const i16 *pcm, FrameMid *mid, StageClock *stage_clock,
+                                      i32 *in_ws)
 {
     (void)stage_clock;
     if (lane() == 0) F.diag = (void *)stage_clock;
     wave_sync();
     const int C = cfg.channels, N = FRAME, LM = LM3, M = M8, end = NB;
     FrameCtx fc;
+    RangeEnc enc;
+    int max_data_bytes, nbCompressedBytes, nbAvailableBytes, effectiveBytes, silence, pitch_index, pf_on, prefilter_tapset;
+    i32 vbr_rate, equiv_rate, total_bits, gain1;
+  if constexpr (PHASE != 2) {
     load_state(fc, F, st_in, C);
 
     // ---- Opus layer: rate bookkeeping (opus_encoder.c:1040-1054, 1440-1453, 1735-1770, 1873-1876) ----
-    int max_data_bytes = imin(1276, cfg.max_data_bytes);
+    max_data_bytes = imin(1276, cfg.max_data_bytes);
     i32 bitrate_bps = cfg.bitrate;
     if (!cfg.vbr) {
         int cbrBytes = imin((3 * bitrate_bps / 8 + 150 / 2) / 150, max_data_bytes);
@@ -168,28 +267,31 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
     const i32 celt_bitrate = cfg.vbr ? bitrate_bps : -1;
     const int constrained_vbr = cfg.constrained_vbr;
 
-    RangeEnc enc;
     ec_enc_init(enc, F.packet + 1, (u32)(max_data_bytes - 1));
     ec_enc_shrink(enc, (u32)nb_compr_bytes);
 
     // ---- stage PCM, dc_reject (opus_encoder.c:1473) ----
-    {
+    if constexpr (PHASE == 1) {
+        const int4 *src = reinterpret_cast<const int4 *>(mid->X);
+        int4 *dst = reinterpret_cast<int4 *>(frame_pcmf(F));
+        for (int k = lane(); k < (N * C * 2) / 16; k += LANES) dst[k] = src[k];
+        for (int k = 0; k < 4; k++) fc.hp_mem[k] = uni(mid->hp_mem[k]);
+        wave_sync();
+    } else {
         const int4 *src = reinterpret_cast<const int4 *>(pcm);
         int4 *dst = reinterpret_cast<int4 *>(F.s.raw_pcm);
         for (int k = lane(); k < (N * C * 2) / 16; k += LANES) dst[k] = src[k];
+        wave_sync();
+        dc_reject_wave(F, fc);
     }
-    wave_sync();
-    dc_reject_wave(F, fc);
     CA_TRACE("dc_reject done");
 
     CA_STAMP(0);
     // ---- celt_encode_with_ec ----
     i32 tell = ec_tell(enc);                                   // == 1
     const int nbFilledBytes = (tell + 4) >> 3;                 // == 0
-    int nbCompressedBytes = imin(nb_compr_bytes, 1275);
-    int nbAvailableBytes = nbCompressedBytes - nbFilledBytes;
-    i32 vbr_rate;
-    int effectiveBytes;
+    nbCompressedBytes = imin(nb_compr_bytes, 1275);
+    nbAvailableBytes = nbCompressedBytes - nbFilledBytes;
     if (celt_vbr && celt_bitrate != -1) {
         i32 den = 48000 >> BITRES;
         vbr_rate = (celt_bitrate * N + (den >> 1)) / den;
@@ -201,7 +303,7 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
         if (celt_bitrate != -1) nbCompressedBytes = imax(2, imin(nbCompressedBytes, (tmp + 4 * 48000) / (8 * 48000)));
         effectiveBytes = nbCompressedBytes;
     }
-    i32 equiv_rate = 510000;
+    equiv_rate = 510000;
     if (celt_bitrate != -1) equiv_rate = celt_bitrate - (40 * C + 20) * ((400 >> LM) - 50);
     if (vbr_rate > 0 && constrained_vbr) {
         i32 vbr_bound = vbr_rate;
@@ -212,13 +314,13 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
             ec_enc_shrink(enc, (u32)nbCompressedBytes);
         }
     }
-    i32 total_bits = nbCompressedBytes * 8;
+    total_bits = nbCompressedBytes * 8;
 
     // 2. silence
     i32 sample_max = imax(fc.overlap_max, maxabs_pcm(F, C, 0, N - OVL));
     fc.overlap_max = maxabs_pcm(F, C, N - OVL, N);
     sample_max = imax(sample_max, fc.overlap_max);
-    int silence = sample_max == 0;
+    silence = sample_max == 0;
     if (tell == 1) ec_enc_bit_logp(enc, silence, 15);
     else silence = 0;
     if (silence) {
@@ -240,8 +342,6 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
 
     CA_STAMP(2);
     // 4. pitch pre-filter
-    int pitch_index, pf_on, prefilter_tapset;
-    i32 gain1;
     {
         const int enabled = (nbAvailableBytes > 12 * C) && !silence && cfg.complexity >= 5;
         prefilter_tapset = fc.tapset_decision;
@@ -283,11 +383,39 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
     CA_TRACE("prefilter done pitch=%d gain=%d pf_on=%d", pitch_index, gain1, pf_on); CA_TRACE("");
     CA_TAP("in_filtered", F.in, sizeof(F.in));
     CA_STAMP(3);
+    if constexpr (PHASE == 1) {
+        for (int c = 0; c < C; c++)
+            for (int i = lane(); i < N + OVL; i += LANES) in_ws[c * (N + OVL) + i] = F.in[c][i];
+        MidScalars m;
+        m.max_data_bytes = max_data_bytes; m.nbCompressedBytes = nbCompressedBytes; m.nbAvailableBytes = nbAvailableBytes;
+        m.effectiveBytes = effectiveBytes; m.vbr_rate = vbr_rate; m.equiv_rate = equiv_rate; m.total_bits = total_bits;
+        m.silence = silence; m.pitch_index = pitch_index; m.pf_on = pf_on; m.prefilter_tapset = prefilter_tapset; m.gain1 = gain1;
+        m.isTransient = m.shortBlocks = m.tf_chan = m.transient_got_disabled = 0;
+        m.tf_estimate = m.temporal_vbr = 0;
+        mid_store(F, mid, enc, fc, m);
+        return;
+    }
+  } else {
+    MidScalars m;
+    mid_load(F, mid, enc, fc, m, C);
+    max_data_bytes = m.max_data_bytes; nbCompressedBytes = m.nbCompressedBytes; nbAvailableBytes = m.nbAvailableBytes;
+    effectiveBytes = m.effectiveBytes; vbr_rate = m.vbr_rate; equiv_rate = m.equiv_rate; total_bits = m.total_bits;
+    silence = m.silence; pitch_index = m.pitch_index; pf_on = m.pf_on; prefilter_tapset = m.prefilter_tapset; gain1 = m.gain1;
+    for (int c = 0; c < C; c++)
+        for (int i = lane(); i < N + OVL; i += LANES) F.in[c][i] = in_ws[c * (N + OVL) + i];
+    wave_sync();
+  }
     // 5. transient analysis
     int isTransient = 0, shortBlocks = 0, tf_chan = 0, transient_got_disabled = 0;
     i32 tf_estimate = 0;
     if (cfg.complexity >= 1) {
-        TransientOut to = transient_analysis_wave(F, fc);
+        TransientOut to;
+        if constexpr (PHASE == 2) {
+            i32 um[2] = {uni(mid->trans_unmask[0]), uni(mid->trans_unmask[1])};
+            to = transient_combine(um, C);
+        } else {
+            to = transient_analysis_wave(F, fc);
+        }
         isTransient = to.is_transient;
         tf_estimate = to.tf_estimate;
         tf_chan = to.tf_chan;
@@ -381,40 +509,21 @@ CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opus
     {
         const i16 *X = frame_X(F);
         for (int k = lane(); k < 2 * FRAME; k += LANES) mid->X[k] = X[k];
-        for (int k = lane(); k < 2 * NB; k += LANES) {
-            mid->bandE[k] = F.bandE[k];
-            mid->bandLogE[k] = F.bandLogE[k];
-            mid->bandLogE2[k] = F.bandLogE2[k];
-            mid->oldBandE[k] = F.oldBandE[k];
-            mid->oldLogE[k] = F.oldLogE[k];
-            mid->oldLogE2[k] = F.oldLogE2[k];
-        }
-        for (int k = lane(); k < 32; k += LANES) mid->packet_head[k] = F.packet[1 + k];
-        if (lane() == 0) {
-            mid->ec_storage = enc.storage; mid->ec_end_offs = enc.end_offs; mid->ec_end_window = enc.end_window;
-            mid->ec_offs = enc.offs; mid->ec_rng = enc.rng; mid->ec_val = enc.val; mid->ec_ext = enc.ext;
-            mid->ec_nend_bits = enc.nend_bits; mid->ec_nbits_total = enc.nbits_total; mid->ec_rem = enc.rem;
-            mid->ec_error = (enc.offs > 32 || enc.end_offs > 0) ? -1 : enc.error;
-            mid->max_data_bytes = max_data_bytes; mid->nbCompressedBytes = nbCompressedBytes;
-            mid->nbAvailableBytes = nbAvailableBytes; mid->vbr_rate = vbr_rate; mid->effectiveBytes = effectiveBytes;
-            mid->equiv_rate = equiv_rate; mid->total_bits = total_bits;
-            mid->silence = silence; mid->pitch_index = pitch_index; mid->gain1 = gain1; mid->pf_on = pf_on;
-            mid->prefilter_tapset = prefilter_tapset;
-            mid->isTransient = isTransient; mid->shortBlocks = shortBlocks; mid->tf_chan = tf_chan;
-            mid->tf_estimate = tf_estimate; mid->transient_got_disabled = transient_got_disabled;
-            mid->temporal_vbr = temporal_vbr;
-            for (int k = 0; k < 4; k++) mid->hp_mem[k] = fc.hp_mem[k];
-            mid->rng = fc.rng; mid->spread_decision = fc.spread_decision; mid->delayedIntra = fc.delayedIntra;
-            mid->tonal_average = fc.tonal_average; mid->lastCodedBands = fc.lastCodedBands; mid->hf_average = fc.hf_average;
-            mid->tapset_decision = fc.tapset_decision; mid->prefilter_period = fc.prefilter_period;
-            mid->prefilter_gain = fc.prefilter_gain; mid->prefilter_tapset_state = fc.prefilter_tapset;
-            mid->consec_transient = fc.consec_transient;
-            mid->preemph_memE[0] = fc.preemph_memE[0]; mid->preemph_memE[1] = fc.preemph_memE[1];
-            mid->vbr_reservoir = fc.vbr_reservoir; mid->vbr_drift = fc.vbr_drift; mid->vbr_offset = fc.vbr_offset;
-            mid->vbr_count = fc.vbr_count; mid->overlap_max = fc.overlap_max; mid->stereo_saving = fc.stereo_saving;
-            mid->intensity = fc.intensity; mid->spec_avg = fc.spec_avg;
-        }
+        MidScalars m;
+        m.max_data_bytes = max_data_bytes; m.nbCompressedBytes = nbCompressedBytes; m.nbAvailableBytes = nbAvailableBytes;
+        m.effectiveBytes = effectiveBytes; m.vbr_rate = vbr_rate; m.equiv_rate = equiv_rate; m.total_bits = total_bits;
+        m.silence = silence; m.pitch_index = pitch_index; m.pf_on = pf_on; m.prefilter_tapset = prefilter_tapset; m.gain1 = gain1;
+        m.isTransient = isTransient; m.shortBlocks = shortBlocks; m.tf_chan = tf_chan;
+        m.transient_got_disabled = transient_got_disabled; m.tf_estimate = tf_estimate; m.temporal_vbr = temporal_vbr;
+        mid_store(F, mid, enc, fc, m);
     }
+}
+
+template <class L>
+CA_DEVFN void celt_encode_front(L &F, const opusgpu_celt_config &cfg, const opusgpu_celt_state *st_in,
+                                opusgpu_celt_state *st_out, const i16 *pcm, FrameMid *mid, StageClock *stage_clock = nullptr)
+{
+    celt_encode_front_phase<0>(F, cfg, st_in, st_out, pcm, mid, stage_clock, nullptr);
 }
 
 // Phase 2: FrameMid -> packet (steps 11-19). out: packet bytes (global, >= max packet size).

@@ -535,10 +535,14 @@ CA_DEVFN PrefilterOut run_prefilter_wave(L &F, FrameCtx &fc, const i32 *in_mem, 
     int pitch_index;
     i32 gain1;
     if (enabled) {
+        CA_STAMP_F(F, 3);
         pitch_downsample_wave(F, fc);
+        CA_STAMP_F(F, 23);
         pitch_index = pitch_search_wave(F);
+        CA_STAMP_F(F, 24);
         pitch_index = MAXP - pitch_index;
         gain1 = remove_doubling_wave(F, &pitch_index, fc.prefilter_period, fc.prefilter_gain);
+        CA_STAMP_F(F, 25);
         if (pitch_index > MAXP - 2) pitch_index = MAXP - 2;
         gain1 = (i16)mul16_16_q15(22938, gain1);                                    // QCONST16(.7f,15)
         if (loss_rate > 2) gain1 = (i16)(gain1 >> 1);
@@ -588,6 +592,20 @@ CA_DEVFN PrefilterOut run_prefilter_wave(L &F, FrameCtx &fc, const i32 *in_mem, 
 // ---- transient_analysis (celt_encoder.c:227-377), len = 1080 ---------------------------------------
 struct TransientOut { int is_transient, tf_chan; i32 tf_estimate; };
 
+// channel with the largest masking metric decides (celt_encoder.c:352-375)
+CA_DEV TransientOut transient_combine(const i32 *unmask, int C)
+{
+    TransientOut o;
+    o.tf_chan = 0;
+    i32 mask_metric = 0;
+    for (int c = 0; c < C; c++)
+        if (unmask[c] > mask_metric) { o.tf_chan = c; mask_metric = unmask[c]; }
+    o.is_transient = mask_metric > 200;
+    i32 tf_max = imax(0, (i16)(celt_sqrt(27 * mask_metric) - 42));
+    o.tf_estimate = (i16)celt_sqrt(imax(0, sub32(shl32(mul16_16(113, imin(163, tf_max)), 14), 37312528)));   // .0069 Q14, .139 Q28
+    return o;
+}
+
 template <class L>
 CA_DEVFN TransientOut transient_analysis_wave(L &F, const FrameCtx &fc)
 {
@@ -629,9 +647,7 @@ CA_DEVFN TransientOut transient_analysis_wave(L &F, const FrameCtx &fc)
         F.scal[4 + c] = norm;
     }
     wave_sync();
-    TransientOut o;
-    o.tf_chan = 0;
-    i32 mask_metric = 0;
+    i32 um[2] = {0, 0};
     for (int c = 0; c < C; c++) {
         const i16 *tmp = F.s.trans[c];
         i32 norm = F.scal[4 + c];
@@ -642,14 +658,10 @@ CA_DEVFN TransientOut transient_analysis_wave(L &F, const FrameCtx &fc)
             p += CLT_inv_table[id];
         }
         i32 unmask = wave_add(p);
-        unmask = 64 * unmask * 4 / (6 * (len2 - 17));
-        if (unmask > mask_metric) { o.tf_chan = c; mask_metric = unmask; }
+        um[c] = 64 * unmask * 4 / (6 * (len2 - 17));
     }
-    o.is_transient = mask_metric > 200;
-    i32 tf_max = imax(0, (i16)(celt_sqrt(27 * mask_metric) - 42));
-    o.tf_estimate = (i16)celt_sqrt(imax(0, sub32(shl32(mul16_16(113, imin(163, tf_max)), 14), 37312528)));   // .0069 Q14, .139 Q28
     wave_sync();
-    return o;
+    return transient_combine(um, C);
 }
 
 // ---- MDCTs of one frame (compute_mdcts, celt_encoder.c:418-461): in -> xf (as freq) ------------------

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include "celt_enc.h"
 #include "opusgpu_internal.h"
+extern "C" void opusgpu_launch_dc_reject(const void *states, const int16_t *pcm, void *mid, int n, hipStream_t s);
+extern "C" void opusgpu_launch_transient(void *mid, const int32_t *in_ws, int n, hipStream_t s);
 extern "C" void opusgpu_launch_back_lane(const opusgpu_celt_config *cfg, void *states, const void *mid, unsigned char *out,
                                          int out_stride, int32_t *out_len, uint32_t *out_rng, int n, hipStream_t s);
 
@@ -27,6 +29,29 @@ __global__ __launch_bounds__(64, 2) void celt_front_kernel(opusgpu_celt_config c
     for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
         opusgpu_celt_state *st = states ? states + n : nullptr;
         celt_encode_front(F, cfg, st, st, pcm + (size_t)n * FRAME * cfg.channels, mid + n);
+        wave_sync();
+    }
+}
+
+// Split front phase (default pipeline): phase 1 = rate bookkeeping .. pitch pre-filter, phase 2 = MDCT ..
+// normalisation; the serial dc_reject and transient stages run in celt_stage_kernels.hip in between.
+__global__ __launch_bounds__(64, 2) void celt_front1_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+                                                            FrameMid *__restrict__ mid, i32 *__restrict__ in_ws, int nframes)
+{
+    __shared__ FrontLds F;
+    for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
+        opusgpu_celt_state *st = states ? states + n : nullptr;
+        celt_encode_front_phase<1>(F, cfg, st, st, nullptr, mid + n, nullptr, in_ws + (size_t)n * 2 * (FRAME + OVL));
+        wave_sync();
+    }
+}
+
+__global__ __launch_bounds__(64, 2) void celt_front2_kernel(opusgpu_celt_config cfg, FrameMid *__restrict__ mid,
+                                                            i32 *__restrict__ in_ws, int nframes)
+{
+    __shared__ FrontLds F;
+    for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
+        celt_encode_front_phase<2>(F, cfg, nullptr, nullptr, nullptr, mid + n, nullptr, in_ws + (size_t)n * 2 * (FRAME + OVL));
         wave_sync();
     }
 }
@@ -98,9 +123,13 @@ extern "C" int opusgpu_celt_state_init(void *d_states, int n_streams, void *stre
     return opusgpu_check_launch();
 }
 
+// per frame in flight: the FrameMid record + the [2][1080] int32 time signal handed from front phase 1 to 2
+static const size_t WS_IN_BYTES = 2 * (FRAME + OVL) * sizeof(i32);
+static const size_t WS_FRAME_BYTES = sizeof(FrameMid) + WS_IN_BYTES;
+
 extern "C" size_t opusgpu_encode_workspace_bytes(int n_frames)
 {
-    return n_frames <= 0 ? 0 : (size_t)n_frames * sizeof(FrameMid);
+    return n_frames <= 0 ? 0 : (size_t)n_frames * WS_FRAME_BYTES;
 }
 
 extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const int16_t *d_pcm,
@@ -114,11 +143,12 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
     if (!d_pcm || !d_out || !d_out_len || !d_out_rng || !d_workspace) return OPUSGPU_BAD_ARG;
     int maxbytes = cfg->max_data_bytes < 1276 ? cfg->max_data_bytes : 1276;
     if (out_stride < ((maxbytes + 3) & ~3) || (out_stride & 3)) return OPUSGPU_BUFFER_TOO_SMALL;
-    size_t chunk = workspace_bytes / sizeof(FrameMid);
+    size_t chunk = workspace_bytes / WS_FRAME_BYTES;
     if (chunk == 0) return OPUSGPU_BUFFER_TOO_SMALL;
     const int cus = opusgpu_num_cus();
     opusgpu_celt_state *st = (opusgpu_celt_state *)d_states;
     FrameMid *mid = (FrameMid *)d_workspace;
+    i32 *in_ws = (i32 *)((char *)d_workspace + chunk * sizeof(FrameMid));
     hipStream_t s = (hipStream_t)stream;
     for (size_t first = 0; first < (size_t)n_frames; first += chunk) {
         int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
@@ -127,10 +157,28 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
         // default: one lane per frame for the serial back phase; OPUSGPU_BACK_WAVE=1 selects the
         // one-wave-per-frame kernel (kept for the stage-stamp diagnostics and as a cross-check)
         const bool lane_back = getenv("OPUSGPU_BACK_WAVE") == nullptr;
-        int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT, s);
-        hipLaunchKernelGGL(celt_front_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr,
-                           d_pcm + first * FRAME * cfg->channels, mid, n);
-        opusgpu_timing_end(slot, s);
+        // OPUSGPU_FRONT_FUSED=1: the whole front phase in one wave-per-frame kernel (cross-check / diagnostics)
+        const bool fused_front = getenv("OPUSGPU_FRONT_FUSED") != nullptr;
+        int slot;
+        if (fused_front) {
+            slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT, s);
+            hipLaunchKernelGGL(celt_front_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr,
+                               d_pcm + first * FRAME * cfg->channels, mid, n);
+            opusgpu_timing_end(slot, s);
+        } else {
+            slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_DC_REJECT, s);
+            opusgpu_launch_dc_reject(st ? st + first : nullptr, d_pcm + first * FRAME * cfg->channels, mid, n, s);
+            opusgpu_timing_end(slot, s);
+            slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT1, s);
+            hipLaunchKernelGGL(celt_front1_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid, in_ws, n);
+            opusgpu_timing_end(slot, s);
+            slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_TRANSIENT, s);
+            opusgpu_launch_transient(mid, in_ws, n, s);
+            opusgpu_timing_end(slot, s);
+            slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT2, s);
+            hipLaunchKernelGGL(celt_front2_kernel, dim3(g1), dim3(64), 0, s, *cfg, mid, in_ws, n);
+            opusgpu_timing_end(slot, s);
+        }
         slot = opusgpu_timing_begin(lane_back ? OPUSGPU_KERNEL_CELT_BACK_LANE : OPUSGPU_KERNEL_CELT_BACK, s);
         if (lane_back)
             opusgpu_launch_back_lane(cfg, st ? st + first : nullptr, mid, d_out + first * (size_t)out_stride, out_stride,

@@ -7,7 +7,7 @@
 
 namespace ca {
 
-enum { NSTAGES = 24 };
+enum { NSTAGES = 32 };
 
 __global__ __launch_bounds__(64, 2) void celt_front_diag_kernel(opusgpu_celt_config cfg, const i16 *__restrict__ pcm,
                                                                 FrameMid *__restrict__ mid, int nframes, unsigned long long *stamps)
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64, 4) void celt_back_diag_kernel(opusgpu_celt_conf
 
 using namespace ca;
 
-// d_stamps: device, zero-initialised u64 [4096][24]; independent frames only; n_frames <= workspace capacity
+// d_stamps: device, zero-initialised u64 [4096][32]; independent frames only; n_frames <= workspace capacity
 extern "C" int opusgpu_encode_batch_diag(const opusgpu_celt_config *cfg, const int16_t *d_pcm, unsigned char *d_out,
                                          int out_stride, int32_t *d_out_len, uint32_t *d_out_rng, int n_frames,
                                          void *d_workspace, size_t workspace_bytes, unsigned long long *d_stamps, void *stream)

@@ -56,6 +56,7 @@ def _check_pcm(pcm, channels):
 
 
 _WORKSPACE = {}
+MID_RECORD_BYTES = 4704         # sizeof(FrameMid) in csrc/celt_enc.h (hand-off record per frame)
 WORKSPACE_FRAMES = int(os.environ.get("CONCENTUS_WS_FRAMES", 262144))      # hand-off records kept in HBM at once (larger batches are chunked by the library)
 
 

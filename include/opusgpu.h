@@ -48,7 +48,11 @@ int opusgpu_num_cus(void);
 #define OPUSGPU_KERNEL_CELT_FRONT 0
 #define OPUSGPU_KERNEL_CELT_BACK  1
 #define OPUSGPU_KERNEL_CELT_BACK_LANE 2
-#define OPUSGPU_KERNEL_COUNT      3
+#define OPUSGPU_KERNEL_CELT_DC_REJECT 3
+#define OPUSGPU_KERNEL_CELT_FRONT1    4
+#define OPUSGPU_KERNEL_CELT_TRANSIENT 5
+#define OPUSGPU_KERNEL_CELT_FRONT2    6
+#define OPUSGPU_KERNEL_COUNT      7
 int opusgpu_kernel_timing_enable(int on);
 int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_kernels);
 
@@ -129,7 +133,7 @@ int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const i
                          int n_frames, void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
 /* Diagnostic only (never used for reported throughput): the same kernels with in-kernel stage stamps;
- * d_stamps = zero-initialised uint64 [4096][24] cycle totals per stage and workgroup. */
+ * d_stamps = zero-initialised uint64 [4096][32] cycle totals per stage and workgroup. */
 int opusgpu_encode_batch_diag(const opusgpu_celt_config *cfg, const int16_t *d_pcm, unsigned char *d_out,
                               int out_stride, int32_t *d_out_len, uint32_t *d_out_rng, int n_frames,
                               void *d_workspace, size_t workspace_bytes, unsigned long long *d_stamps, void *hip_stream);

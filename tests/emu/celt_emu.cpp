@@ -21,6 +21,7 @@ extern "C" int emu_tap_get(const char *name, void *out, int cap)
     return n;
 }
 #include "../../concentus_amd/csrc/celt_enc.h"
+#include "../../concentus_amd/csrc/celt_stage_lane.h"
 
 using namespace ca;
 
@@ -67,6 +68,42 @@ extern "C" int emu_celt_encode_frames(const opusgpu_celt_config *cfg, opusgpu_ce
     free(F1);
     free(F2);
     free(mid);
+    return 0;
+}
+
+// The split pipeline of the GPU library on the CPU: dc_reject stage -> front phase 1 -> transient stage ->
+// front phase 2 -> back phase, with the same hand-off buffers.
+extern "C" int emu_celt_encode_frames_split(const opusgpu_celt_config *cfg, opusgpu_celt_state *states /* or NULL */,
+                                            const int16_t *pcm, int nframes, int frames_per_stream,
+                                            unsigned char *out, int out_stride, int *out_len, uint32_t *out_rng)
+{
+    FrontLds *F1 = (FrontLds *)aligned_alloc(64, sizeof(FrontLds) + 64);
+    BackLds *F2 = (BackLds *)aligned_alloc(64, sizeof(BackLds) + 64);
+    FrameMid *mid = (FrameMid *)aligned_alloc(64, sizeof(FrameMid) + 64);
+    int32_t *in_ws = (int32_t *)aligned_alloc(64, 2 * 1080 * 4);
+    const int C = cfg->channels;
+    for (int n = 0; n < nframes; n++) {
+        memset(F1, 0xAB, sizeof(FrontLds));
+        memset(F2, 0xAB, sizeof(BackLds));
+        memset(mid, 0xCD, sizeof(FrameMid));
+        memset(in_ws, 0xEF, 2 * 1080 * 4);
+        opusgpu_celt_state *st = states ? &states[n / frames_per_stream] : NULL;
+        const int16_t *p = pcm + (size_t)n * 960 * C;
+        for (int c = 0; c < C; c++) {
+            i32 hp[2] = {st ? st->hp_mem[2 * c] : 0, st ? st->hp_mem[2 * c + 1] : 0};
+            stage_dc_reject_channel(p, c, hp, mid->X + c * 960);
+            mid->hp_mem[2 * c] = hp[0];
+            mid->hp_mem[2 * c + 1] = hp[1];
+        }
+        celt_encode_front_phase<1>(*F1, *cfg, st, st, p, mid, nullptr, in_ws);
+        for (int c = 0; c < C; c++) mid->trans_unmask[c] = stage_transient_channel(in_ws + c * 1080, mid->X + c * 960);
+        memset(F1, 0xAB, sizeof(FrontLds));
+        celt_encode_front_phase<2>(*F1, *cfg, nullptr, nullptr, nullptr, mid, nullptr, in_ws);
+        FrameResult r = celt_encode_back(*F2, *cfg, mid, st, out + (size_t)n * out_stride);
+        out_len[n] = r.bytes;
+        out_rng[n] = r.final_range;
+    }
+    free(F1); free(F2); free(mid); free(in_ws);
     return 0;
 }
 

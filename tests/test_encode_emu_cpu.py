@@ -11,7 +11,7 @@ import emulib
 import encode_cases as ec
 
 
-def _run_emu(pcm, fps, cfgvals):
+def _run_emu(pcm, fps, cfgvals, split=False):
     emu = emulib.lib()
     br, vbr, cvbr, cx = cfgvals
     cfg = emulib.Config(2, br, vbr, cvbr, cx, 16, 0, 1500)
@@ -21,11 +21,12 @@ def _run_emu(pcm, fps, cfgvals):
     rng = np.zeros(n, np.uint32)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     pcm = np.ascontiguousarray(pcm)
+    fn = emu.emu_celt_encode_frames_split if split else emu.emu_celt_encode_frames
     if fps == 1:
-        emu.emu_celt_encode_frames(C.byref(cfg), None, p(pcm), n, 1, p(out), 1280, p(lens), p(rng))
+        fn(C.byref(cfg), None, p(pcm), n, 1, p(out), 1280, p(lens), p(rng))
     else:
         st = emulib.fresh_states(n // fps)
-        emu.emu_celt_encode_frames(C.byref(cfg), p(st), p(pcm), n, fps, p(out), 1280, p(lens), p(rng))
+        fn(C.byref(cfg), p(st), p(pcm), n, fps, p(out), 1280, p(lens), p(rng))
     return out, lens, rng
 
 
@@ -34,6 +35,15 @@ def test_emulated_kernel_matches_golden_packets(case):
     name, _kind, _n, fps, _seed, cfgvals = case
     pcm, pk, ln, rg = ec.load_case(name)
     out, lens, rng = _run_emu(pcm, fps, cfgvals)
+    ec.assert_packets_equal(out, lens, rng, pk, ln, rg, name)
+
+
+@pytest.mark.parametrize("case", ec.cases(), ids=lambda c: c[0])
+def test_emulated_split_pipeline_matches_golden_packets(case):
+    """dc_reject stage -> front phase 1 -> transient stage -> front phase 2 -> back phase, as the GPU library runs them"""
+    name, _kind, _n, fps, _seed, cfgvals = case
+    pcm, pk, ln, rg = ec.load_case(name)
+    out, lens, rng = _run_emu(pcm, fps, cfgvals, split=True)
     ec.assert_packets_equal(out, lens, rng, pk, ln, rg, name)
 
 

@@ -14,8 +14,9 @@ import concentus_amd as ca
 NAMES = ["load+dc_reject+rate", "silence", "preemph", "prefilter(pitch)", "transient", "mdct+energies+patch", "normalise",
          "tf_analysis", "coarse_energy", "tf_enc+spread+dynalloc+trim", "vbr", "allocation", "fine_energy", "PVQ",
          "finalise", "done+store",
-         "pvq:theta", "pvq:exp_rotation", "pvq:presearch", "pvq:greedy", "pvq:encode_pulses", "pvq:band_setup", "pvq:other", "-"]
-NS = 24
+         "pvq:theta", "pvq:exp_rotation", "pvq:presearch", "pvq:greedy", "pvq:encode_pulses", "pvq:band_setup", "pvq:other",
+         "pitch:downsample", "pitch:search", "pitch:remove_doubling", "-", "-", "-", "-", "-", "-"]
+NS = 32
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 kind = sys.argv[2] if len(sys.argv) > 2 else "noise"
