@@ -561,14 +561,20 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     const i32 tf_estimate = uni(mid->tf_estimate), temporal_vbr = uni(mid->temporal_vbr);
     const int transient_got_disabled = uni(mid->transient_got_disabled);
     RangeEnc enc;
+#if defined(CA_LANE_FRAME)
+    F.x16 = const_cast<i16 *>(mid->X);
+    F.packet = out;
+#endif
     enc.buf = F.packet + 1;
     enc.storage = uni(mid->ec_storage); enc.end_offs = uni(mid->ec_end_offs); enc.end_window = uni(mid->ec_end_window);
     enc.offs = uni(mid->ec_offs); enc.rng = uni(mid->ec_rng); enc.val = uni(mid->ec_val); enc.ext = uni(mid->ec_ext);
     enc.nend_bits = uni(mid->ec_nend_bits); enc.nbits_total = uni(mid->ec_nbits_total); enc.rem = uni(mid->ec_rem);
     enc.error = uni(mid->ec_error);
     {
+#if !defined(CA_LANE_FRAME)
         i16 *X = frame_X(F);
         for (int k = lane(); k < 2 * FRAME; k += LANES) X[k] = mid->X[k];
+#endif
         for (int k = lane(); k < 2 * NB; k += LANES) {
             F.bandE[k] = mid->bandE[k];
             F.bandLogE[k] = mid->bandLogE[k];
@@ -766,11 +772,13 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     if (lane() == 0)
         for (int k = ret; k < ((ret + 3) & ~3); k++) F.packet[k] = 0;               // deterministic pad bytes
     wave_sync();
+#if !defined(CA_LANE_FRAME)
     {   // packet -> HBM (word-wise; the slab stride is a multiple of 4)
         const u32 *src = reinterpret_cast<const u32 *>(F.packet);
         u32 *dst = reinterpret_cast<u32 *>(out);
         for (int k = lane(); k < (ret + 3) / 4; k += LANES) dst[k] = src[k];
     }
+#endif
     CA_STAMP(15);
     FrameResult r;
     r.bytes = enc.error ? -3 : ret;                                                  // OPUS_INTERNAL_ERROR

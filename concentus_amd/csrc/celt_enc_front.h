@@ -63,12 +63,21 @@ struct __attribute__((aligned(16))) FrontLds {
 };
 
 struct __attribute__((aligned(16))) BackLds {
+#if defined(CA_LANE_FRAME)
+    // lane-per-frame build: the working set is private memory, so the two big sequentially walked arrays
+    // stay where they already are in HBM (per-lane sequential access is what the L1/L2 lines are good at)
+    i16 *x16;                      // -> FrameMid::X of this frame (transformed in place)
+    u8 *packet;                    // -> the output slab of this frame
+#else
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
+#endif
     union {
         struct { i16 tmp[176]; i16 tmp1[176]; } tf;
         struct { i16 y[176]; i32 iy[176]; i16 xabs[176]; } pvq;
     } s;
+#if !defined(CA_LANE_FRAME)
     u8 packet[1280];
+#endif
     i32 bandE[2 * NB];
     i16 bandLogE[2 * NB], bandLogE2[2 * NB], error[2 * NB];
     i16 oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];

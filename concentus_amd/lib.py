@@ -29,6 +29,7 @@ SYMBOLS = [
     ("opusgpu_silk_burg_modified_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_nsq_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_silk_nsq_batch", _i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
+    ("opusgpu_back_lane_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
 

@@ -137,6 +137,14 @@ int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const i
 int opusgpu_encode_batch_diag(const opusgpu_celt_config *cfg, const int16_t *d_pcm, unsigned char *d_out,
                               int out_stride, int32_t *d_out_len, uint32_t *d_out_rng, int n_frames,
                               void *d_workspace, size_t workspace_bytes, unsigned long long *d_stamps, void *hip_stream);
+/* Diagnostic: the back phase alone, one lane per frame, with per-stage cycle stamps of each wavefront.
+ * Consumes the FrameMid records a preceding opusgpu_encode_batch_diag(same n_frames) left in d_workspace
+ * (the records are transformed in place: run it once per encode). d_stamps as above, one row
+ * per wavefront of 64 frames. */
+int opusgpu_back_lane_diag(const opusgpu_celt_config *cfg, void *d_workspace, unsigned char *d_out, int out_stride,
+                           int32_t *d_out_len, uint32_t *d_out_rng, int n_frames, unsigned long long *d_stamps,
+                           void *stream);
+
 
 #ifdef __cplusplus
 }

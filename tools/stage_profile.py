@@ -45,4 +45,16 @@ per_frame = tot / n
 res = {NAMES[k]: round(per_frame[k]) for k in range(NS)}
 res["_total_cycles_per_frame"] = round(per_frame.sum())
 print(json.dumps(res, indent=1))
+if len(sys.argv) > 3 and sys.argv[3] == "lane":
+    # the back phase again, one lane per frame, on the same FrameMid records: cycles per wavefront (64 frames)
+    st2 = torch.zeros((4096, NS), dtype=torch.int64, device="cuda")
+    g = L.opusgpu_back_lane_diag(C.byref(cfg), ws.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
+                                 st2.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert g == 0, g
+    waves = (n + 63) // 64
+    per_wave = st2[:min(waves, 4096)].sum(0).cpu().numpy().astype(np.float64) / min(waves, 4096)
+    print("lane-per-frame back phase, cycles per wavefront:")
+    print(json.dumps({NAMES[k]: round(per_wave[k]) for k in range(NS) if per_wave[k] > 0}, indent=1))
+    print("total", round(per_wave.sum()), "shares %:", {NAMES[k]: round(100 * per_wave[k] / per_wave.sum(), 1) for k in range(NS) if per_wave[k] > 0})
 print("shares %:", {NAMES[k]: round(100 * per_frame[k] / per_frame.sum(), 1) for k in range(NS)})
