@@ -75,6 +75,7 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
             total -= dual_stereo_rsv;
         }
     }
+    CA_UNROLL_LANE
     for (int j = lane(); j < end; j += LANES) {
         int w = eB[j + 1] - eB[j];
         F.thresh[j] = imax(C << BITRES, ((3 * w) << LM << BITRES) >> 4);
@@ -284,6 +285,7 @@ struct BandCtx {                 // uniform; cf. struct band_ctx (bands.c:623-63
 CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c, i32 s)
 {
     const i32 ms = (i16)neg32(s);
+    CA_UNROLL_LANE
     for (int ch = lane(); ch < nblocks * stride; ch += LANES) {
         i16 *x = X + (ch / stride) * len;
         const int r = ch % stride;
@@ -348,6 +350,7 @@ CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
     }
     wave_sync();
     u32 p = 0;
+    CA_UNROLL_LANE
     for (int j = lane(); j < N - 1; j += LANES) {
         p += pvq_u(N - j, suf[j + 1]);
         if (y[j] < 0) p += pvq_u(N - j, suf[j] + 1);
@@ -396,6 +399,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
     CA_COUNT(N <= 16 ? "leaf.N<=16" : N <= 32 ? "leaf.N<=32" : N <= 64 ? "leaf.N<=64" : "leaf.N>64", N);
     exp_rotation_wave(X, N, B, K, spread);
     CA_STAMP_F(F, 17);
+    CA_UNROLL_LANE
     for (int j = lane(); j < N; j += LANES) {
         i32 v = X[j];
         xa[j] = (i16)(v > 0 ? v : -v);
@@ -407,15 +411,18 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
     int pulsesLeft = K;
     if (K > (N >> 1)) {
         i32 p = 0;
+        CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) p += xa[j];
         i32 sum = wave_add(p);
         if (sum <= K) {
+            CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES) xa[j] = j == 0 ? 16384 : 0;
             sum = 16384;
             wave_sync();
         }
         i32 rcp = (i16)mul16_32_q16((i16)(K - 1), celt_rcp(sum));
         i32 pyy = 0, pxy = 0, ppl = 0;
+        CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) {
             i32 q = mul16_16_q15(xa[j], rcp);
             iy[j] = q;
@@ -447,6 +454,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
         yy = (i16)add32(yy, 1);
         i32 best_num = -32767, best_den = 0;
         int best_id = 0;
+        CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) {
             i32 Rxy = (i16)(add32(xy, xa[j]) >> rshift);
             i32 Ryy = add16(yy, y[j]);
@@ -461,6 +469,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
         wave_sync();
     }
     CA_STAMP_F(F, 19);
+    CA_UNROLL_LANE
     for (int j = lane(); j < N; j += LANES)
         if (X[j] <= 0) iy[j] = -iy[j];                                            // signx[j] < 0  <=>  X[j] <= 0
     wave_sync();
@@ -472,12 +481,14 @@ CA_DEV int stereo_itheta_wave(const i16 *X, const i16 *Y, int stereo, int N)    
 {
     i32 pm = 0, ps = 0;
     if (stereo) {
+        CA_UNROLL_LANE
         for (int i = lane(); i < N; i += LANES) {
             i32 m = add16(X[i] >> 1, Y[i] >> 1), s = (i16)sub16(X[i] >> 1, Y[i] >> 1);
             pm = mac16_16(pm, m, m);
             ps = mac16_16(ps, s, s);
         }
     } else {
+        CA_UNROLL_LANE
         for (int i = lane(); i < N; i += LANES) { pm = mac16_16(pm, X[i], X[i]); ps = mac16_16(ps, Y[i], Y[i]); }
     }
     i32 Emid = add32(1, wave_add(pm)), Eside = add32(1, wave_add(ps));
@@ -539,9 +550,11 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
                 i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
                 i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
                 i32 a1 = (i16)(shl32(left, 14) / norm), a2 = (i16)(shl32(right, 14) / norm);
+                CA_UNROLL_LANE
                 for (int j = lane(); j < N; j += LANES)
                     X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
             } else {
+                CA_UNROLL_LANE
                 for (int j = lane(); j < N; j += LANES) {                                  // stereo_split (bands.c:362-373)
                     i32 l = mul16_16(23170, X[j]), r = mul16_16(23170, Y[j]);
                     X[j] = (i16)(add32(l, r) >> 15);
@@ -553,6 +566,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
     } else if (stereo) {
         inv = itheta > 8192;
         if (inv)
+            CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES) Y[j] = (i16)(-Y[j]);
         wave_sync();
         {
@@ -561,6 +575,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
             i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
             i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
             i32 a1 = (i16)(shl32(left, 14) / norm), a2 = (i16)(shl32(right, 14) / norm);
+            CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES)
                 X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
         }
@@ -604,9 +619,11 @@ CA_DEV void deinterleave_hadamard_wave(L &F, i16 *X, int N0, int stride, int had
     const u8 *ordery = CLT_ordery_table + stride - 2;
     for (int s = 0; s < stride; s++) {
         int d = hadamard ? ordery[s] : s;
+        CA_UNROLL_LANE
         for (int j = lane(); j < N0; j += LANES) tmp[d * N0 + j] = X[j * stride + s];
     }
     wave_sync();
+    CA_UNROLL_LANE
     for (int k = lane(); k < N; k += LANES) X[k] = tmp[k];
     wave_sync();
 }

@@ -21,6 +21,7 @@ CA_DEV int iabs(int a) { return a < 0 ? -a : a; }
 CA_DEV void haar1_wave(i16 *X, int N0, int stride)
 {
     N0 >>= 1;
+    CA_UNROLL_LANE
     for (int k = lane(); k < stride * N0; k += LANES) {
         int i = k % stride, j = k / stride;
         i32 t1 = mul16_16(23170, X[stride * 2 * j + i]);
@@ -34,6 +35,7 @@ CA_DEV void haar1_wave(i16 *X, int N0, int stride)
 CA_DEV i32 l1_metric_wave(const i16 *tmp, int N, int LM, i32 bias)              // celt_encoder.c:541-550
 {
     i32 p = 0;
+    CA_UNROLL_LANE
     for (int i = lane(); i < N; i += LANES) { i32 v = tmp[i]; p += v < 0 ? -v : v; }
     i32 L1 = wave_add(p);
     return mac16_32_q15(L1, (i16)(LM * bias), L1);
@@ -50,12 +52,14 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
     for (int i = 0; i < len; i++) {
         const int width = CLT_eband5ms[i + 1] - CLT_eband5ms[i];
         const int N = width << LM, narrow = width == 1;
+        CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) tmp[j] = X[tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j];
         wave_sync();
         i32 L1 = l1_metric_wave(tmp, N, isTransient ? LM : 0, bias);
         i32 best_L1 = L1;
         int best_level = 0;
         if (isTransient && !narrow) {
+            CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES) tmp_1[j] = tmp[j];
             wave_sync();
             haar1_wave(tmp_1, N >> LM, 1 << LM);
@@ -137,6 +141,7 @@ CA_DEVFN void tf_encode_wave(L &F, RangeEnc &enc, int isTransient, int tf_select
     else
         tf_select = 0;
     wave_sync();
+    CA_UNROLL_LANE
     for (int i = lane(); i < NB; i += LANES) F.tf_res[i] = (i32)tab[4 * isTransient + 2 * tf_select + res[i]];
     wave_sync();
 }
@@ -209,6 +214,7 @@ CA_DEVFN void quant_coarse_energy_wave(L &F, FrameCtx &fc, RangeEnc &enc, u32 bu
     i32 new_distortion;
     {   // loss_distortion (quant_bands.c:142-156)
         i32 p = 0;
+        CA_UNROLL_LANE
         for (int k = lane(); k < C * NB; k += LANES) {
             i32 d = (i16)sub16(F.bandLogE[k] >> 3, F.oldBandE[k] >> 3);
             p = mac16_16(p, d, d);
@@ -220,6 +226,7 @@ CA_DEVFN void quant_coarse_energy_wave(L &F, FrameCtx &fc, RangeEnc &enc, u32 bu
     i32 max_decay = 16384;
     max_decay = imin(max_decay, shl32(nbAvailableBytes, 7));                      // end-start > 10
     RangeEnc enc_start = enc;
+    CA_UNROLL_LANE
     for (int k = lane(); k < C * NB; k += LANES) F.oldE_intra[k] = F.oldBandE[k];
     wave_sync();
     // Two trips through ONE inlined copy of the coder loop: pass 0 = intra (when two_pass || intra),
@@ -249,11 +256,13 @@ CA_DEVFN void quant_coarse_energy_wave(L &F, FrameCtx &fc, RangeEnc &enc, u32 bu
         if (two_pass && (badness1 < badness2 || (badness1 == badness2 && (i32)ec_tell_frac(enc) + intra_bias > tell_intra))) {
             enc = enc_intra;
             for (u32 k = lane(); k < save_bytes && k < 256; k += LANES) enc.buf[nstart_bytes + k] = F.coarse_save[k];
+            CA_UNROLL_LANE
             for (int k = lane(); k < C * NB; k += LANES) { F.oldBandE[k] = F.oldE_intra[k]; F.error[k] = F.error_intra[k]; }
             if (save_bytes > 256) enc.error = -1;
             intra = 1;
         }
     } else {
+        CA_UNROLL_LANE
         for (int k = lane(); k < C * NB; k += LANES) { F.oldBandE[k] = F.oldE_intra[k]; F.error[k] = F.error_intra[k]; }
     }
     wave_sync();
@@ -275,6 +284,7 @@ CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
             if (N <= 8) continue;
             const i16 *x = X + M * CLT_eband5ms[i] + c * FRAME;
             i32 t = 0;                                                            // three 10-bit counters
+            CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES) {
                 i32 x2N = mul16_16(mul16_16_q15(x[j], x[j]), N);
                 if (x2N < 2048) t += 1;
@@ -422,6 +432,7 @@ CA_DEVFN int stereo_analysis_wave(L &F)
     const i16 *X = frame_X(F);
     i32 pLR = 0, pMS = 0;
     const int jend = CLT_eband5ms[13] << LM3;
+    CA_UNROLL_LANE
     for (int j = lane(); j < jend; j += LANES) {
         i32 Lv = X[j], R = X[FRAME + j];
         i32 Mi = add32(Lv, R), S = sub32(Lv, R);
@@ -458,6 +469,7 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
         for (int i = 0; i < 8; i++) {
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
+            CA_UNROLL_LANE
             for (int j = lane(); j < n; j += LANES) p = mac16_16(p, X[j0 + j], X[FRAME + j0 + j]);
             sum = add16(sum, (i16)(wave_add(p) >> 18));
         }
@@ -467,6 +479,7 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
         for (int i = 8; i < intensity; i++) {
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
+            CA_UNROLL_LANE
             for (int j = lane(); j < n; j += LANES) p = mac16_16(p, X[j0 + j], X[FRAME + j0 + j]);
             i32 v = (i16)(wave_add(p) >> 18);
             minXC = imin(minXC, v < 0 ? -v : v);

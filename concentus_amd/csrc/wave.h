@@ -65,6 +65,14 @@ namespace ca { struct StageClock; }
 #define CA_STAMP_F(F, k) do {} while (0)
 #endif
 
+// Lane-strided loops become plain serial loops in the lane-per-frame build; unrolling them lets the loads of
+// several iterations be in flight together (the lone wavefront of a SIMD has nothing else to hide them with).
+#if defined(CA_LANE_FRAME)
+#define CA_UNROLL_LANE _Pragma("unroll 4")
+#else
+#define CA_UNROLL_LANE
+#endif
+
 namespace ca {
 
 #if defined(CA_SINGLE_LANE)
