@@ -24,6 +24,8 @@ CA_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1
 
 CA_DEV const u8 *pulse_cache(int band, int LM) { return CLT_cache_bits50 + CLT_cache_index50[(LM + 1) * NB + band]; }
 
+CA_DEV int pulse_cache_max(int band, int LM) { const u8 *cache = pulse_cache(band, LM); return cache[cache[0]]; }
+
 CA_DEV int bits2pulses(int band, int LM, int bits)                                         // rate.h:51-77
 {
     const u8 *cache = pulse_cache(band, LM);
@@ -659,9 +661,10 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
     int sp = 0;
     int xoff = 0;
     for (;;) {
-        i16 *X = Xband + xoff;
-        const u8 *cache = pulse_cache(ctx.i, LM);
-        if (LM != -1 && b > cache[cache[0]] + 12 && N > 2) {
+        // descend: split until the current node is a leaf. Written as an inner loop so that, in the
+        // lane-per-frame build, the lanes of a wavefront split together and then code their leaves together.
+        while (LM != -1 && N > 2 && b > pulse_cache_max(ctx.i, LM) + 12) {
+            i16 *X = Xband + xoff;
             const int B0 = B;
             N >>= 1;
             i16 *Y = X + N;
@@ -694,8 +697,8 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
             wave_sync();
             if (!mid_first) xoff += N;
             b = mid_first ? mbits : sbits;
-            continue;
         }
+        i16 *X = Xband + xoff;
         // leaf: the basic no-split case (bands.c:983-1039)
         int q = bits2pulses(ctx.i, LM, b);
         CA_COUNT(q ? "node.leaf" : "node.leaf_q0", N);

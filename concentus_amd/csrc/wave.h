@@ -68,7 +68,7 @@ namespace ca { struct StageClock; }
 // Lane-strided loops become plain serial loops in the lane-per-frame build; unrolling them lets the loads of
 // several iterations be in flight together (the lone wavefront of a SIMD has nothing else to hide them with).
 #if defined(CA_LANE_FRAME)
-#define CA_UNROLL_LANE _Pragma("unroll 4")
+#define CA_UNROLL_LANE _Pragma("unroll 8")
 #else
 #define CA_UNROLL_LANE
 #endif
