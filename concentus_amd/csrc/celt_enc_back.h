@@ -296,6 +296,7 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
         if (r < len - stride) {
             i32 x1 = x[r];
             int i;
+            CA_UNROLL_LANE
             for (i = r; i < len - stride; i += stride) {
                 i32 x2 = x[i + stride];
                 i32 n2 = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
@@ -310,6 +311,7 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
         if (top >= r) {
             int i = top - ((top - r) % stride);
             i32 x2 = x[i + stride];
+            CA_UNROLL_LANE
             for (; i >= 0; i -= stride) {
                 i32 x1 = x[i];
                 x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
@@ -344,6 +346,19 @@ template <class L>
 CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
 {
     const i32 *y = F.s.pvq.iy;
+    u32 idx;
+    if (LANES == 1) {
+        // one lane owns the frame: icwrs as the reference walks it (cwrs.c:440-456), no suffix-sum array
+        int j = N - 1;
+        idx = (u32)(y[j] < 0);
+        int k = y[j] < 0 ? -y[j] : y[j];
+        do {
+            j--;
+            idx += pvq_u(N - j, k);
+            k += y[j] < 0 ? -y[j] : y[j];
+            if (y[j] < 0) idx += pvq_u(N - j, k + 1);
+        } while (j > 0);
+    } else {
     // suffix sums k_j = sum_{t>=j} |y_t| are produced serially (cheap), the table look-ups in parallel
     i16 *suf = F.s.pvq.xabs;                         // free after the search: reuse as suffix sums
     if (lane() == 0) {
@@ -357,7 +372,8 @@ CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
         p += pvq_u(N - j, suf[j + 1]);
         if (y[j] < 0) p += pvq_u(N - j, suf[j] + 1);
     }
-    u32 idx = (u32)wave_add((i32)p) + (u32)(uni(y[N - 1]) < 0);
+    idx = (u32)wave_add((i32)p) + (u32)(uni(y[N - 1]) < 0);
+    }
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
     wave_sync();
     ec_enc_uint(ec, idx, V);
