@@ -336,6 +336,67 @@ CA_DEV void find_best_pitch_uniform(const i32 *xcorr, const i16 *y, int len, int
     }
 }
 
+// find_best_pitch on the whole wave, exactly the sequential result. The running top-2 changes only at
+// "record" lags, so each block of LANES lags is tested against the current state in parallel; the first lag
+// that passes is applied, the lags after it are re-tested, and so on (a lag that fails against the state it
+// would see sequentially never updates anything). Syy is a prefix sum as long as its max(1, .) clamp never
+// triggers; that is checked first and the uniform scalar loop above is kept for the (silence-like) rest.
+CA_DEV void find_best_pitch_wave(const i32 *xcorr, const i16 *y, int len, int max_pitch, int *best_pitch,
+                                 int yshift, i32 maxcorr)
+{
+    i32 Syy0;
+    {
+        i32 p = 0;
+        for (int j = lane(); j < len; j += LANES) p = add32(p, mul16_16(y[j], y[j]) >> yshift);
+        Syy0 = add32(1, wave_add(p));
+    }
+    // pass 1: would the clamp ever trigger?
+    i32 run = Syy0, mn = Syy0;
+    for (int base = 0; base < max_pitch; base += LANES) {
+        const int i = base + lane();
+        i32 d = 0;
+        if (i < max_pitch) d = sub32(mul16_16(y[i + len], y[i + len]) >> yshift, mul16_16(y[i], y[i]) >> yshift);
+        i32 inc = wave_scan_add(d);
+        mn = imin(mn, add32(run, inc));
+        run = add32(run, wave_last(inc));
+    }
+    if (wave_min(mn) < 1) { find_best_pitch_uniform(xcorr, y, len, max_pitch, best_pitch, yshift, maxcorr); return; }
+    i32 bn0 = -1, bn1 = -1, bd0 = 0, bd1 = 0;
+    int bp0 = 0, bp1 = 1;
+    const int xshift = celt_ilog2(maxcorr) - 14;
+    run = Syy0;
+    for (int base = 0; base < max_pitch; base += LANES) {
+        const int i = base + lane();
+        i32 d = 0, xc = 0;
+        if (i < max_pitch) {
+            d = sub32(mul16_16(y[i + len], y[i + len]) >> yshift, mul16_16(y[i], y[i]) >> yshift);
+            xc = xcorr[i];
+        }
+        const i32 inc = wave_scan_add(d);
+        const i32 S = add32(run, sub32(inc, d));              // Syy as lag i sees it
+        run = add32(run, wave_last(inc));
+        const i32 x16 = (i16)vshr32(xc, xshift);
+        const i32 num = (i16)mul16_16_q15(x16, x16);
+        bool pending = xc > 0;
+        for (;;) {
+            const bool pass = pending && mul16_32_q15(num, bd1) > mul16_32_q15(bn1, S);
+            const uint64_t m = wave_ballot(pass);
+            if (m == 0) break;
+            const int l = __builtin_ctzll(m);
+            const i32 ne = lane_bcast(num, l), Se = lane_bcast(S, l);
+            if (mul16_32_q15(ne, bd0) > mul16_32_q15(bn0, Se)) {
+                bn1 = bn0; bd1 = bd0; bp1 = bp0;
+                bn0 = ne; bd0 = Se; bp0 = base + l;
+            } else {
+                bn1 = ne; bd1 = Se; bp1 = base + l;
+            }
+            pending = pending && lane() > l;
+        }
+    }
+    best_pitch[0] = bp0;
+    best_pitch[1] = bp1;
+}
+
 // pitch_search(x_lp = buf+512, y = buf, len = 960, max_pitch = 979)  (pitch.c:260-369)
 template <class L>
 CA_DEVFN int pitch_search_wave(L &F)
@@ -359,6 +420,7 @@ CA_DEVFN int pitch_search_wave(L &F)
         shift = 0;
     }
     wave_sync();
+    CA_STAMP_F(F, 26);
     // coarse search, 4x decimation: celt_pitch_xcorr(x4, y4, xcorr, 240, 244) -- one lane per lag
     i32 mc = 1;
     for (int i = lane(); i < (max_pitch >> 2); i += LANES) {
@@ -369,24 +431,28 @@ CA_DEVFN int pitch_search_wave(L &F)
     }
     i32 maxcorr = wave_max(mc);
     wave_sync();
+    CA_STAMP_F(F, 27);
     int best_pitch[2];
-    find_best_pitch_uniform(xcorr, y4, len >> 2, max_pitch >> 2, best_pitch, 0, maxcorr);
+    find_best_pitch_wave(xcorr, y4, len >> 2, max_pitch >> 2, best_pitch, 0, maxcorr);
     wave_sync();
+    CA_STAMP_F(F, 28);
     // finer search, 2x decimation: only lags within +-2 of the two candidates are evaluated
     for (int i = lane(); i < (max_pitch >> 1); i += LANES) xcorr[i] = 0;
     wave_sync();
     maxcorr = 1;
-    for (int i = 0; i < (max_pitch >> 1); i++) {
-        int d0 = i - 2 * best_pitch[0], d1 = i - 2 * best_pitch[1];
-        if ((d0 < 0 ? -d0 : d0) > 2 && (d1 < 0 ? -d1 : d1) > 2) continue;
-        i32 p = 0;
-        for (int j = lane(); j < (len >> 1); j += LANES) p = add32(p, mul16_16(x_lp[j], y[i + j]) >> shift);
-        i32 sum = wave_add(p);
-        st0(&xcorr[i], imax(-1, sum));
-        maxcorr = imax(maxcorr, sum);
+    for (int cand = 0; cand < 2; cand++) {
+        for (int i = imax(0, 2 * best_pitch[cand] - 2); i <= imin((max_pitch >> 1) - 1, 2 * best_pitch[cand] + 2); i++) {
+            if (cand == 1) { int d0 = i - 2 * best_pitch[0]; if ((d0 < 0 ? -d0 : d0) <= 2) continue; }   // done already
+            i32 p = 0;
+            for (int j = lane(); j < (len >> 1); j += LANES) p = add32(p, mul16_16(x_lp[j], y[i + j]) >> shift);
+            i32 sum = wave_add(p);
+            st0(&xcorr[i], imax(-1, sum));
+            maxcorr = imax(maxcorr, sum);
+        }
     }
     wave_sync();
-    find_best_pitch_uniform(xcorr, y, len >> 1, max_pitch >> 1, best_pitch, shift + 1, maxcorr);
+    CA_STAMP_F(F, 29);
+    find_best_pitch_wave(xcorr, y, len >> 1, max_pitch >> 1, best_pitch, shift + 1, maxcorr);
     int offset = 0;
     if (best_pitch[0] > 0 && best_pitch[0] < (max_pitch >> 1) - 1) {
         i32 a = xcorr[best_pitch[0] - 1], b = xcorr[best_pitch[0]], c = xcorr[best_pitch[0] + 1];

@@ -107,6 +107,10 @@ CA_DEV uint32_t wave_or(uint32_t v) { return v; }
 CA_DEV int64_t wave_add64(int64_t v) { return v; }
 CA_DEV int32_t uni(int32_t v) { return v; }
 CA_DEV uint32_t uni(uint32_t v) { return v; }
+CA_DEV int32_t wave_scan_add(int32_t v) { return v; }
+CA_DEV int32_t wave_last(int32_t v) { return v; }
+CA_DEV uint64_t wave_ballot(bool p) { return p ? 1u : 0u; }
+CA_DEV int32_t lane_bcast(int32_t v, int) { return v; }
 #else
 // DPP row operations instead of ds_bpermute shuffles: an inclusive scan over the 64 lanes in six VALU
 // steps (row_shr 1/2/4/8 inside each row of 16, row_bcast15 into rows 1/3, row_bcast31 into the upper
@@ -142,6 +146,22 @@ CA_DEV int64_t wave_add64(int64_t v)
 }
 // Assert to the compiler that a value is wave-uniform (it then lives in an SGPR and feeds scalar
 // branches / scalar loads).
+// inclusive prefix sum over the lanes (the scan the reductions are built on), value of the last lane,
+// ballot, and broadcast of one lane's value (src uniform)
+CA_DEV int32_t wave_scan_add(int32_t v)
+{
+    int32_t _t;
+    _t = CA_DPP(0, v, 0x111, 0xf); v = CA_OP_ADD(v, _t);
+    _t = CA_DPP(0, v, 0x112, 0xf); v = CA_OP_ADD(v, _t);
+    _t = CA_DPP(0, v, 0x114, 0xf); v = CA_OP_ADD(v, _t);
+    _t = CA_DPP(0, v, 0x118, 0xf); v = CA_OP_ADD(v, _t);
+    _t = CA_DPP(0, v, 0x142, 0xa); v = CA_OP_ADD(v, _t);
+    _t = CA_DPP(0, v, 0x143, 0xc); v = CA_OP_ADD(v, _t);
+    return v;
+}
+CA_DEV int32_t wave_last(int32_t v) { return __builtin_amdgcn_readlane(v, 63); }
+CA_DEV uint64_t wave_ballot(bool p) { return __ballot(p); }
+CA_DEV int32_t lane_bcast(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
 CA_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 CA_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); }
 #endif
