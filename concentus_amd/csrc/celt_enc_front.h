@@ -495,12 +495,17 @@ CA_DEVFN i32 remove_doubling_wave(L &F, int *T0_, int prev_period, i32 prev_gain
     T = T0 = *T0_;
     i32 xx, xy;
     dual_inner_prod_wave(x, x, x - T0, N, xx, xy);
-    {   // yy_lookup[i] = max(0, xx + sum_{j=1..i} (x[-j]^2 - x[N-j]^2)): serial running sum, lane 0 stores
-        i32 yy = xx;
+    {   // yy_lookup[i] = max(0, xx + sum_{j=1..i} (x[-j]^2 - x[N-j]^2)): a prefix sum (wrap-around adds commute),
+        // scanned LANES entries at a time
         st0(&yy_lookup[0], xx);
-        for (int i = 1; i <= maxperiod; i++) {
-            yy = sub32(add32(yy, mul16_16(x[-i], x[-i])), mul16_16(x[N - i], x[N - i]));
-            st0(&yy_lookup[i], imax(0, yy));
+        i32 run = xx;
+        for (int base = 1; base <= maxperiod; base += LANES) {
+            const int i = base + lane();
+            i32 d = 0;
+            if (i <= maxperiod) d = sub32(mul16_16(x[-i], x[-i]), mul16_16(x[N - i], x[N - i]));
+            const i32 inc = wave_scan_add(d);
+            if (i <= maxperiod) yy_lookup[i] = imax(0, add32(run, inc));
+            run = add32(run, wave_last(inc));
         }
     }
     wave_sync();
