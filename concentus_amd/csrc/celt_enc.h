@@ -436,8 +436,11 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     const int secondMdct = shortBlocks && cfg.complexity >= 8;
     i32 temporal_vbr = 0;
     for (int mdct_pass = secondMdct ? 0 : 1;;) {
+        CA_STAMP(5);
         compute_mdcts_wave(F, fc, mdct_pass == 0 ? 0 : shortBlocks);
+        CA_STAMP(30);
         band_energies_wave(F, fc, mdct_pass == 0 ? F.bandLogE2 : F.bandLogE);
+        CA_STAMP(31);
         if (mdct_pass == 0) {
             for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
             wave_sync();
