@@ -21,7 +21,20 @@ CA_DEV int iabs(int a) { return a < 0 ? -a : a; }
 CA_DEV void haar1_wave(i16 *X, int N0, int stride)
 {
     N0 >>= 1;
-    CA_UNROLL_LANE
+    if (LANES == 1) {
+        // one lane owns the frame: plain nested loops, no index division
+        for (int i = 0; i < stride; i++) {
+#pragma unroll 4
+            for (int j = 0; j < N0; j++) {
+                i32 t1 = mul16_16(23170, X[stride * 2 * j + i]);
+                i32 t2 = mul16_16(23170, X[stride * (2 * j + 1) + i]);
+                X[stride * 2 * j + i] = (i16)pshr32(add32(t1, t2), 15);
+                X[stride * (2 * j + 1) + i] = (i16)pshr32(sub32(t1, t2), 15);
+            }
+        }
+        wave_sync();
+        return;
+    }
     for (int k = lane(); k < stride * N0; k += LANES) {
         int i = k % stride, j = k / stride;
         i32 t1 = mul16_16(23170, X[stride * 2 * j + i]);

@@ -16,11 +16,12 @@ enum { STG_FRAME = 960, STG_OVL = 120 };
 
 // dc_reject of channel c: pcm interleaved int16 [960][2] (16-byte aligned) -> out planar int16 [960];
 // hp[2] is the filter memory (in/out). Stereo only.
-CA_DEV void stage_dc_reject_channel(const i16 *pcm, int c, i32 *hp, i16 *out)
+CA_DEV void stage_dc_reject_channel(const i16 *__restrict__ pcm, int c, i32 *hp, i16 *__restrict__ out)
 {
     i32 m0 = hp[0], m1 = hp[1];
     const int4 *src = reinterpret_cast<const int4 *>(pcm);
     int4 *dst = reinterpret_cast<int4 *>(out);
+#pragma unroll 4
     for (int i0 = 0; i0 < STG_FRAME; i0 += 8) {
         const int4 a = src[(i0 >> 2) + 0], b = src[(i0 >> 2) + 1];      // 8 stereo pairs
         const i32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -60,11 +61,13 @@ CA_DEV i32 stage_trans_hp(i32 in_q12, i32 &mem0, i32 &mem1)
 // (16-byte aligned), tmp2 = 544 int16 of scratch (16-byte aligned). Returns `unmask` of celt_encoder.c:352.
 // The high-pass output is recomputed in the second pass instead of being stored: the normalising shift
 // depends on the maximum over the whole frame.
-CA_DEV i32 stage_transient_channel(const i32 *in, i16 *tmp2)
+CA_DEV i32 stage_transient_channel(const i32 *__restrict__ in, i16 *__restrict__ tmp2)
 {
     const int len = STG_FRAME + STG_OVL, len2 = len / 2;
     const int4 *src = reinterpret_cast<const int4 *>(in);
     i32 mem0 = 0, mem1 = 0, mx = 0, mn = 0;
+    // the loads of several groups are issued ahead of the recurrence that consumes them
+#pragma unroll 6
     for (int i0 = 0; i0 < len; i0 += 4) {
         const int4 a = src[i0 >> 2];
         const i32 w[4] = {a.x, a.y, a.z, a.w};
@@ -80,6 +83,7 @@ CA_DEV i32 stage_transient_channel(const i32 *in, i16 *tmp2)
     // forward follower over pair energies
     i32 mean = 0, fm = 0;
     mem0 = mem1 = 0;
+#pragma unroll 3
     for (int i0 = 0; i0 < len; i0 += 8) {
         const int4 a = src[(i0 >> 2) + 0], b = src[(i0 >> 2) + 1];
         const i32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -105,6 +109,7 @@ CA_DEV i32 stage_transient_channel(const i32 *in, i16 *tmp2)
     }
     // backward follower, in place; len2 = 540 = 135 groups of 4
     i32 bm = 0, maxE = 0;
+#pragma unroll 5
     for (int g = len2 / 4 - 1; g >= 0; g--) {
         int2 v = reinterpret_cast<const int2 *>(tmp2)[g];
         i32 e[4] = {(i32)(i16)v.x, v.x >> 16, (i32)(i16)v.y, v.y >> 16};
