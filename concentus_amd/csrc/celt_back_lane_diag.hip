@@ -3,6 +3,7 @@
 // wavefront go to a buffer of their own and feed no output.
 #define CA_LANE_FRAME 1
 #define CA_STAGE_TIMING 1
+#include "celt_lane_tables.h"
 #include "celt_enc.h"
 #include "opusgpu_internal.h"
 
@@ -14,6 +15,7 @@ __global__ __launch_bounds__(64) void celt_back_lane_diag_kernel(opusgpu_celt_co
                                                                  int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes,
                                                                  unsigned long long *stamps)
 {
+    fill_lds_tables();
     const int n = blockIdx.x * 64 + threadIdx.x;
     if (n >= nframes) return;
     BackLds F;

@@ -295,9 +295,23 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
         // so each step needs one independent LDS read instead of a read-after-write round trip
         if (r < len - stride) {
             i32 x1 = x[r];
-            int i;
-            CA_UNROLL_LANE
-            for (i = r; i < len - stride; i += stride) {
+            int i = r;
+            if (LANES == 1) {
+                // four look-ahead loads before the first store of the group (they never alias: the stores
+                // trail the loads by `stride`)
+                for (; i + 3 * stride < len - stride; i += 4 * stride) {
+                    i32 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = x[i + (u + 1) * stride];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        i32 n2 = (i16)pshr32(mac16_16(mul16_16(c, v[u]), s, x1), 15);
+                        x[i + u * stride] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, v[u]), 15);
+                        x1 = n2;
+                    }
+                }
+            }
+            for (; i < len - stride; i += stride) {
                 i32 x2 = x[i + stride];
                 i32 n2 = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
                 x[i] = (i16)pshr32(mac16_16(mul16_16(c, x1), ms, x2), 15);
@@ -311,7 +325,18 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
         if (top >= r) {
             int i = top - ((top - r) % stride);
             i32 x2 = x[i + stride];
-            CA_UNROLL_LANE
+            if (LANES == 1) {
+                for (; i - 3 * stride >= 0; i -= 4 * stride) {
+                    i32 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v[u] = x[i - u * stride];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        x[i - u * stride + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, v[u]), 15);
+                        x2 = (i16)pshr32(mac16_16(mul16_16(c, v[u]), ms, x2), 15);
+                    }
+                }
+            }
             for (; i >= 0; i -= stride) {
                 i32 x1 = x[i];
                 x[i + stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);

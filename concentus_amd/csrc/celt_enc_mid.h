@@ -22,10 +22,22 @@ CA_DEV void haar1_wave(i16 *X, int N0, int stride)
 {
     N0 >>= 1;
     if (LANES == 1) {
-        // one lane owns the frame: plain nested loops, no index division
+        // one lane owns the frame: plain nested loops, four butterflies loaded before the first store (the
+        // compiler cannot prove the stores of one step clear of the loads of the next)
         for (int i = 0; i < stride; i++) {
-#pragma unroll 4
-            for (int j = 0; j < N0; j++) {
+            int j = 0;
+            for (; j + 4 <= N0; j += 4) {
+                i32 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { a[u] = X[stride * 2 * (j + u) + i]; b[u] = X[stride * (2 * (j + u) + 1) + i]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    i32 t1 = mul16_16(23170, a[u]), t2 = mul16_16(23170, b[u]);
+                    X[stride * 2 * (j + u) + i] = (i16)pshr32(add32(t1, t2), 15);
+                    X[stride * (2 * (j + u) + 1) + i] = (i16)pshr32(sub32(t1, t2), 15);
+                }
+            }
+            for (; j < N0; j++) {
                 i32 t1 = mul16_16(23170, X[stride * 2 * j + i]);
                 i32 t2 = mul16_16(23170, X[stride * (2 * j + 1) + i]);
                 X[stride * 2 * j + i] = (i16)pshr32(add32(t1, t2), 15);
