@@ -18,6 +18,7 @@
 
 namespace ca {
 
+enum { PVQ_LDS_N = 48 };       // lane build: largest leaf whose search state lives in LDS
 enum { BITRES = 3, ALLOC_STEPS = 6, MAX_FINE_BITS = 8, FINE_OFFSET = 21, QTHETA_OFFSET = 4, QTHETA_OFFSET_TWOPHASE = 16 };
 
 CA_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1); }     // rate.h:46-49
@@ -368,9 +369,8 @@ CA_DEV void exp_rotation_wave(i16 *X, int len, int stride, int K, int spread)   
 
 // encode_pulses(iy, N, K) = ec_enc_uint(icwrs(N, iy), V(N,K))  (cwrs.c:440-460)
 template <class L>
-CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K)
+CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K, LP<i32> y)
 {
-    const i32 *y = F.s.pvq.iy;
     u32 idx;
     if (LANES == 1) {
         // one lane owns the frame: icwrs as the reference walks it (cwrs.c:440-456), no suffix-sum array
@@ -433,8 +433,16 @@ CA_DEV void pvq_argmax(i32 &num, i32 &den, int &id)
 template <class L>
 CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
 {
+    // search state: |X|, 2*iy, iy. Lane build: leaves of up to PVQ_LDS_N elements keep it in LDS.
+#if defined(CA_LANE_FRAME)
+    const bool in_lds = N <= PVQ_LDS_N;
+    LP<i16> y = in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.pvq.y, 1);
+    LP<i16> xa = in_lds ? lp_make(F.lds_pvq16 + PVQ_LDS_N * 64, 64) : lp_make((i16 *)F.s.pvq.xabs, 1);
+    LP<i32> iy = in_lds ? lp_make(F.lds_pvq32, 64) : lp_make((i32 *)F.s.pvq.iy, 1);
+#else
     i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
     i32 *iy = F.s.pvq.iy;
+#endif
     CA_STAMP_F(F, 22);
     CA_COUNT("leaf.N", N);
     CA_COUNT("leaf.K", K);
@@ -516,7 +524,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
     for (int j = lane(); j < N; j += LANES)
         if (X[j] <= 0) iy[j] = -iy[j];                                            // signx[j] < 0  <=>  X[j] <= 0
     wave_sync();
-    encode_pulses_wave(F, ec, N, K);
+    encode_pulses_wave(F, ec, N, K, iy);
     CA_STAMP_F(F, 20);
 }
 
@@ -686,16 +694,20 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
     int tf_change = ctx.tf_change;
     if (N == 1) { quant_band_n1_wave(ec, ctx, Xband, nullptr); return; }
     int recombine = tf_change > 0 ? tf_change : 0;
-    for (int k = 0; k < recombine; k++) haar1_wave(Xband, N >> k, 1 << k);
+    CA_COUNT("band.tf_change", tf_change);
+    CA_COUNT(B > 1 ? "band.short" : "band.long", N);
+    for (int k = 0; k < recombine; k++) { CA_COUNT("band.haar_recombine", N); haar1_wave(Xband, N >> k, 1 << k); }
     B >>= recombine;
     N_B <<= recombine;
     while ((N_B & 1) == 0 && tf_change < 0) {
+        CA_COUNT("band.haar_timediv", N);
         haar1_wave(Xband, N_B, B);
         B <<= 1;
         N_B >>= 1;
         tf_change++;
     }
     const int B0band = B;
+    if (B0band > 1) CA_COUNT("band.deinterleave", N);
     if (B0band > 1) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
     CA_STAMP_F(F, 21);
 

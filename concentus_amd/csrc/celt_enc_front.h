@@ -68,6 +68,8 @@ struct __attribute__((aligned(16))) BackLds {
     // stay where they already are in HBM (per-lane sequential access is what the L1/L2 lines are good at)
     i16 *x16;                      // -> FrameMid::X of this frame (transformed in place)
     u8 *packet;                    // -> the output slab of this frame
+    i16 *lds_pvq16;                // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
+    i32 *lds_pvq32;
 #else
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
 #endif

@@ -166,4 +166,19 @@ CA_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 CA_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); }
 #endif
 
+// LP<T>: pointer to a per-frame array. In the lane-per-frame build the hot little arrays live in LDS laid out
+// [element][lane] (stride 64), the rest stays contiguous (stride 1): one runtime stride covers both. In the
+// other builds it is a plain pointer.
+#if defined(CA_LANE_FRAME)
+template <class T> struct LP {
+    T *p;
+    int s;
+    __device__ __forceinline__ T &operator[](int j) const { return p[j * s]; }
+};
+template <class T> __device__ __forceinline__ LP<T> lp_make(T *p, int stride) { LP<T> r; r.p = p; r.s = stride; return r; }
+#else
+template <class T> using LP = T *;
+template <class T> CA_DEV LP<T> lp_make(T *p, int) { return p; }
+#endif
+
 }  // namespace ca
