@@ -18,7 +18,8 @@ namespace ca {
 CA_DEV int iabs(int a) { return a < 0 ? -a : a; }
 
 // haar1 on a vector in LDS (bands.c:581-594): N0 halved, `stride` interleaved sub-vectors; all pairs independent.
-CA_DEV void haar1_wave(i16 *X, int N0, int stride)
+template <class P>
+CA_DEV void haar1_wave(P X, int N0, int stride)
 {
     N0 >>= 1;
     if (LANES == 1) {
@@ -57,7 +58,8 @@ CA_DEV void haar1_wave(i16 *X, int N0, int stride)
     wave_sync();
 }
 
-CA_DEV i32 l1_metric_wave(const i16 *tmp, int N, int LM, i32 bias)              // celt_encoder.c:541-550
+template <class P>
+CA_DEV i32 l1_metric_wave(P tmp, int N, int LM, i32 bias)              // celt_encoder.c:541-550
 {
     i32 p = 0;
     CA_UNROLL_LANE
@@ -72,11 +74,18 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
 {
     const int len = NB, LM = LM3;
     const i16 *X = frame_X(F);
-    i16 *tmp = F.s.tf.tmp, *tmp_1 = F.s.tf.tmp1;
     i32 bias = (i16)mul16_16_q14(1311, imax(-4096, 8192 - tf_estimate));          // .04 Q15, -.25 Q14, .5 Q14
     for (int i = 0; i < len; i++) {
         const int width = CLT_eband5ms[i + 1] - CLT_eband5ms[i];
         const int N = width << LM, narrow = width == 1;
+#if defined(CA_LANE_FRAME)
+        // bands of up to 48 bins are analysed in the workgroup's LDS scratch ([element][lane])
+        const bool in_lds = N <= 48;
+        LP<i16> tmp = in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.tf.tmp, 1);
+        LP<i16> tmp_1 = in_lds ? lp_make(F.lds_pvq16 + 48 * 64, 64) : lp_make((i16 *)F.s.tf.tmp1, 1);
+#else
+        i16 *tmp = F.s.tf.tmp, *tmp_1 = F.s.tf.tmp1;
+#endif
         CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) tmp[j] = X[tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j];
         wave_sync();
