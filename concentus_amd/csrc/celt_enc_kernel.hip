@@ -152,7 +152,7 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
     hipStream_t s = (hipStream_t)stream;
     for (size_t first = 0; first < (size_t)n_frames; first += chunk) {
         int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
-        int g1 = n < cus * 6 ? n : cus * 6;          // ~23 KB LDS per workgroup -> 6 resident per CU
+        int g1 = n < cus * 7 ? n : cus * 7;          // 22.8 KB LDS per workgroup -> 7 resident per CU (measured best)
         int g2 = n < cus * 16 ? n : cus * 16;        // ~9.6 KB LDS per workgroup -> 16 resident per CU
         // default: one lane per frame for the serial back phase; OPUSGPU_BACK_WAVE=1 selects the
         // one-wave-per-frame kernel (kept for the stage-stamp diagnostics and as a cross-check)
