@@ -337,7 +337,7 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     CA_STAMP(1);
     // 3. pre-emphasis
     preemphasis_wave(F, fc);
-    CA_TAP("in_preemph", F.in, sizeof(F.in));
+    if constexpr (!L::IN_IS_GLOBAL) CA_TAP("in_preemph", F.in, sizeof(F.in));
     CA_TRACE("preemph done");
 
     CA_STAMP(2);
@@ -366,7 +366,7 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     // stream state that depends on the (still live) unfiltered / filtered time signal
     if (st_out) {
         for (int c = 0; c < C; c++) {
-            for (int i = lane(); i < OVL; i += LANES) st_out->in_mem[c * OVL + i] = F.in[c][N + i];
+            for (int i = lane(); i < OVL; i += LANES) st_out->in_mem[c * OVL + i] = tsig(F, c)[N + i];
             // prefilter_mem <- last 1024 of [history | new]; new[j] = j<64 ? old[960+j] : unfiltered[j-64].
             // In-place safe: element j (>= 64) no longer depends on the old array, element j < 64 reads old[960+j]
             // which only lanes handling j' = 960+j >= 64 overwrite -> read everything first.
@@ -381,11 +381,12 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     wave_sync();
 
     CA_TRACE("prefilter done pitch=%d gain=%d pf_on=%d", pitch_index, gain1, pf_on); CA_TRACE("");
-    CA_TAP("in_filtered", F.in, sizeof(F.in));
+    if constexpr (!L::IN_IS_GLOBAL) CA_TAP("in_filtered", F.in, sizeof(F.in));
     CA_STAMP(3);
     if constexpr (PHASE == 1) {
-        for (int c = 0; c < C; c++)
-            for (int i = lane(); i < N + OVL; i += LANES) in_ws[c * (N + OVL) + i] = F.in[c][i];
+        if (!L::IN_IS_GLOBAL)
+            for (int c = 0; c < C; c++)
+                for (int i = lane(); i < N + OVL; i += LANES) in_ws[c * (N + OVL) + i] = tsig(F, c)[i];
         MidScalars m;
         m.max_data_bytes = max_data_bytes; m.nbCompressedBytes = nbCompressedBytes; m.nbAvailableBytes = nbAvailableBytes;
         m.effectiveBytes = effectiveBytes; m.vbr_rate = vbr_rate; m.equiv_rate = equiv_rate; m.total_bits = total_bits;
@@ -401,10 +402,12 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     max_data_bytes = m.max_data_bytes; nbCompressedBytes = m.nbCompressedBytes; nbAvailableBytes = m.nbAvailableBytes;
     effectiveBytes = m.effectiveBytes; vbr_rate = m.vbr_rate; equiv_rate = m.equiv_rate; total_bits = m.total_bits;
     silence = m.silence; pitch_index = m.pitch_index; pf_on = m.pf_on; prefilter_tapset = m.prefilter_tapset; gain1 = m.gain1;
-    for (int c = 0; c < C; c++)
-        for (int i = lane(); i < N + OVL; i += LANES) F.in[c][i] = in_ws[c * (N + OVL) + i];
+    if (!L::IN_IS_GLOBAL)
+        for (int c = 0; c < C; c++)
+            for (int i = lane(); i < N + OVL; i += LANES) tsig(F, c)[i] = in_ws[c * (N + OVL) + i];
     wave_sync();
   }
+  if constexpr (PHASE != 1) {
     // 5. transient analysis
     int isTransient = 0, shortBlocks = 0, tf_chan = 0, transient_got_disabled = 0;
     i32 tf_estimate = 0;
@@ -506,12 +509,13 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     // 10. normalise
     normalise_bands_wave(F, fc);
 
-    CA_TAP("X", F.in, 2 * FRAME * 2);
+    if constexpr (!L::IN_IS_GLOBAL) CA_TAP("X", F.in, 2 * FRAME * 2);
     CA_STAMP(6);
     // ---- hand-off ----
     {
         const i16 *X = frame_X(F);
-        for (int k = lane(); k < 2 * FRAME; k += LANES) mid->X[k] = X[k];
+        if (X != mid->X)
+            for (int k = lane(); k < 2 * FRAME; k += LANES) mid->X[k] = X[k];
         MidScalars m;
         m.max_data_bytes = max_data_bytes; m.nbCompressedBytes = nbCompressedBytes; m.nbAvailableBytes = nbAvailableBytes;
         m.effectiveBytes = effectiveBytes; m.vbr_rate = vbr_rate; m.equiv_rate = equiv_rate; m.total_bits = total_bits;
@@ -520,6 +524,7 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
         m.transient_got_disabled = transient_got_disabled; m.tf_estimate = tf_estimate; m.temporal_vbr = temporal_vbr;
         mid_store(F, mid, enc, fc, m);
     }
+  }
 }
 
 template <class L>

@@ -35,23 +35,29 @@ __global__ __launch_bounds__(64, 2) void celt_front_kernel(opusgpu_celt_config c
 
 // Split front phase (default pipeline): phase 1 = rate bookkeeping .. pitch pre-filter, phase 2 = MDCT ..
 // normalisation; the serial dc_reject and transient stages run in celt_stage_kernels.hip in between.
-__global__ __launch_bounds__(64, 2) void celt_front1_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+__global__ __launch_bounds__(64, 3) void celt_front1_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
                                                             FrameMid *__restrict__ mid, i32 *__restrict__ in_ws, int nframes)
 {
-    __shared__ FrontLds F;
+    __shared__ Front1Lds F;
     for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
         opusgpu_celt_state *st = states ? states + n : nullptr;
-        celt_encode_front_phase<1>(F, cfg, st, st, nullptr, mid + n, nullptr, in_ws + (size_t)n * 2 * (FRAME + OVL));
+        i32 *in = in_ws + (size_t)n * 2 * (FRAME + OVL);
+        if (lane() == 0) F.in_g = in;
+        wave_sync();
+        celt_encode_front_phase<1>(F, cfg, st, st, nullptr, mid + n, nullptr, in);
         wave_sync();
     }
 }
 
-__global__ __launch_bounds__(64, 2) void celt_front2_kernel(opusgpu_celt_config cfg, FrameMid *__restrict__ mid,
+__global__ __launch_bounds__(64, 3) void celt_front2_kernel(opusgpu_celt_config cfg, FrameMid *__restrict__ mid,
                                                             i32 *__restrict__ in_ws, int nframes)
 {
-    __shared__ FrontLds F;
+    __shared__ Front2Lds F;
     for (int n = blockIdx.x; n < nframes; n += gridDim.x) {
-        celt_encode_front_phase<2>(F, cfg, nullptr, nullptr, nullptr, mid + n, nullptr, in_ws + (size_t)n * 2 * (FRAME + OVL));
+        i32 *in = in_ws + (size_t)n * 2 * (FRAME + OVL);
+        if (lane() == 0) { F.in_g = in; F.x_g = mid[n].X; }
+        wave_sync();
+        celt_encode_front_phase<2>(F, cfg, nullptr, nullptr, nullptr, mid + n, nullptr, in);
         wave_sync();
     }
 }
@@ -169,14 +175,15 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_DC_REJECT, s);
             opusgpu_launch_dc_reject(st ? st + first : nullptr, d_pcm + first * FRAME * cfg->channels, mid, n, s);
             opusgpu_timing_end(slot, s);
+            const int gf1 = n < cus * 11 ? n : cus * 11, gf2 = n < cus * 12 ? n : cus * 12;   // 14.4 / 12.7 KB LDS per workgroup
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT1, s);
-            hipLaunchKernelGGL(celt_front1_kernel, dim3(g1), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid, in_ws, n);
+            hipLaunchKernelGGL(celt_front1_kernel, dim3(gf1), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid, in_ws, n);
             opusgpu_timing_end(slot, s);
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_TRANSIENT, s);
             opusgpu_launch_transient(mid, in_ws, n, s);
             opusgpu_timing_end(slot, s);
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT2, s);
-            hipLaunchKernelGGL(celt_front2_kernel, dim3(g1), dim3(64), 0, s, *cfg, mid, in_ws, n);
+            hipLaunchKernelGGL(celt_front2_kernel, dim3(gf2), dim3(64), 0, s, *cfg, mid, in_ws, n);
             opusgpu_timing_end(slot, s);
         }
         slot = opusgpu_timing_begin(lane_back ? OPUSGPU_KERNEL_CELT_BACK_LANE : OPUSGPU_KERNEL_CELT_BACK, s);

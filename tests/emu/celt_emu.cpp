@@ -95,10 +95,15 @@ extern "C" int emu_celt_encode_frames_split(const opusgpu_celt_config *cfg, opus
             mid->hp_mem[2 * c] = hp[0];
             mid->hp_mem[2 * c + 1] = hp[1];
         }
-        celt_encode_front_phase<1>(*F1, *cfg, st, st, p, mid, nullptr, in_ws);
+        Front1Lds *Fa = (Front1Lds *)F1;                 // the split kernels' own (smaller) working sets
+        Fa->in_g = in_ws;
+        celt_encode_front_phase<1>(*Fa, *cfg, st, st, p, mid, nullptr, in_ws);
         for (int c = 0; c < C; c++) mid->trans_unmask[c] = stage_transient_channel(in_ws + c * 1080, mid->X + c * 960);
         memset(F1, 0xAB, sizeof(FrontLds));
-        celt_encode_front_phase<2>(*F1, *cfg, nullptr, nullptr, nullptr, mid, nullptr, in_ws);
+        Front2Lds *Fb = (Front2Lds *)F1;
+        Fb->in_g = in_ws;
+        Fb->x_g = mid->X;
+        celt_encode_front_phase<2>(*Fb, *cfg, nullptr, nullptr, nullptr, mid, nullptr, in_ws);
         FrameResult r = celt_encode_back(*F2, *cfg, mid, st, out + (size_t)n * out_stride);
         out_len[n] = r.bytes;
         out_rng[n] = r.final_range;
