@@ -138,3 +138,31 @@ def test_wave_per_frame_back_kernel_agrees_with_lane_per_frame(ca, monkeypatch):
     monkeypatch.setenv("OPUSGPU_BACK_WAVE", "1")
     w = _gpu_encode(ca, ec.load_case("music_vbr_indep")[0], 1, (96000, 1, 0, 10))
     ec.assert_packets_equal(w[0], w[1], w[2], pk, ln, rg, "wave back kernel vs golden")
+
+
+def test_small_workspace_chunks_the_batch(ca, monkeypatch):
+    """A workspace smaller than the batch is legal (include/opusgpu.h): the library then runs the pipeline over
+    chunks of workspace_bytes / opusgpu_encode_workspace_bytes(1) frames. Same packets, and the fused
+    single-kernel front phase (OPUSGPU_FRONT_FUSED=1) agrees with the split pipeline."""
+    import torch
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm("music", 700, 7)
+    ref = _gpu_encode(ca, pcm, 1, (96000, 1, 0, 10))
+    cfg = _cfg(ca, (96000, 1, 0, 10))
+    L = ca.lib.load()
+    d = torch.from_numpy(np.ascontiguousarray(pcm)).cuda()
+    stride = ca.encoder.out_stride_for(cfg)
+    for fused in (False, True):
+        if fused:
+            monkeypatch.setenv("OPUSGPU_FRONT_FUSED", "1")
+        out = torch.zeros((700, stride), dtype=torch.uint8, device="cuda")
+        lens = torch.empty((700,), dtype=torch.int32, device="cuda")
+        rng = torch.empty((700,), dtype=torch.int32, device="cuda")
+        ws = torch.empty((L.opusgpu_encode_workspace_bytes(256) + 100,), dtype=torch.uint8, device="cuda")   # 256-frame chunks: 256+256+188
+        rc = L.opusgpu_encode_batch(C.byref(cfg), None, d.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rng.data_ptr(),
+                                    700, ws.data_ptr(), ws.numel(), None)
+        torch.cuda.synchronize()
+        assert rc == 0
+        ec.assert_packets_equal(out.cpu().numpy(), lens.cpu().numpy(), rng.cpu().numpy().view(np.uint32),
+                                ref[0], ref[1], ref[2], "chunked, fused=%s" % fused)
+    monkeypatch.delenv("OPUSGPU_FRONT_FUSED")
