@@ -630,7 +630,9 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         ec_enc_icdf(enc, fc.spread_decision, CLT_spread_icdf, 5);
     }
     i32 tot_boost;
-    const i32 maxDepth = dynalloc_analysis_wave(F, fc, cfg.lsb_depth, isTransient, celt_vbr, constrained_vbr,
+    // opus_encode() hands int16 input over with lsb_depth 16; opus_encode_native takes the min with the ctl value
+    // (src/opus_encoder.c:2022, :1034)
+    const i32 maxDepth = dynalloc_analysis_wave(F, fc, imin(16, cfg.lsb_depth), isTransient, celt_vbr, constrained_vbr,
                                                 effectiveBytes, &tot_boost);
     for (int i = lane(); i < NB; i += LANES) {                                     // init_caps (celt.c:246-256)
         int Nb = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;

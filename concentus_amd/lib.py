@@ -29,6 +29,10 @@ SYMBOLS = [
     ("opusgpu_silk_burg_modified_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_nsq_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_silk_nsq_batch", _i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
+    ("opusgpu_encoder_create", _vp, [_i, _i, _i, _vp]),
+    ("opusgpu_encoder_ctl", _i, None),          # variadic
+    ("opusgpu_encode", _i, [_vp, _vp, _i, _vp, _i]),
+    ("opusgpu_encoder_destroy", None, [_vp]),
     ("opusgpu_back_lane_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
@@ -54,7 +58,8 @@ def load():
         for name, res, args in SYMBOLS:
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
-            fn.argtypes = args
+            if args is not None:
+                fn.argtypes = args
         _lib = lib
     return _lib
 

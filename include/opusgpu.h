@@ -103,7 +103,7 @@ typedef struct opusgpu_celt_config {
     int32_t vbr;               /* OPUS_SET_VBR */
     int32_t constrained_vbr;   /* OPUS_SET_VBR_CONSTRAINT */
     int32_t complexity;        /* OPUS_SET_COMPLEXITY 0..10 */
-    int32_t lsb_depth;         /* OPUS_SET_LSB_DEPTH (16 for int16 input) */
+    int32_t lsb_depth;         /* OPUS_SET_LSB_DEPTH, 8..24; the int16 entry points use min(16, lsb_depth) as opus_encode does */
     int32_t loss_rate;         /* OPUS_SET_PACKET_LOSS_PERC */
     int32_t max_data_bytes;    /* opus_encode()'s max_data_bytes (opus_demo passes 1500) */
 } opusgpu_celt_config;
@@ -131,6 +131,19 @@ size_t opusgpu_encode_workspace_bytes(int n_frames);
 int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const int16_t *d_pcm,
                          unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
                          int n_frames, void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
+/* ---- libopus single-stream encoder API as a batch of one (plumbing; BASELINE config #1) --------------
+ * Same verbs, argument meaning and return codes as opus_encoder_create / opus_encoder_ctl / opus_encode /
+ * opus_encoder_destroy (opus-fix/include/opus.h:164-263; src/opus_encoder.c:482, :2031, :2007, :2491), host
+ * pointers, for 48 kHz stereo OPUS_APPLICATION_RESTRICTED_LOWDELAY and frame_size 960 (anything else that is
+ * legal in libopus returns OPUS_UNIMPLEMENTED). ctl requests: the ones src/opus_demo.c:531-543 issues,
+ * OPUS_GET_FINAL_RANGE (4031) and OPUS_RESET_STATE (4028). Each call is one opusgpu_encode_batch of a single
+ * frame between two small copies: latency-bound by construction. */
+typedef struct OpusGpuEncoder OpusGpuEncoder;
+OpusGpuEncoder *opusgpu_encoder_create(int32_t Fs, int channels, int application, int *error);
+int opusgpu_encoder_ctl(OpusGpuEncoder *st, int request, ...);
+int32_t opusgpu_encode(OpusGpuEncoder *st, const int16_t *pcm, int frame_size, unsigned char *data, int32_t max_data_bytes);
+void opusgpu_encoder_destroy(OpusGpuEncoder *st);
 
 /* Diagnostic only (never used for reported throughput): the same kernels with in-kernel stage stamps;
  * d_stamps = zero-initialised uint64 [4096][32] cycle totals per stage and workgroup. */

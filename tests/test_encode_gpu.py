@@ -166,3 +166,38 @@ def test_small_workspace_chunks_the_batch(ca, monkeypatch):
         ec.assert_packets_equal(out.cpu().numpy(), lens.cpu().numpy(), rng.cpu().numpy().view(np.uint32),
                                 ref[0], ref[1], ref[2], "chunked, fused=%s" % fused)
     monkeypatch.delenv("OPUSGPU_FRONT_FUSED")
+
+
+@pytest.mark.parametrize("name", ["music_vbr_stream", "noise_cvbr_stream", "music_cbr_stream_cx5"])
+def test_single_stream_api_shim_matches_golden_stream(ca, name):
+    """opusgpu_encoder_create / _ctl / opusgpu_encode / _destroy driven exactly as src/opus_demo.c:519-543,
+    :740-760 drives libopus (host pointers, one frame per call): the packets and OPUS_GET_FINAL_RANGE of each
+    stream of the golden case, frame by frame."""
+    case = [c for c in ec.cases() if c[0] == name][0]
+    _n, _kind, n, fps, _seed, (br, vbr, cvbr, cx) = case
+    pcm, pk, ln, rg = ec.load_case(name)
+    L = ca.lib.load()
+    for s in range(n // fps):
+        err = C.c_int(12345)
+        st = L.opusgpu_encoder_create(48000, 2, 2051, C.byref(err))
+        assert st and err.value == 0
+        i32 = C.c_int32
+        for req, v in ((4002, br), (4008, -1000), (4006, vbr), (4020, cvbr), (4010, cx), (4012, 0), (4022, -1000),
+                       (4016, 0), (4014, 0), (4036, 16), (4040, 5000)):
+            assert L.opusgpu_encoder_ctl(C.c_void_p(st), req, i32(v)) == 0, req
+        data = (C.c_ubyte * 1500)()
+        for f in range(fps):
+            k = s * fps + f
+            frame = np.ascontiguousarray(pcm[k])
+            got = L.opusgpu_encode(C.c_void_p(st), frame.ctypes.data_as(C.c_void_p), 960, data, 1500)
+            assert got == ln[k], (name, s, f, got, ln[k])
+            assert bytes(data[:got]) == pk[k, :got].tobytes(), (name, s, f)
+            fr = C.c_uint32(0)
+            assert L.opusgpu_encoder_ctl(C.c_void_p(st), 4031, C.byref(fr)) == 0
+            assert fr.value == rg[k]
+        assert L.opusgpu_encode(C.c_void_p(st), frame.ctypes.data_as(C.c_void_p), 480, data, 1500) == -5     # legal in libopus, not here
+        assert L.opusgpu_encode(C.c_void_p(st), frame.ctypes.data_as(C.c_void_p), 961, data, 1500) == -1     # OPUS_BAD_ARG
+        L.opusgpu_encoder_destroy(C.c_void_p(st))
+    err = C.c_int(0)
+    assert not L.opusgpu_encoder_create(44100, 2, 2051, C.byref(err)) and err.value == -1
+    assert not L.opusgpu_encoder_create(48000, 2, 2049, C.byref(err)) and err.value == -5
