@@ -665,13 +665,36 @@ CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i
 template <class L>
 CA_DEV void deinterleave_hadamard_wave(L &F, i16 *X, int N0, int stride, int hadamard)   // bands.c:524-549
 {
-    i16 *tmp = F.s.pvq.xabs;
     const int N = N0 * stride;
+#if defined(CA_LANE_FRAME)
+    // the PVQ search scratch is idle here: bands of up to 2*PVQ_LDS_N bins bounce through its LDS copy
+    LP<i16> tmp = N <= 2 * PVQ_LDS_N ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.pvq.xabs, 1);
+#else
+    i16 *tmp = F.s.pvq.xabs;
+#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
-    for (int s = 0; s < stride; s++) {
-        int d = hadamard ? ordery[s] : s;
-        CA_UNROLL_LANE
-        for (int j = lane(); j < N0; j += LANES) tmp[d * N0 + j] = X[j * stride + s];
+    if (LANES == 1) {
+        // one lane owns the frame: walk the N outputs flat, eight loads in flight before the first store
+        int sidx = 0, j = 0, d = hadamard ? ordery[0] : 0;
+        for (int k = 0; k < N; k += 8) {
+            i32 v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool ok = k + u < N;
+                v[u] = ok ? (i32)X[j * stride + sidx] : 0;
+                dst[u] = ok ? d * N0 + j : -1;
+                if (++j == N0) { j = 0; sidx++; d = hadamard ? ordery[sidx < stride ? sidx : 0] : sidx; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (dst[u] >= 0) tmp[dst[u]] = (i16)v[u];
+        }
+    } else {
+        for (int s = 0; s < stride; s++) {
+            int d = hadamard ? ordery[s] : s;
+            for (int j = lane(); j < N0; j += LANES) tmp[d * N0 + j] = X[j * stride + s];
+        }
     }
     wave_sync();
     CA_UNROLL_LANE
@@ -696,7 +719,9 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
     int recombine = tf_change > 0 ? tf_change : 0;
     CA_COUNT("band.tf_change", tf_change);
     CA_COUNT(B > 1 ? "band.short" : "band.long", N);
+    CA_STAMP_F(F, 26);
     for (int k = 0; k < recombine; k++) { CA_COUNT("band.haar_recombine", N); haar1_wave(Xband, N >> k, 1 << k); }
+    CA_STAMP_F(F, 27);
     B >>= recombine;
     N_B <<= recombine;
     while ((N_B & 1) == 0 && tf_change < 0) {
@@ -706,6 +731,7 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
         N_B >>= 1;
         tf_change++;
     }
+    CA_STAMP_F(F, 28);
     const int B0band = B;
     if (B0band > 1) CA_COUNT("band.deinterleave", N);
     if (B0band > 1) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
