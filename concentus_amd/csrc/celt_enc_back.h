@@ -15,6 +15,7 @@
 // bits, so they are not carried here (the decoder path will need them).
 #pragma once
 #include "celt_enc_mid.h"
+#include "rangedec.h"
 
 namespace ca {
 
@@ -54,8 +55,8 @@ CA_DEV u32 pvq_u(int n, int k)                                                  
 // ---- compute_allocation (rate.c:527-639 + :248-525), start 0, end 21, LM 3, encode 1 ---------------
 struct AllocOut { int codedBands; i32 balance; int intensity; int dual_stereo; };
 
-template <class L>
-CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_trim, int intensity_in,
+template <class L, class EC>
+CA_DEVFN AllocOut compute_allocation_wave(L &F, EC &ec, int C, int alloc_trim, int intensity_in,
                                           int dual_stereo_in, i32 total, int prev, int signalBandwidth)
 {
     const int LM = LM3, end = NB, start = 0, len = NB;
@@ -155,11 +156,9 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
         int band_width = eB[codedBands] - eB[j];
         int band_bits = (int)(uni(bits[j]) + percoeff * band_width + rem);
         if (band_bits >= imax(uni(F.thresh[j]), alloc_floor + (1 << BITRES))) {
-            if (codedBands <= start + 2 || (band_bits > (((j < prev ? 7 : 9) * band_width) << LM << BITRES) >> 4 && j <= signalBandwidth)) {
-                ec_enc_bit_logp(ec, 1, 1);
+            // encoder: keep the band if it is worth it and say so; decoder: read the decision (rate.c:352-376)
+            if (coder_bit_logp(ec, codedBands <= start + 2 || (band_bits > (((j < prev ? 7 : 9) * band_width) << LM << BITRES) >> 4 && j <= signalBandwidth), 1))
                 break;
-            }
-            ec_enc_bit_logp(ec, 0, 1);
             psum += 1 << BITRES;
             band_bits -= 1 << BITRES;
         }
@@ -171,12 +170,12 @@ CA_DEVFN AllocOut compute_allocation_wave(L &F, RangeEnc &ec, int C, int alloc_t
     }
     if (intensity_rsv > 0) {
         out.intensity = imin(out.intensity, codedBands);
-        ec_enc_uint(ec, (u32)(out.intensity - start), (u32)(codedBands + 1 - start));
+        out.intensity = start + (int)coder_uint(ec, (u32)(out.intensity - start), (u32)(codedBands + 1 - start));
     } else {
         out.intensity = 0;
     }
     if (out.intensity <= start) { total += dual_stereo_rsv; dual_stereo_rsv = 0; }
-    if (dual_stereo_rsv > 0) ec_enc_bit_logp(ec, out.dual_stereo, 1);
+    if (dual_stereo_rsv > 0) out.dual_stereo = coder_bit_logp(ec, out.dual_stereo, 1);
     else out.dual_stereo = 0;
     wave_sync();
     i32 left = total - psum;

@@ -54,6 +54,26 @@ typedef struct opusgpu_celt_state {
     int32_t prefilter_mem[2 * OPUSGPU_COMBFILTER_MAXPERIOD];
 } opusgpu_celt_state;
 
+/* Decoder counterpart: everything `struct OpusCustomDecoder` keeps past DECODER_RESET_START for a stereo
+ * stream (opus-fix/celt/celt_decoder.c:66-97 and the trailing arrays :94-96; `lpc` is only used by the
+ * packet loss concealment, which is not implemented). */
+#define OPUSGPU_DECODE_BUFFER_SIZE 2048
+typedef struct opusgpu_celt_dec_state {
+    uint32_t rng;
+    int32_t error;
+    int32_t postfilter_period, postfilter_period_old;
+    int32_t postfilter_gain, postfilter_gain_old;          /* opus_val16 */
+    int32_t postfilter_tapset, postfilter_tapset_old;
+    int32_t preemph_memD[2];
+    int32_t loss_count;
+    int32_t reserved[5];
+    int16_t oldBandE[2 * OPUSGPU_CELT_NBANDS];
+    int16_t oldLogE[2 * OPUSGPU_CELT_NBANDS];
+    int16_t oldLogE2[2 * OPUSGPU_CELT_NBANDS];
+    int16_t backgroundLogE[2 * OPUSGPU_CELT_NBANDS];
+    int32_t decode_mem[2][OPUSGPU_DECODE_BUFFER_SIZE + OPUSGPU_CELT_OVERLAP];
+} opusgpu_celt_dec_state;
+
 #ifdef __cplusplus
 }
 #endif

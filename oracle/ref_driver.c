@@ -149,3 +149,54 @@ void refdrv_encode_frames(const refdrv_config *cfg, const int16_t *pcm, long nfr
     free(th);
     free(jobs);
 }
+
+
+/* ---- decode side: opus_decoder_create(48000, 2) + opus_decode(960) per packet, streams of frames_per_stream ---- */
+typedef struct OpusDecoder OpusDecoder;
+extern OpusDecoder *opus_decoder_create(int32_t Fs, int channels, int *error);             /* include/opus.h:438 */
+extern int opus_decode(OpusDecoder *st, const unsigned char *data, int32_t len, int16_t *pcm, int frame_size, int decode_fec);
+extern int opus_decoder_ctl(OpusDecoder *st, int request, ...);
+extern void opus_decoder_destroy(OpusDecoder *st);
+#define REF_OPUS_GET_FINAL_RANGE_REQUEST 4031
+typedef struct {
+    const unsigned char *pk; int stride; const int *len; int16_t *pcm; uint32_t *rng; int *ret;
+    long first, count; int fps;
+} dec_job;
+
+static void *dec_worker(void *arg)
+{
+    dec_job *j = (dec_job *)arg;
+    for (long s = j->first; s < j->first + j->count; s++) {
+        int err = 0;
+        OpusDecoder *d = opus_decoder_create(48000, 2, &err);
+        for (int f = 0; f < j->fps; f++) {
+            long k = s * j->fps + f;
+            j->ret[k] = d ? opus_decode(d, j->pk + (size_t)k * j->stride, j->len[k], j->pcm + (size_t)k * 960 * 2, 960, 0) : err;
+            if (d) opus_decoder_ctl(d, REF_OPUS_GET_FINAL_RANGE_REQUEST, &j->rng[k]);
+        }
+        if (d) opus_decoder_destroy(d);
+    }
+    return NULL;
+}
+
+void refdrv_decode_frames(const unsigned char *packets, int stride, const int *len, long nframes, int frames_per_stream,
+                          int16_t *pcm, uint32_t *rng, int *ret, int threads)
+{
+    long nstreams = nframes / frames_per_stream;
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    dec_job *jobs = (dec_job *)malloc(sizeof(dec_job) * threads);
+    long per = (nstreams + threads - 1) / threads;
+    int used = 0;
+    for (int i = 0; i < threads; i++) {
+        long first = (long)i * per;
+        if (first >= nstreams) break;
+        long cnt = nstreams - first < per ? nstreams - first : per;
+        jobs[i] = (dec_job){packets, stride, len, pcm, rng, ret, first, cnt, frames_per_stream};
+        pthread_create(&th[i], NULL, dec_worker, &jobs[i]);
+        used++;
+    }
+    for (int i = 0; i < used; i++) pthread_join(th[i], NULL);
+    free(th);
+    free(jobs);
+}

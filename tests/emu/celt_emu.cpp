@@ -22,6 +22,7 @@ extern "C" int emu_tap_get(const char *name, void *out, int cap)
 }
 #include "../../concentus_amd/csrc/celt_enc.h"
 #include "../../concentus_amd/csrc/celt_stage_lane.h"
+#include "../../concentus_amd/csrc/celt_dec.h"
 
 using namespace ca;
 
@@ -111,6 +112,31 @@ extern "C" int emu_celt_encode_frames_split(const opusgpu_celt_config *cfg, opus
     free(F1); free(F2); free(mid); free(in_ws);
     return 0;
 }
+
+// ---- decoder: packets -> PCM, streams of frames_per_stream packets each starting from a fresh decoder ----
+static void dec_state_reset(opusgpu_celt_dec_state *st)
+{
+    memset(st, 0, sizeof(*st));
+    for (int i = 0; i < 42; i++) st->oldLogE[i] = st->oldLogE2[i] = -28672;
+}
+
+extern "C" int emu_celt_decode_frames(const unsigned char *packets, int stride, const int *len, int nframes,
+                                      int frames_per_stream, int16_t *pcm, uint32_t *rng, int *ret)
+{
+    DecWork *F = (DecWork *)aligned_alloc(64, sizeof(DecWork) + 64);
+    opusgpu_celt_dec_state *st = (opusgpu_celt_dec_state *)aligned_alloc(64, sizeof(opusgpu_celt_dec_state) + 64);
+    for (int n = 0; n < nframes; n++) {
+        if (n % frames_per_stream == 0) dec_state_reset(st);
+        memset(F, 0xAB, sizeof(DecWork));
+        DecResult r = celt_decode_frame(*F, st, packets + (size_t)n * stride, len[n], pcm + (size_t)n * 960 * 2);
+        ret[n] = r.samples;
+        rng[n] = r.final_range;
+    }
+    free(F);
+    free(st);
+    return 0;
+}
+extern "C" int emu_sizeof_dec_state(void) { return (int)sizeof(opusgpu_celt_dec_state); }
 
 extern "C" int emu_sizeof_state(void) { return (int)sizeof(opusgpu_celt_state); }
 extern "C" int emu_sizeof_frame_lds(void) { return (int)(sizeof(FrontLds) * 100000 + sizeof(BackLds)); }
