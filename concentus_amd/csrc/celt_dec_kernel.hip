@@ -1,0 +1,64 @@
+// celt_dec_kernel.hip -- batched opus_decode() for CELT-only 20 ms stereo packets, one lane per stream.
+//
+// Replaces opus_decode() (opus-fix/src/opus_decoder.c:758; include/opus.h:462) -> opus_decode_native ->
+// opus_decode_frame -> celt_decode_with_ec (celt/celt_decoder.c:713) for N streams at once. Decoding a
+// packet is a serial chain (range decoder -> energies -> allocation -> PVQ -> synthesis), so the mapping is
+// the one of the encoder's back phase: 64 streams share a wavefront, the working set of a lane is private
+// memory, the stream state (decode_mem, energies, post-filter) lives in HBM. First version: parity; the
+// synthesis (inverse MDCT, post-filter, de-emphasis) still runs inside the lane and is the part to move to
+// wave-per-frame / lane-per-channel kernels next.
+#define CA_LANE_FRAME 1
+#include "celt_dec.h"
+#include "opusgpu_internal.h"
+
+namespace ca {
+
+__global__ __launch_bounds__(64) void celt_decode_lane_kernel(opusgpu_celt_dec_state *states, const u8 *__restrict__ packets,
+                                                              int packet_stride, const int *__restrict__ len, i16 *__restrict__ pcm,
+                                                              int *__restrict__ ret, u32 *__restrict__ rng, int n)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n) return;
+    DecWork F;
+    DecResult r = celt_decode_frame(F, states + k, packets + (size_t)k * packet_stride, len[k], pcm + (size_t)k * FRAME * 2);
+    ret[k] = r.samples;
+    rng[k] = r.final_range;
+}
+
+// fresh decoder state (opus_decoder_create + OPUS_RESET_STATE, celt_decoder.c:1177-1190)
+__global__ void celt_dec_state_init_kernel(opusgpu_celt_dec_state *states, int n)
+{
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    u32 *w = reinterpret_cast<u32 *>(&states[i]);
+    for (int k = threadIdx.x; k < (int)(sizeof(opusgpu_celt_dec_state) / 4); k += blockDim.x) w[k] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * NB; k += blockDim.x) {
+        states[i].oldLogE[k] = -28672;
+        states[i].oldLogE2[k] = -28672;
+    }
+}
+
+}  // namespace ca
+
+extern "C" int opusgpu_celt_dec_state_size(void) { return (int)sizeof(opusgpu_celt_dec_state); }
+
+extern "C" int opusgpu_celt_dec_state_init(void *d_states, int n_streams, void *stream)
+{
+    if (n_streams < 0 || (n_streams > 0 && !d_states)) return OPUSGPU_BAD_ARG;
+    if (n_streams == 0) return OPUSGPU_OK;
+    hipLaunchKernelGGL(ca::celt_dec_state_init_kernel, dim3(n_streams), dim3(256), 0, (hipStream_t)stream,
+                       (opusgpu_celt_dec_state *)d_states, n_streams);
+    return opusgpu_check_launch();
+}
+
+extern "C" int opusgpu_decode_batch(void *d_states, const unsigned char *d_packets, int packet_stride, const int32_t *d_len,
+                                    int16_t *d_pcm, int32_t *d_ret, uint32_t *d_rng, int n_streams, void *stream)
+{
+    if (n_streams < 0) return OPUSGPU_BAD_ARG;
+    if (n_streams == 0) return OPUSGPU_OK;
+    if (!d_states || !d_packets || !d_len || !d_pcm || !d_ret || !d_rng || packet_stride <= 0) return OPUSGPU_BAD_ARG;
+    hipLaunchKernelGGL(ca::celt_decode_lane_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       (opusgpu_celt_dec_state *)d_states, d_packets, packet_stride, d_len, d_pcm, d_ret, d_rng, n_streams);
+    return opusgpu_check_launch();
+}

@@ -132,6 +132,23 @@ int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const i
                          unsigned char *d_out, int out_stride, int32_t *d_out_len, uint32_t *d_out_rng,
                          int n_frames, void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* ---- batched opus_decode(), CELT-only ------------------------------------------------------------------
+ * Replaces, for N streams at once, opus_decode() (opus-fix/src/opus_decoder.c:758, include/opus.h:462) ->
+ * opus_decode_native -> opus_decode_frame -> celt_decode_with_ec (celt/celt_decoder.c:713) for packets with
+ * TOC 0xFC (CELT-only, fullband, 20 ms, stereo, one frame). One call decodes the next packet of every stream:
+ *   d_states   device, n x opusgpu_celt_dec_state_size() bytes, initialised once with
+ *              opusgpu_celt_dec_state_init (== opus_decoder_create(48000, 2)); advanced by one frame per call.
+ *   d_packets  device, packet i at d_packets + i * packet_stride, d_len[i] bytes (as opus_decode's data, len).
+ *   d_pcm      device, int16 [n][960][2] interleaved (as opus_decode's pcm with frame_size 960).
+ *   d_ret      device, int32 [n]: 960, or a negative OPUSGPU_* code for that stream (opus_decode's return value):
+ *              OPUSGPU_UNIMPLEMENTED for other TOCs and for 1-byte packets (loss concealment / DTX).
+ *   d_rng      device, uint32 [n]: OPUS_GET_FINAL_RANGE after the packet (equals the encoder's).
+ * Asynchronous on hip_stream. */
+int opusgpu_celt_dec_state_size(void);
+int opusgpu_celt_dec_state_init(void *d_states, int n_streams, void *hip_stream);
+int opusgpu_decode_batch(void *d_states, const unsigned char *d_packets, int packet_stride, const int32_t *d_len,
+                         int16_t *d_pcm, int32_t *d_ret, uint32_t *d_rng, int n_streams, void *hip_stream);
+
 /* ---- libopus single-stream encoder API as a batch of one (plumbing; BASELINE config #1) --------------
  * Same verbs, argument meaning and return codes as opus_encoder_create / opus_encoder_ctl / opus_encode /
  * opus_encoder_destroy (opus-fix/include/opus.h:164-263; src/opus_encoder.c:482, :2031, :2007, :2491), host

@@ -137,6 +137,53 @@ if __name__ == "__main__":
     print("wrote encode_golden.npz")
 
 
+# ---- opus_decode() of packets (decoder batch) ----------------------------------------------------------
+DECODE_EXTRA_CASES = [
+    # low rates: band folding, noise fill, intensity stereo and anti-collapse are all exercised here
+    ("dec_music_32k_stream", "music", 32, 16, 21, (32000, 1, 0, 10)),
+    ("dec_noise_36k_cvbr_stream", "noise", 32, 16, 22, (36000, 1, 1, 10)),
+    ("dec_edge_40k_cbr_stream", "edge", 16, 8, 23, (40000, 0, 0, 5)),
+]
+
+
+def ref_decode(packets, lens, frames_per_stream, threads=4):
+    drv = C.CDLL(os.path.join(os.path.dirname(HERE), "..", "oracle", "_ref", "librefdrv.so"))
+    n = packets.shape[0]
+    packets = np.ascontiguousarray(packets)
+    lens = np.ascontiguousarray(lens.astype(np.int32))
+    pcm = np.zeros((n, 960, 2), np.int16)
+    rng = np.zeros(n, np.uint32)
+    ret = np.zeros(n, np.int32)
+    drv.refdrv_decode_frames(_p(packets), packets.shape[1], _p(lens), C.c_long(n), frames_per_stream, _p(pcm), _p(rng), _p(ret), threads)
+    return pcm, rng, ret
+
+
+def decode_vectors():
+    """Expected opus_decode() output (PCM, final range) for the packets of the encode cases, each stream decoded by
+    its own fresh decoder, plus a few low-rate streams encoded by the reference for the purpose."""
+    out = {}
+    enc = np.load(os.path.join(HERE, "encode_golden.npz"))
+    for name, kind, n, fps, seed, _cfg in ENCODE_CASES:
+        pcm, rng, ret = ref_decode(enc[name + "_packets"], enc[name + "_len"], fps)
+        assert (ret == 960).all() and (rng == enc[name + "_rng"]).all(), name
+        out[name + "_dpcm"] = pcm
+    for name, kind, n, fps, seed, (br, vbr, cvbr, cx) in DECODE_EXTRA_CASES:
+        pk, ln, rg = ref_encode(_Cfg(2, br, vbr, cvbr, cx, 16, 0, 1500), synth_pcm(kind, n, seed), fps)
+        pk = pk[:, :int(ln.max())]
+        pcm, rng, ret = ref_decode(pk, ln, fps)
+        assert (ret == 960).all() and (rng == rg).all(), name
+        out[name + "_packets"] = pk
+        out[name + "_len"] = ln
+        out[name + "_rng"] = rg
+        out[name + "_dpcm"] = pcm
+    return out
+
+
+if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "decode_golden.npz"), **decode_vectors())
+    print("wrote decode_golden.npz")
+
+
 # ---- SILK function-boundary records (BASELINE config #4) ---------------------------------------------
 def synth_voice(nsamples, seed, fs=16000):
     """Synthetic voiced/unvoiced speech-like mono int16 signal: glottal pulse train with slowly varying pitch

@@ -1,0 +1,101 @@
+"""GPU parity tests for the batched CELT decoder, through the C-ABI (opusgpu_decode_batch): PCM + final range
+bit-exact against (a) committed opus_decode() outputs of the compiled reference (tests/golden/decode_golden.npz),
+(b) the compiled reference itself, live, on fresh packets at several rates when oracle/_ref travelled."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import encode_cases as ec
+from test_decode_emu_cpu import decode_cases, load_decode_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ca():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import concentus_amd
+    concentus_amd.lib.load()
+    return concentus_amd
+
+
+def _gpu_decode(ca, pk, ln, fps):
+    """Streams of fps packets, every stream through its own decoder; returns pcm [n][960][2], rng [n], ret [n]."""
+    import torch
+    n = pk.shape[0]
+    ns = n // fps
+    dec = ca.OpusDecoderBatch(ns)
+    pcm = np.zeros((n, 960, 2), np.int16)
+    rng = np.zeros(n, np.uint32)
+    ret = np.zeros(n, np.int32)
+    p3 = pk.reshape(ns, fps, pk.shape[1])
+    l2 = ln.reshape(ns, fps)
+    for f in range(fps):
+        o, r = dec.decode(torch.from_numpy(np.ascontiguousarray(p3[:, f])).cuda(), torch.from_numpy(np.ascontiguousarray(l2[:, f])).cuda())
+        torch.cuda.synchronize()
+        idx = np.arange(ns) * fps + f
+        pcm[idx] = o.cpu().numpy()
+        ret[idx] = r.cpu().numpy()
+        rng[idx] = dec.ctl(4031).cpu().numpy().view(np.uint32)
+    return pcm, rng, ret
+
+
+@pytest.mark.parametrize("case", decode_cases(), ids=lambda c: c[0])
+def test_gpu_decoder_matches_golden_pcm(ca, case):
+    name, fps, from_encode = case
+    pk, ln, rg, want = load_decode_case(name, from_encode)
+    pcm, rng, ret = _gpu_decode(ca, pk, ln, fps)
+    assert (ret == 960).all()
+    assert np.array_equal(rng, rg)
+    assert np.array_equal(pcm, want), "PCM differs at frame %d" % int(np.nonzero((pcm != want).reshape(len(ln), -1).any(1))[0][0])
+
+
+@pytest.mark.parametrize("kind,n,fps,cfgvals", [
+    ("music", 2048, 16, (32000, 1, 0, 10)),
+    ("noise", 1024, 8, (36000, 1, 1, 10)),
+    ("music", 1024, 1, (96000, 1, 0, 10)),
+    ("noise", 512, 16, (256000, 0, 0, 10)),
+    ("edge", 256, 8, (40000, 1, 0, 5)),
+])
+def test_gpu_decoder_matches_live_reference(ca, kind, n, fps, cfgvals):
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("oracle/_ref did not travel")
+    gm = ec.golden_module()
+    br, vbr, cvbr, cx = cfgvals
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, br, vbr, cvbr, cx, 16, 0, 1500), gm.synth_pcm(kind, n, 555 + n + fps), fps, threads=8)
+    pk = np.ascontiguousarray(pk[:, :int(ln.max()) + 3 & ~3])
+    want, wrng, wret = gm.ref_decode(pk, ln, fps, threads=8)
+    assert (wret == 960).all()
+    pcm, rng, ret = _gpu_decode(ca, pk, ln.astype(np.int32), fps)
+    assert (ret == 960).all()
+    assert np.array_equal(rng, wrng)
+    assert np.array_equal(pcm, want)
+
+
+def test_gpu_encode_then_decode_round_trip(ca):
+    """GPU encoder -> GPU decoder on 4096 independent frames: the decoder's final range equals the encoder's for
+    every packet (the reference's own consistency check, tests/test_opus_encode.c:305-306)."""
+    import torch
+    rng = np.random.default_rng(11)
+    pcm = torch.from_numpy(rng.integers(-8192, 8192, size=(4096, 960, 2), dtype=np.int16)).cuda()
+    pk, ln, erng = ca.encode_independent(pcm)
+    out, ret, drng = ca.decode_independent(pk, ln)
+    torch.cuda.synchronize()
+    assert (ret.cpu().numpy() == 960).all()
+    assert np.array_equal(erng.cpu().numpy(), drng.cpu().numpy())
+
+
+def test_gpu_decoder_rejects_what_it_does_not_implement(ca):
+    import torch
+    pk = np.zeros((3, 8), np.uint8)
+    pk[0, 0] = 0x78
+    pk[1, 0] = 0xFC
+    pk[2, 0] = 0xFD
+    ln = np.array([8, 1, 8], np.int32)
+    _pcm, ret, _r = ca.decode_independent(torch.from_numpy(pk).cuda(), torch.from_numpy(ln).cuda())
+    assert ret.cpu().numpy().tolist() == [-5, -5, -5]
