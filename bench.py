@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk"])
+    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "decode"])
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL packet gather (N > 1)")
@@ -140,6 +140,29 @@ def cpu_baseline_celt(pcm_sample, cfgvals):
     one, multi = _time_cpu(run, n, cores)
     return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
             "sample": "%d independent frames per pass through opus-fix opus_encode() (create+ctl+encode per frame), "
+                      "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+
+
+def cpu_baseline_decode(pk, ln):
+    """The reference's own opus_decode() over a bounded sample: fresh opus_decoder_create + one opus_decode per packet."""
+    refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
+    if not os.path.exists(refdrv):
+        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
+                "sample": "oracle/_ref/librefdrv.so did not travel; no CPU baseline"}
+    drv = C.CDLL(refdrv)
+    cores = host_threads()
+    n = pk.shape[0]
+    pk = np.ascontiguousarray(pk)
+    ln = np.ascontiguousarray(ln.astype(np.int32))
+    pcm = np.zeros((n, 960, 2), np.int16)
+    rng = np.zeros(n, np.uint32)
+    ret = np.zeros(n, np.int32)
+
+    def run(threads):
+        drv.refdrv_decode_frames(_p(pk), pk.shape[1], _p(ln), C.c_long(n), 1, _p(pcm), _p(rng), _p(ret), threads)
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+            "sample": "%d independent packets per pass through opus-fix opus_decode() (create+decode per packet), "
                       "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
 
 
@@ -240,6 +263,42 @@ def main():
         dtype = "int32"
         extra = {"other_kernel_ms": round(bwd_ms if kname.startswith("mdct_forward") else fwd_ms, 5)}
         cpu = (lambda: cpu_baseline_mdct(host[:256]))
+    elif a.workload == "decode":
+        # packets of config #3 (GPU-encoded, bit-exact with the reference) decoded by fresh decoders
+        F = a.frames or 65536
+        steps = a.steps or 5
+        warm = a.warmup if a.warmup is not None else 1
+        rng = np.random.default_rng(3 + rank)
+        host = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
+        pk, ln, _r = ca.encode_independent(torch.from_numpy(host).to(dev), ca.default_config(2, 96000))
+        torch.cuda.synchronize()
+        dec = ca.OpusDecoderBatch(F, device=dev)
+        for _ in range(warm):
+            dec.reset()
+            pcm, ret = dec.decode(pk, ln)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            dec.reset()                           # every packet is the first of its own stream (fresh decoder)
+            ev[k][0].record()
+            pcm, ret = dec.decode(pk, ln)
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        assert (ret.cpu().numpy() == 960).all(), "decoder reported an error"
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        mean_len = float(ln.float().mean().item())
+        kname = "celt_decode_lane_kernel"
+        kbytes = int(F * (mean_len + 4 + 3840 + 8))
+        metric = "48kHz stereo 20ms CELT frames decoded/sec"
+        workload = ("%d independent CELT-only 20 ms stereo packets per GPU (config #3's packets, mean %.1f B), each through a "
+                    "fresh decoder (state reset included in the step), PCM bit-exact vs FIXED_POINT opus_decode()" % (F, mean_len))
+        dtype = "int16/int32 fixed-point"
+        extra = {"mean_packet_bytes": round(mean_len, 2)}
+        pk_h, ln_h = pk[:4096].cpu().numpy(), ln[:4096].cpu().numpy()
+        cpu = (lambda: cpu_baseline_decode(pk_h, ln_h))
     elif a.workload == "silk":
         F = a.frames or 65536
         steps = a.steps or 20
