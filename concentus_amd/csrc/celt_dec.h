@@ -20,16 +20,20 @@ enum { DEC_BUF = 2048, DEC_MEM = DEC_BUF + OVL };           // DECODE_BUFFER_SIZ
 
 // per-packet working set (host memory in the emulation, private/global memory on the GPU)
 struct __attribute__((aligned(16))) DecWork {
-    i16 X[2 * FRAME];              // decoded normalised bands X[c*960 + j]
+    i16 *X;                        // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
     i16 norm[2 * 624];             // folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel
-    i32 freq[FRAME];
-    int2 f2[480];
     i32 iy[176];
     i16 tmp[176];
     i32 offsets[NB], cap[NB], pulses[NB], fine_quant[NB], fine_priority[NB], tf_res[NB];
     i32 bits1[NB], bits2[NB], thresh[NB], trim_offset[NB];
     u8 collapse_masks[2 * NB];
     void *diag;
+};
+
+// working set of the synthesis (one wavefront per stream: LDS; host memory in the emulation)
+struct __attribute__((aligned(16))) SynthLds {
+    i32 freq[FRAME];
+    int2 f2[480];
 };
 
 CA_DEV u32 celt_lcg_rand(u32 seed) { return 1664525u * seed + 1013904223u; }                   // bands.c:63
@@ -722,17 +726,14 @@ CA_DEV void anti_collapse_dec(D &F, const i16 *logE, const i16 *prev1logE, const
     }
 }
 
-// denormalise_bands (bands.c:169-238) for one channel, start 0, end 21, downsample 1
+// denormalise_bands (bands.c:169-238) for one channel, start 0, end 21, downsample 1; lanes share a band's bins
 CA_DEV void denormalise_bands_dec(const i16 *X, i32 *freq, const i16 *bandLogE, int silence)
 {
     const int M = M8, N = FRAME;
     int end = NB, bound = M * CLT_eband5ms[NB];
     if (silence) { bound = 0; end = 0; }
-    i32 *f = freq;
-    const i16 *x = X;
     for (int i = 0; i < end; i++) {
-        int j = M * CLT_eband5ms[i];
-        const int band_end = M * CLT_eband5ms[i + 1];
+        const int j0 = M * CLT_eband5ms[i], j1 = M * CLT_eband5ms[i + 1];
         i32 lg = add16(bandLogE[i], shl16(CLT_eMeans[i], 6));
         int shift = 16 - (lg >> 10);
         i32 g;
@@ -740,12 +741,13 @@ CA_DEV void denormalise_bands_dec(const i16 *X, i32 *freq, const i16 *bandLogE, 
         else g = celt_exp2_frac(lg & 1023);
         if (shift < 0) {
             if (shift < -2) { g = 32767; shift = -2; }
-            do { *f++ = shl32(mul16_16(*x++, g), -shift); } while (++j < band_end);
+            for (int j = j0 + lane(); j < j1; j += LANES) freq[j] = shl32(mul16_16(X[j], g), -shift);
         } else {
-            do { *f++ = mul16_16(*x++, g) >> shift; } while (++j < band_end);
+            for (int j = j0 + lane(); j < j1; j += LANES) freq[j] = mul16_16(X[j], g) >> shift;
         }
     }
-    for (int k = bound; k < N; k++) freq[k] = 0;
+    for (int k = bound + lane(); k < N; k += LANES) freq[k] = 0;
+    wave_sync();
 }
 
 // comb_filter (celt.c:183-237) as the decoder uses it: y == x, in place, looking back into the history
@@ -790,13 +792,17 @@ CA_DEV void comb_filter_inplace_dec(i32 *x, int T0, int T1, int N, i32 g0, i32 g
 
 struct DecResult { int samples; u32 final_range; };
 
-// opus_decode() of one CELT-only 20 ms stereo packet (code 0). data: the whole packet incl. TOC.
+// Stage 1 of opus_decode() of one CELT-only 20 ms stereo packet (code 0; data: the whole packet incl. TOC):
+// everything up to the normalised bands (one lane per stream). Leaves X and the frame parameters in the state's
+// hand-off fields; st->mid_valid == 0 tells the later stages to leave this stream alone.
 template <class D>
-CA_DEV DecResult celt_decode_frame(D &F, opusgpu_celt_dec_state *st, const u8 *data, int len, i16 *pcm)
+CA_DEV DecResult celt_decode_front(D &F, opusgpu_celt_dec_state *st, const u8 *data, int len)
 {
     DecResult res;
     res.samples = OPUSGPU_INVALID_PACKET;
     res.final_range = 0;
+    st->mid_valid = 0;
+    F.X = st->mid_X;
     const int C = 2, N = FRAME, LM = LM3, M = M8;
     if (len < 2) { res.samples = len < 1 ? OPUSGPU_BAD_ARG : OPUSGPU_UNIMPLEMENTED; return res; }   // len == 1: PLC/DTX, not implemented
     // TOC (src/opus_decoder.c, opus_packet_parse_impl): CELT-only (0x80), fullband (3 << 5), 20 ms (3 << 3), stereo (4), code 0
@@ -871,11 +877,6 @@ CA_DEV DecResult celt_decode_frame(D &F, opusgpu_celt_dec_state *st, const u8 *d
     AllocOut al = compute_allocation_wave(F, dec, C, alloc_trim, 0, 0, bits, 0, 0);
     unquant_fine_energy_dec(oldBandE, F.fine_quant, dec, C);
 
-    i32 *decode_mem[2] = {st->decode_mem[0], st->decode_mem[1]};
-    i32 *out_syn[2] = {decode_mem[0] + DEC_BUF - N, decode_mem[1] + DEC_BUF - N};
-    for (int c = 0; c < C; c++)                                                                 // OPUS_MOVE(decode_mem, decode_mem+N, 2048-N+overlap/2)
-        for (int k = 0; k < DEC_BUF - N + OVL / 2; k++) decode_mem[c][k] = decode_mem[c][k + N];
-
     u32 rng = st->rng;
     quant_all_bands_dec(F, dec, shortBlocks, spread_decision, al.dual_stereo, al.intensity,
                         len * (8 << BITRES) - anti_collapse_rsv, al.balance, al.codedBands, &rng);
@@ -887,33 +888,19 @@ CA_DEV DecResult celt_decode_frame(D &F, opusgpu_celt_dec_state *st, const u8 *d
     if (silence)
         for (int i = 0; i < C * NB; i++) oldBandE[i] = -28672;
 
-    // celt_synthesis (celt_decoder.c:287-350), C == CC == 2
-    for (int c = 0; c < C; c++) {
-        denormalise_bands_dec(F.X + c * N, F.freq, oldBandE + c * NB, silence);
-        if (isTransient) {
-            const MdctTab T = mdct_global_tab<3>();
-            mdct_backward_wave<3, 8>(F.freq, 1, F.f2, out_syn[c], T, lane());
-        } else {
-            const MdctTab T = mdct_global_tab<0>();
-            mdct_backward_wave<0, 1>(F.freq, 1, F.f2, out_syn[c], T, lane());
-        }
-    }
-    // post-filter
-    for (int c = 0; c < C; c++) {
-        st->postfilter_period = imax(st->postfilter_period, MINP);
-        st->postfilter_period_old = imax(st->postfilter_period_old, MINP);
-        comb_filter_inplace_dec(out_syn[c], st->postfilter_period_old, st->postfilter_period, 120, st->postfilter_gain_old,
-                                st->postfilter_gain, st->postfilter_tapset_old, st->postfilter_tapset);
-        comb_filter_inplace_dec(out_syn[c] + 120, st->postfilter_period, postfilter_pitch, N - 120, st->postfilter_gain,
-                                postfilter_gain, st->postfilter_tapset, postfilter_tapset);
-    }
-    st->postfilter_period_old = st->postfilter_period;
-    st->postfilter_gain_old = st->postfilter_gain;
-    st->postfilter_tapset_old = st->postfilter_tapset;
-    st->postfilter_period = postfilter_pitch;
+    // hand the frame over to the synthesis and post-filter stages
+    st->mid_valid = 1;
+    st->mid_isTransient = isTransient;
+    st->mid_silence = silence;
+    st->postfilter_period = imax(st->postfilter_period, MINP);
+    st->postfilter_period_old = imax(st->postfilter_period_old, MINP);
+    st->mid_pf_period_old = st->postfilter_period_old; st->mid_pf_period = st->postfilter_period; st->mid_pf_period_new = postfilter_pitch;
+    st->mid_pf_gain_old = st->postfilter_gain_old; st->mid_pf_gain = st->postfilter_gain; st->mid_pf_gain_new = postfilter_gain;
+    st->mid_pf_tapset_old = st->postfilter_tapset_old; st->mid_pf_tapset = st->postfilter_tapset; st->mid_pf_tapset_new = postfilter_tapset;
+    st->postfilter_period = postfilter_pitch;                                                    // celt_decoder.c:1000-1011, LM != 0
     st->postfilter_gain = postfilter_gain;
     st->postfilter_tapset = postfilter_tapset;
-    st->postfilter_period_old = st->postfilter_period;                                          // LM != 0
+    st->postfilter_period_old = st->postfilter_period;
     st->postfilter_gain_old = st->postfilter_gain;
     st->postfilter_tapset_old = st->postfilter_tapset;
 
@@ -926,26 +913,79 @@ CA_DEV DecResult celt_decode_frame(D &F, opusgpu_celt_dec_state *st, const u8 *d
     }
     st->rng = dec.rng;
 
-    // deemphasis (celt_decoder.c:183-285): coef0 = 27853, no downsampling, no accumulation
-    for (int c = 0; c < C; c++) {
-        i32 m = st->preemph_memD[c];
-        const i32 *x = out_syn[c];
-        for (int j = 0; j < N; j++) {
-            i32 t = add32(x[j], m);
-            m = mul16_32_q15(27853, t);
-            i32 v = pshr32(t, 12);
-            v = imax(v, -32768);
-            v = imin(v, 32767);
-            pcm[j * C + c] = (i16)v;
-        }
-        st->preemph_memD[c] = m;
-    }
     st->loss_count = 0;
     if (ec_tell(dec) > 8 * len) { res.samples = OPUSGPU_INTERNAL_ERROR; return res; }
     if (dec.error) st->error = 1;
     res.samples = N;
     res.final_range = dec.rng;
     return res;
+}
+
+// Stage 2 (one wavefront per stream; LANES == 1 in the emulation): celt_synthesis (celt_decoder.c:287-350) for
+// C == CC == 2 -- shift the history, denormalise, inverse MDCT with TDAC into decode_mem.
+template <class S>
+CA_DEV void celt_decode_synth(S &L, opusgpu_celt_dec_state *st)
+{
+    if (!uni(st->mid_valid)) return;
+    const int N = FRAME;
+    const int isTransient = uni(st->mid_isTransient), silence = uni(st->mid_silence);
+    for (int c = 0; c < 2; c++) {
+        i32 *mem = st->decode_mem[c];
+        // OPUS_MOVE(decode_mem, decode_mem + N, DECODE_BUFFER_SIZE - N + overlap/2): ascending blocks, each read
+        // before it is written (the source runs 960 ahead of the destination)
+        for (int k0 = 0; k0 < DEC_BUF - N + OVL / 2; k0 += LANES) {
+            const int k = k0 + lane();
+            i32 v = 0;
+            if (k < DEC_BUF - N + OVL / 2) v = mem[k + N];
+            wave_sync();
+            if (k < DEC_BUF - N + OVL / 2) mem[k] = v;
+        }
+        wave_sync();
+        i32 *out_syn = mem + DEC_BUF - N;
+        denormalise_bands_dec(st->mid_X + c * N, L.freq, st->oldBandE + c * NB, silence);
+        if (isTransient) {
+            const MdctTab T = mdct_global_tab<3>();
+            mdct_backward_wave<3, 8>(L.freq, 1, L.f2, out_syn, T, lane());
+        } else {
+            const MdctTab T = mdct_global_tab<0>();
+            mdct_backward_wave<0, 1>(L.freq, 1, L.f2, out_syn, T, lane());
+        }
+        wave_sync();
+    }
+}
+
+// Stage 3 (one lane per (stream, channel)): the pitch post-filter in place on the synthesis output
+// (celt_decoder.c:983-998) and deemphasis to interleaved int16 (celt_decoder.c:183-285: coef0 = 27853, no
+// downsampling, no accumulation).
+CA_DEV void celt_decode_post_channel(opusgpu_celt_dec_state *st, int c, i16 *pcm)
+{
+    if (!st->mid_valid) return;
+    const int N = FRAME;
+    i32 *out_syn = st->decode_mem[c] + DEC_BUF - N;
+    comb_filter_inplace_dec(out_syn, st->mid_pf_period_old, st->mid_pf_period, 120, st->mid_pf_gain_old, st->mid_pf_gain,
+                            st->mid_pf_tapset_old, st->mid_pf_tapset);
+    comb_filter_inplace_dec(out_syn + 120, st->mid_pf_period, st->mid_pf_period_new, N - 120, st->mid_pf_gain, st->mid_pf_gain_new,
+                            st->mid_pf_tapset, st->mid_pf_tapset_new);
+    i32 m = st->preemph_memD[c];
+    for (int j = 0; j < N; j++) {
+        i32 t = add32(out_syn[j], m);
+        m = mul16_32_q15(27853, t);
+        i32 v = pshr32(t, 12);
+        v = imax(v, -32768);
+        v = imin(v, 32767);
+        pcm[j * 2 + c] = (i16)v;
+    }
+    st->preemph_memD[c] = m;
+}
+
+// all three stages, for the host emulation
+template <class D, class S>
+CA_DEV DecResult celt_decode_frame(D &F, S &L, opusgpu_celt_dec_state *st, const u8 *data, int len, i16 *pcm)
+{
+    DecResult r = celt_decode_front(F, st, data, len);
+    celt_decode_synth(L, st);
+    for (int c = 0; c < 2; c++) celt_decode_post_channel(st, c, pcm);
+    return r;
 }
 
 }  // namespace ca

@@ -2,11 +2,12 @@
 //
 // Replaces opus_decode() (opus-fix/src/opus_decoder.c:758; include/opus.h:462) -> opus_decode_native ->
 // opus_decode_frame -> celt_decode_with_ec (celt/celt_decoder.c:713) for N streams at once. Decoding a
-// packet is a serial chain (range decoder -> energies -> allocation -> PVQ -> synthesis), so the mapping is
-// the one of the encoder's back phase: 64 streams share a wavefront, the working set of a lane is private
-// memory, the stream state (decode_mem, energies, post-filter) lives in HBM. First version: parity; the
-// synthesis (inverse MDCT, post-filter, de-emphasis) still runs inside the lane and is the part to move to
-// wave-per-frame / lane-per-channel kernels next.
+// packet is a serial chain (range decoder -> energies -> allocation -> PVQ), so that part uses the mapping of
+// the encoder's back phase: 64 streams share a wavefront (celt_decode_lane_kernel, this file, LANES == 1 build).
+// The synthesis has data parallelism inside a frame (denormalisation, inverse MDCT) and runs one wavefront per
+// stream (celt_dec_synth_kernel.hip); the post-filter and de-emphasis are recurrences per channel and run one
+// lane per (stream, channel) (celt_decode_post_kernel, this file). The stream state (decode_mem, energies,
+// post-filter) and the hand-off between the three kernels live in opusgpu_celt_dec_state in HBM.
 #define CA_LANE_FRAME 1
 #include "celt_dec.h"
 #include "opusgpu_internal.h"
@@ -14,15 +15,23 @@
 namespace ca {
 
 __global__ __launch_bounds__(64) void celt_decode_lane_kernel(opusgpu_celt_dec_state *states, const u8 *__restrict__ packets,
-                                                              int packet_stride, const int *__restrict__ len, i16 *__restrict__ pcm,
+                                                              int packet_stride, const int *__restrict__ len,
                                                               int *__restrict__ ret, u32 *__restrict__ rng, int n)
 {
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n) return;
     DecWork F;
-    DecResult r = celt_decode_frame(F, states + k, packets + (size_t)k * packet_stride, len[k], pcm + (size_t)k * FRAME * 2);
+    DecResult r = celt_decode_front(F, states + k, packets + (size_t)k * packet_stride, len[k]);
     ret[k] = r.samples;
     rng[k] = r.final_range;
+}
+
+__global__ __launch_bounds__(256) void celt_decode_post_kernel(opusgpu_celt_dec_state *states, i16 *__restrict__ pcm, int n)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = t >> 1, c = t & 1;
+    if (k >= n) return;
+    celt_decode_post_channel(states + k, c, pcm + (size_t)k * FRAME * 2);
 }
 
 // fresh decoder state (opus_decoder_create + OPUS_RESET_STATE, celt_decoder.c:1177-1190)
@@ -41,6 +50,8 @@ __global__ void celt_dec_state_init_kernel(opusgpu_celt_dec_state *states, int n
 
 }  // namespace ca
 
+extern "C" void opusgpu_launch_dec_synth(void *states, int n, hipStream_t s);
+
 extern "C" int opusgpu_celt_dec_state_size(void) { return (int)sizeof(opusgpu_celt_dec_state); }
 
 extern "C" int opusgpu_celt_dec_state_init(void *d_states, int n_streams, void *stream)
@@ -58,7 +69,11 @@ extern "C" int opusgpu_decode_batch(void *d_states, const unsigned char *d_packe
     if (n_streams < 0) return OPUSGPU_BAD_ARG;
     if (n_streams == 0) return OPUSGPU_OK;
     if (!d_states || !d_packets || !d_len || !d_pcm || !d_ret || !d_rng || packet_stride <= 0) return OPUSGPU_BAD_ARG;
-    hipLaunchKernelGGL(ca::celt_decode_lane_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       (opusgpu_celt_dec_state *)d_states, d_packets, packet_stride, d_len, d_pcm, d_ret, d_rng, n_streams);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ca::celt_decode_lane_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, s,
+                       (opusgpu_celt_dec_state *)d_states, d_packets, packet_stride, d_len, d_ret, d_rng, n_streams);
+    opusgpu_launch_dec_synth(d_states, n_streams, s);
+    hipLaunchKernelGGL(ca::celt_decode_post_kernel, dim3((2 * n_streams + 255) / 256), dim3(256), 0, s,
+                       (opusgpu_celt_dec_state *)d_states, d_pcm, n_streams);
     return opusgpu_check_launch();
 }

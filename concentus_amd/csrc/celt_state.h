@@ -72,6 +72,13 @@ typedef struct opusgpu_celt_dec_state {
     int16_t oldLogE2[2 * OPUSGPU_CELT_NBANDS];
     int16_t backgroundLogE[2 * OPUSGPU_CELT_NBANDS];
     int32_t decode_mem[2][OPUSGPU_DECODE_BUFFER_SIZE + OPUSGPU_CELT_OVERLAP];
+    /* hand-off between the kernels of one opusgpu_decode_batch call (not stream state): the decoded normalised
+     * bands, what the synthesis and post-filter kernels need to know about the frame, and the per-stream result */
+    int16_t mid_X[2 * OPUSGPU_CELT_FRAME];
+    int32_t mid_valid, mid_isTransient, mid_silence;
+    int32_t mid_pf_period_old, mid_pf_period, mid_pf_period_new;
+    int32_t mid_pf_gain_old, mid_pf_gain, mid_pf_gain_new;
+    int32_t mid_pf_tapset_old, mid_pf_tapset, mid_pf_tapset_new;
 } opusgpu_celt_dec_state;
 
 #ifdef __cplusplus

@@ -124,15 +124,18 @@ extern "C" int emu_celt_decode_frames(const unsigned char *packets, int stride, 
                                       int frames_per_stream, int16_t *pcm, uint32_t *rng, int *ret)
 {
     DecWork *F = (DecWork *)aligned_alloc(64, sizeof(DecWork) + 64);
+    SynthLds *L = (SynthLds *)aligned_alloc(64, sizeof(SynthLds) + 64);
     opusgpu_celt_dec_state *st = (opusgpu_celt_dec_state *)aligned_alloc(64, sizeof(opusgpu_celt_dec_state) + 64);
     for (int n = 0; n < nframes; n++) {
         if (n % frames_per_stream == 0) dec_state_reset(st);
         memset(F, 0xAB, sizeof(DecWork));
-        DecResult r = celt_decode_frame(*F, st, packets + (size_t)n * stride, len[n], pcm + (size_t)n * 960 * 2);
+        memset(L, 0xAB, sizeof(SynthLds));
+        DecResult r = celt_decode_frame(*F, *L, st, packets + (size_t)n * stride, len[n], pcm + (size_t)n * 960 * 2);
         ret[n] = r.samples;
         rng[n] = r.final_range;
     }
     free(F);
+    free(L);
     free(st);
     return 0;
 }
