@@ -230,11 +230,19 @@ CA_DEV i32 cwrsi_dec(int n, int k, u32 i, i32 *y)
 CA_DEV void renormalise_vector_dec(i16 *X, int N, i32 gain)                                     // vq.c:349-374
 {
     i32 E = 1;
+#pragma unroll 8
     for (int i = 0; i < N; i++) E = mac16_16(E, X[i], X[i]);
     int k = celt_ilog2(E) >> 1;
     i32 t = vshr32(E, 2 * (k - 7));
     i32 g = (i16)mul16_16_p15(celt_rsqrt_norm(t), gain);
-    for (int i = 0; i < N; i++) X[i] = (i16)pshr32(mul16_16(g, X[i]), k + 1);
+    for (int i = 0; i < N; i += 8) {                 // eight loads in flight before the first store
+        i32 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = i + u < N ? (i32)X[i + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i + u < N) X[i + u] = (i16)pshr32(mul16_16(g, v[u]), k + 1);
+    }
 }
 
 template <class D>
@@ -247,7 +255,12 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
         int k = celt_ilog2(Ryy) >> 1;
         i32 t = vshr32(Ryy, 2 * (k - 7));
         i32 g = (i16)mul16_16_p15(celt_rsqrt_norm(t), gain);
-        for (int i = 0; i < N; i++) X[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
+        {
+            i16 *__restrict__ xo = X;
+            const i32 *__restrict__ yi = iy;
+#pragma unroll 8
+            for (int i = 0; i < N; i++) xo[i] = (i16)pshr32(mul16_16(g, yi[i]), k + 1);
+        }
     }
     exp_rotation_inv(X, N, B, K, spread);
     if (B <= 1) return 1;                                                                     // extract_collapse_mask
@@ -392,10 +405,13 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
                     }
                     cm = cm_mask;
                 } else {
+                    i16 *__restrict__ xo = X;
+                    const i16 *__restrict__ lb = lowband;
+#pragma unroll 8
                     for (int j = 0; j < N; j++) {
                         ctx.seed = celt_lcg_rand(ctx.seed);
                         i32 t = (ctx.seed & 0x8000) ? 4 : -4;                                 // QCONST16(1.0f/256, 10)
-                        X[j] = (i16)(lowband[j] + t);
+                        xo[j] = (i16)(lb[j] + t);
                     }
                     cm = (unsigned)fill;
                 }
@@ -415,13 +431,26 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
 CA_DEV void haar1_ref(i16 *X, int N0, int stride)                                               // bands.c:580-594
 {
     N0 >>= 1;
-    for (int i = 0; i < stride; i++)
-        for (int j = 0; j < N0; j++) {
+    for (int i = 0; i < stride; i++) {
+        int j = 0;
+        for (; j + 4 <= N0; j += 4) {                // four butterflies loaded before the first store
+            i32 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = X[stride * 2 * (j + u) + i]; b[u] = X[stride * (2 * (j + u) + 1) + i]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                i32 t1 = mul16_16(23170, a[u]), t2 = mul16_16(23170, b[u]);
+                X[stride * 2 * (j + u) + i] = (i16)pshr32(add32(t1, t2), 15);
+                X[stride * (2 * (j + u) + 1) + i] = (i16)pshr32(sub32(t1, t2), 15);
+            }
+        }
+        for (; j < N0; j++) {
             i32 t1 = mul16_16(23170, X[stride * 2 * j + i]);
             i32 t2 = mul16_16(23170, X[stride * (2 * j + 1) + i]);
             X[stride * 2 * j + i] = (i16)pshr32(add32(t1, t2), 15);
             X[stride * (2 * j + 1) + i] = (i16)pshr32(sub32(t1, t2), 15);
         }
+    }
 }
 
 template <class D>
@@ -430,9 +459,21 @@ CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hada
     i16 *tmp = F.tmp;
     const int N = N0 * stride;
     const u8 *ordery = CLT_ordery_table + stride - 2;
-    for (int i = 0; i < stride; i++)
-        for (int j = 0; j < N0; j++) tmp[(hadamard ? ordery[i] : i) * N0 + j] = X[j * stride + i];
-    for (int k = 0; k < N; k++) X[k] = tmp[k];
+    {
+        i16 *__restrict__ t = tmp;
+        const i16 *__restrict__ x = X;
+        for (int i = 0; i < stride; i++) {
+            const int d = hadamard ? ordery[i] : i;
+#pragma unroll 4
+            for (int j = 0; j < N0; j++) t[d * N0 + j] = x[j * stride + i];
+        }
+    }
+    {
+        i16 *__restrict__ x = X;
+        const i16 *__restrict__ t = tmp;
+#pragma unroll 8
+        for (int k = 0; k < N; k++) x[k] = t[k];
+    }
 }
 
 template <class D>
@@ -441,9 +482,21 @@ CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadama
     i16 *tmp = F.tmp;
     const int N = N0 * stride;
     const u8 *ordery = CLT_ordery_table + stride - 2;
-    for (int i = 0; i < stride; i++)
-        for (int j = 0; j < N0; j++) tmp[j * stride + i] = X[(hadamard ? ordery[i] : i) * N0 + j];
-    for (int k = 0; k < N; k++) X[k] = tmp[k];
+    {
+        i16 *__restrict__ t = tmp;
+        const i16 *__restrict__ x = X;
+        for (int i = 0; i < stride; i++) {
+            const int d = hadamard ? ordery[i] : i;
+#pragma unroll 4
+            for (int j = 0; j < N0; j++) t[j * stride + i] = x[d * N0 + j];
+        }
+    }
+    {
+        i16 *__restrict__ x = X;
+        const i16 *__restrict__ t = tmp;
+#pragma unroll 8
+        for (int k = 0; k < N; k++) x[k] = t[k];
+    }
 }
 
 // quant_band_n1 (bands.c:819-862), encode = 0
@@ -476,7 +529,12 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     if (N == 1) return quant_band_n1_dec(dec, ctx, X, nullptr, lowband_out);
     if (tf_change > 0) recombine = tf_change;
     if (lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
-        for (int j = 0; j < N; j++) lowband_scratch[j] = lowband[j];
+        {
+            i16 *__restrict__ d = lowband_scratch;
+            const i16 *__restrict__ sQ = lowband;
+#pragma unroll 8
+            for (int j = 0; j < N; j++) d[j] = sQ[j];
+        }
         lowband = lowband_scratch;
     }
     for (int k = 0; k < recombine; k++) {
@@ -514,7 +572,12 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     B <<= recombine;
     if (lowband_out) {
         i32 n = (i16)celt_sqrt(shl32(N0, 22));
-        for (int j = 0; j < N0; j++) lowband_out[j] = (i16)mul16_16_q15(n, X[j]);
+        {
+            i16 *__restrict__ d = lowband_out;
+            const i16 *__restrict__ sQ = X;
+#pragma unroll 8
+            for (int j = 0; j < N0; j++) d[j] = (i16)mul16_16_q15(n, sQ[j]);
+        }
     }
     cm &= (1u << B) - 1;
     return cm;

@@ -9,6 +9,7 @@
 // lane per (stream, channel) (celt_decode_post_kernel, this file). The stream state (decode_mem, energies,
 // post-filter) and the hand-off between the three kernels live in opusgpu_celt_dec_state in HBM.
 #define CA_LANE_FRAME 1
+#include "celt_lane_tables.h"
 #include "celt_dec.h"
 #include "opusgpu_internal.h"
 
@@ -18,6 +19,7 @@ __global__ __launch_bounds__(64) void celt_decode_lane_kernel(opusgpu_celt_dec_s
                                                               int packet_stride, const int *__restrict__ len,
                                                               int *__restrict__ ret, u32 *__restrict__ rng, int n)
 {
+    fill_lds_tables();
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n) return;
     DecWork F;
