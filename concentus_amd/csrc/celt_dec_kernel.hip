@@ -72,10 +72,16 @@ extern "C" int opusgpu_decode_batch(void *d_states, const unsigned char *d_packe
     if (n_streams == 0) return OPUSGPU_OK;
     if (!d_states || !d_packets || !d_len || !d_pcm || !d_ret || !d_rng || packet_stride <= 0) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_LANE, s);
     hipLaunchKernelGGL(ca::celt_decode_lane_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, s,
                        (opusgpu_celt_dec_state *)d_states, d_packets, packet_stride, d_len, d_ret, d_rng, n_streams);
+    opusgpu_timing_end(slot, s);
+    slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_SYNTH, s);
     opusgpu_launch_dec_synth(d_states, n_streams, s);
+    opusgpu_timing_end(slot, s);
+    slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_POST, s);
     hipLaunchKernelGGL(ca::celt_decode_post_kernel, dim3((2 * n_streams + 255) / 256), dim3(256), 0, s,
                        (opusgpu_celt_dec_state *)d_states, d_pcm, n_streams);
+    opusgpu_timing_end(slot, s);
     return opusgpu_check_launch();
 }

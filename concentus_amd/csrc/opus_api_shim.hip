@@ -154,3 +154,100 @@ extern "C" int32_t opusgpu_encode(OpusGpuEncoder *st, const int16_t *pcm, int fr
     if (len > 0) memcpy(data, host, (size_t)(len < max_data_bytes ? len : max_data_bytes));
     return len;
 }
+
+// ---- decoder side: opus_decoder_create / opus_decode / opus_decoder_ctl / opus_decoder_destroy as a batch of one --
+struct OpusGpuDecoder {
+    void *d_state;
+    unsigned char *d_pkt;
+    int32_t *d_len, *d_ret;
+    uint32_t *d_rng;
+    int16_t *d_pcm;
+    uint32_t final_range;
+    hipStream_t stream;
+};
+
+static void free_all(OpusGpuDecoder *st)
+{
+    if (!st) return;
+    if (st->d_state) (void)hipFree(st->d_state);
+    if (st->d_pkt) (void)hipFree(st->d_pkt);
+    if (st->d_len) (void)hipFree(st->d_len);
+    if (st->d_ret) (void)hipFree(st->d_ret);
+    if (st->d_rng) (void)hipFree(st->d_rng);
+    if (st->d_pcm) (void)hipFree(st->d_pcm);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    free(st);
+}
+
+extern "C" OpusGpuDecoder *opusgpu_decoder_create(int32_t Fs, int channels, int *error)
+{
+    int err = OPUSGPU_OK;
+    OpusGpuDecoder *st = nullptr;
+    if ((Fs != 48000 && Fs != 24000 && Fs != 16000 && Fs != 12000 && Fs != 8000) || (channels != 1 && channels != 2))
+        err = OPUSGPU_BAD_ARG;                                                   // src/opus_decoder.c:127-133
+    else if (Fs != 48000 || channels != 2)
+        err = OPUSGPU_UNIMPLEMENTED;
+    if (err == OPUSGPU_OK) {
+        st = (OpusGpuDecoder *)calloc(1, sizeof(OpusGpuDecoder));
+        if (!st) err = OPUSGPU_ALLOC_FAIL;
+    }
+    if (err == OPUSGPU_OK) {
+        if (hipStreamCreate(&st->stream) != hipSuccess || hipMalloc(&st->d_state, (size_t)opusgpu_celt_dec_state_size()) != hipSuccess ||
+            hipMalloc((void **)&st->d_pkt, 1280) != hipSuccess || hipMalloc((void **)&st->d_len, 4) != hipSuccess ||
+            hipMalloc((void **)&st->d_ret, 4) != hipSuccess || hipMalloc((void **)&st->d_rng, 4) != hipSuccess ||
+            hipMalloc((void **)&st->d_pcm, 960 * 2 * sizeof(int16_t)) != hipSuccess)
+            err = OPUSGPU_ALLOC_FAIL;
+        else
+            err = opusgpu_celt_dec_state_init(st->d_state, 1, st->stream);
+        if (err != OPUSGPU_OK) { free_all(st); st = nullptr; }
+    }
+    if (error) *error = err;
+    return st;
+}
+
+extern "C" void opusgpu_decoder_destroy(OpusGpuDecoder *st) { free_all(st); }
+
+extern "C" int opusgpu_decoder_ctl(OpusGpuDecoder *st, int request, ...)
+{
+    if (!st) return OPUSGPU_BAD_ARG;
+    va_list ap;
+    va_start(ap, request);
+    int ret = OPUSGPU_OK;
+    switch (request) {
+    case 4031: {                                                                  // OPUS_GET_FINAL_RANGE
+        uint32_t *p = va_arg(ap, uint32_t *);
+        if (!p) ret = OPUSGPU_BAD_ARG; else *p = st->final_range;
+        break;
+    }
+    case 4028:                                                                    // OPUS_RESET_STATE
+        ret = opusgpu_celt_dec_state_init(st->d_state, 1, st->stream);
+        st->final_range = 0;
+        break;
+    default: ret = OPUSGPU_UNIMPLEMENTED;
+    }
+    va_end(ap);
+    return ret;
+}
+
+// opus_decode(st, data, len, pcm, frame_size, decode_fec): returns the number of decoded samples per channel
+extern "C" int opusgpu_decode(OpusGpuDecoder *st, const unsigned char *data, int32_t len, int16_t *pcm, int frame_size, int decode_fec)
+{
+    if (!st || !pcm || frame_size <= 0 || len < 0) return OPUSGPU_BAD_ARG;
+    if (!data || len == 0 || decode_fec) return OPUSGPU_UNIMPLEMENTED;           // packet loss concealment / FEC
+    if (len > 1276) return OPUSGPU_INVALID_PACKET;
+    if (frame_size < 960) return OPUSGPU_BUFFER_TOO_SMALL;
+    int32_t ret = 0;
+    if (hipMemcpyAsync(st->d_pkt, data, (size_t)len, hipMemcpyHostToDevice, st->stream) != hipSuccess ||
+        hipMemcpyAsync(st->d_len, &len, 4, hipMemcpyHostToDevice, st->stream) != hipSuccess)
+        return OPUSGPU_INTERNAL_ERROR;
+    int rc = opusgpu_decode_batch(st->d_state, st->d_pkt, 1280, st->d_len, st->d_pcm, st->d_ret, st->d_rng, 1, st->stream);
+    if (rc < 0) return rc;
+    if (hipMemcpyAsync(&ret, st->d_ret, 4, hipMemcpyDeviceToHost, st->stream) != hipSuccess ||
+        hipMemcpyAsync(&st->final_range, st->d_rng, 4, hipMemcpyDeviceToHost, st->stream) != hipSuccess ||
+        hipStreamSynchronize(st->stream) != hipSuccess)
+        return OPUSGPU_INTERNAL_ERROR;
+    if (ret > 0) {
+        if (hipMemcpy(pcm, st->d_pcm, (size_t)ret * 2 * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess) return OPUSGPU_INTERNAL_ERROR;
+    }
+    return ret;
+}

@@ -41,7 +41,7 @@ int opusgpu_get_last_error(void);
 int opusgpu_num_cus(void);
 
 /* Optional per-kernel timing, the hook bench.py's roofline leg uses: while enabled, every kernel launch
- * of opusgpu_encode_batch is bracketed by HIP events recorded on the launch stream.
+ * of opusgpu_encode_batch / opusgpu_decode_batch is bracketed by HIP events recorded on the launch stream.
  * opusgpu_kernel_timing_read waits for the recorded launches, writes the summed duration (ms) and the
  * launch count per kernel id into ms_sum[0..n_kernels) / launches[0..n_kernels), and forgets them.
  * No counterpart in the reference (its timing is wall clock in src/opus_demo.c:750-800). */
@@ -52,7 +52,10 @@ int opusgpu_num_cus(void);
 #define OPUSGPU_KERNEL_CELT_FRONT1    4
 #define OPUSGPU_KERNEL_CELT_TRANSIENT 5
 #define OPUSGPU_KERNEL_CELT_FRONT2    6
-#define OPUSGPU_KERNEL_COUNT      7
+#define OPUSGPU_KERNEL_DEC_LANE       7
+#define OPUSGPU_KERNEL_DEC_SYNTH      8
+#define OPUSGPU_KERNEL_DEC_POST       9
+#define OPUSGPU_KERNEL_COUNT      10
 int opusgpu_kernel_timing_enable(int on);
 int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_kernels);
 
@@ -161,6 +164,15 @@ OpusGpuEncoder *opusgpu_encoder_create(int32_t Fs, int channels, int application
 int opusgpu_encoder_ctl(OpusGpuEncoder *st, int request, ...);
 int32_t opusgpu_encode(OpusGpuEncoder *st, const int16_t *pcm, int frame_size, unsigned char *data, int32_t max_data_bytes);
 void opusgpu_encoder_destroy(OpusGpuEncoder *st);
+/* Decoder side, likewise: opus_decoder_create / opus_decode / opus_decoder_ctl / opus_decoder_destroy
+ * (opus-fix/include/opus.h:438-505; src/opus_decoder.c:121, :758, :788, :911) for 48 kHz stereo and CELT-only
+ * 20 ms stereo packets; ctl: OPUS_GET_FINAL_RANGE, OPUS_RESET_STATE. data == NULL / decode_fec (loss concealment)
+ * return OPUS_UNIMPLEMENTED. */
+typedef struct OpusGpuDecoder OpusGpuDecoder;
+OpusGpuDecoder *opusgpu_decoder_create(int32_t Fs, int channels, int *error);
+int opusgpu_decode(OpusGpuDecoder *st, const unsigned char *data, int32_t len, int16_t *pcm, int frame_size, int decode_fec);
+int opusgpu_decoder_ctl(OpusGpuDecoder *st, int request, ...);
+void opusgpu_decoder_destroy(OpusGpuDecoder *st);
 
 /* Diagnostic only (never used for reported throughput): the same kernels with in-kernel stage stamps;
  * d_stamps = zero-initialised uint64 [4096][32] cycle totals per stage and workgroup. */

@@ -99,3 +99,33 @@ def test_gpu_decoder_rejects_what_it_does_not_implement(ca):
     ln = np.array([8, 1, 8], np.int32)
     _pcm, ret, _r = ca.decode_independent(torch.from_numpy(pk).cuda(), torch.from_numpy(ln).cuda())
     assert ret.cpu().numpy().tolist() == [-5, -5, -5]
+
+
+def test_single_stream_decoder_shim_config1_plumbing(ca):
+    """BASELINE config #1 through the libopus-shaped single-stream entry points: opusgpu_encoder_* encodes a stream
+    frame by frame, opusgpu_decoder_* decodes it; packets, PCM and both final ranges equal the golden stream."""
+    name = "music_vbr_stream"
+    pcm_in, pk, ln, rg = ec.load_case(name)
+    want = np.load(os.path.join(ROOT, "tests", "golden", "decode_golden.npz"))[name + "_dpcm"]
+    L = ca.lib.load()
+    err = C.c_int(0)
+    enc = L.opusgpu_encoder_create(48000, 2, 2051, C.byref(err))
+    dec = L.opusgpu_decoder_create(48000, 2, C.byref(err))
+    assert enc and dec and err.value == 0
+    for req, v in ((4002, 96000), (4006, 1), (4020, 0), (4010, 10), (4036, 16)):
+        assert L.opusgpu_encoder_ctl(C.c_void_p(enc), req, C.c_int32(v)) == 0
+    data = (C.c_ubyte * 1500)()
+    out = np.zeros((960, 2), np.int16)
+    for f in range(16):
+        frame = np.ascontiguousarray(pcm_in[f])
+        n = L.opusgpu_encode(C.c_void_p(enc), frame.ctypes.data_as(C.c_void_p), 960, data, 1500)
+        assert n == ln[f] and bytes(data[:n]) == pk[f, :n].tobytes()
+        got = L.opusgpu_decode(C.c_void_p(dec), data, n, out.ctypes.data_as(C.c_void_p), 960, 0)
+        assert got == 960 and np.array_equal(out, want[f])
+        er, dr = C.c_uint32(0), C.c_uint32(1)
+        L.opusgpu_encoder_ctl(C.c_void_p(enc), 4031, C.byref(er))
+        L.opusgpu_decoder_ctl(C.c_void_p(dec), 4031, C.byref(dr))
+        assert er.value == dr.value == rg[f]
+    assert L.opusgpu_decode(C.c_void_p(dec), None, 0, out.ctypes.data_as(C.c_void_p), 960, 0) == -5       # PLC not implemented
+    L.opusgpu_encoder_destroy(C.c_void_p(enc))
+    L.opusgpu_decoder_destroy(C.c_void_p(dec))
