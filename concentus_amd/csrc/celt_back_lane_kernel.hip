@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64) void celt_back_lane_kernel(opusgpu_celt_config 
     BackLds F;
     F.lds_pvq16 = g_lds_pvq16 + threadIdx.x;
     F.lds_pvq32 = g_lds_pvq32 + threadIdx.x;
+    F.lds_xs = g_lds_xs + threadIdx.x;
     opusgpu_celt_state *st = states ? states + n : nullptr;
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;

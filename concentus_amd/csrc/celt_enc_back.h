@@ -284,12 +284,13 @@ struct BandCtx {                 // uniform; cf. struct band_ctx (bands.c:623-63
 
 // exp_rotation1 chains (vq.c:43-68): positions r, r+stride, ... of one block form a serial recurrence; the
 // `stride` residues and the blocks are independent, one lane walks one chain.
-CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c, i32 s)
+template <class P>
+CA_DEV void exp_rotation1_chains(P X, int len, int nblocks, int stride, i32 c, i32 s)
 {
     const i32 ms = (i16)neg32(s);
     CA_UNROLL_LANE
     for (int ch = lane(); ch < nblocks * stride; ch += LANES) {
-        i16 *x = X + (ch / stride) * len;
+        P x = X + (ch / stride) * len;
         const int r = ch % stride;
         // forward: the value written to x[i+stride] is the x1 of the next step -> carried in a register,
         // so each step needs one independent LDS read instead of a read-after-write round trip
@@ -348,7 +349,8 @@ CA_DEV void exp_rotation1_chains(i16 *X, int len, int nblocks, int stride, i32 c
     wave_sync();
 }
 
-CA_DEV void exp_rotation_wave(i16 *X, int len, int stride, int K, int spread)              // vq.c:70-117, dir = 1
+template <class P>
+CA_DEV void exp_rotation_wave(P X, int len, int stride, int K, int spread)              // vq.c:70-117, dir = 1
 {
     if (2 * K >= len || spread == SPREAD_NONE) return;
     const int factor = spread == SPREAD_LIGHT ? 15 : spread == SPREAD_NORMAL ? 10 : 5;   // SPREAD_FACTOR[spread-1]
@@ -430,7 +432,7 @@ CA_DEV void pvq_argmax(i32 &num, i32 &den, int &id)
 
 // alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build
 template <class L>
-CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int spread, int B)
+CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spread, int B)
 {
     // search state: |X|, 2*iy, iy. Lane build: leaves of up to PVQ_LDS_N elements keep it in LDS.
 #if defined(CA_LANE_FRAME)
@@ -441,6 +443,25 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *X, int N, int K, int sprea
 #else
     i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
     i32 *iy = F.s.pvq.iy;
+#endif
+#if defined(CA_LANE_FRAME)
+    // leaves of up to PVQ_LDS_N bins are rotated, searched and sign-fixed on an LDS copy ([element][lane]); the
+    // encoder never reads X again after coding it, so nothing is copied back
+    LP<i16> X = lp_make(Xg, 1);
+    if (in_lds) {
+        LP<i16> st = lp_make(F.lds_xs, 64);
+        for (int k = 0; k < N; k += 8) {
+            i32 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = k + u < N ? (i32)Xg[k + u] : 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (k + u < N) st[k + u] = (i16)v[u];
+        }
+        X = st;
+    }
+#else
+    i16 *X = Xg;
 #endif
     CA_STAMP_F(F, 22);
     CA_COUNT("leaf.N", N);

@@ -71,6 +71,7 @@ struct __attribute__((aligned(16))) BackLds {
     u8 *packet;                    // -> the output slab of this frame
     i16 *lds_pvq16;                // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
     i32 *lds_pvq32;
+    i16 *lds_xs;                   // -> this lane's column of the leaf copy of X ([element][lane])
 #else
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
 #endif

@@ -39,6 +39,7 @@ __shared__ LdsTables g_lds_tables;
 // PVQ search state of the 64 frames of the workgroup, [element][lane]: y and |x| (int16, 48 each), iy (int32, 48)
 __shared__ int16_t g_lds_pvq16[2 * 48 * 64];
 __shared__ int32_t g_lds_pvq32[48 * 64];
+__shared__ int16_t g_lds_xs[48 * 64];
 __device__ __forceinline__ void fill_lds_tables()
 {
 #define X(T, NAME, N) for (int k = threadIdx.x; k < N; k += blockDim.x) g_lds_tables.NAME##_[k] = NAME[k];

@@ -174,6 +174,7 @@ template <class T> struct LP {
     T *p;
     int s;
     __device__ __forceinline__ T &operator[](int j) const { return p[j * s]; }
+    __device__ __forceinline__ LP operator+(int o) const { LP r; r.p = p + o * s; r.s = s; return r; }
 };
 template <class T> __device__ __forceinline__ LP<T> lp_make(T *p, int stride) { LP<T> r; r.p = p; r.s = stride; return r; }
 #else
