@@ -209,6 +209,26 @@ template <class L>
 CA_DEV void preemphasis_wave(L &F, FrameCtx &fc)
 {
     const i16 *pcmf = frame_pcmf(F);
+    if (L::IN_IS_GLOBAL) {
+        // split pipeline: the pre-emphasised samples are only needed in xf (the pitch analysis' and the comb
+        // filter's input), so they are written there directly instead of through the HBM time-signal buffer.
+        // pcmf aliases the first half of xf: channel 1 goes first (its xf half is clear of pcmf), channel 0
+        // walks down in blocks whose reads complete before their writes (xf[0][i] lands on pcmf[2i], pcmf[2i+1]).
+        for (int c = fc.C - 1; c >= 0; c--) {
+            const i32 mem0 = fc.preemph_memE[c];
+            fc.preemph_memE[c] = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+            wave_sync();
+            for (int base = FRAME - LANES; base >= 0; base -= LANES) {
+                const int i = base + lane();
+                i32 x = pcmf[c * FRAME + i];
+                i32 m = i == 0 ? mem0 : (mul16_16(27853, pcmf[c * FRAME + i - 1]) >> 3);
+                wave_sync();
+                F.xf[c][i] = sub32(shl32(x, 12), m);
+                wave_sync();
+            }
+        }
+        return;
+    }
     for (int c = 0; c < fc.C; c++) {
         for (int i = lane(); i < FRAME; i += LANES) {
             i32 x = pcmf[c * FRAME + i];
@@ -657,10 +677,12 @@ CA_DEVFN PrefilterOut run_prefilter_wave(L &F, FrameCtx &fc, const i32 *in_mem, 
 {
     const int C = fc.C;
     PrefilterOut o;
-    // pre[c] = [history | new]: keep the unfiltered new samples in xf
-    for (int c = 0; c < C; c++)
-        for (int i = lane(); i < FRAME; i += LANES) F.xf[c][i] = tsig(F, c)[OVL + i];
-    wave_sync();
+    // pre[c] = [history | new]: keep the unfiltered new samples in xf (the split pipeline put them there already)
+    if (!L::IN_IS_GLOBAL) {
+        for (int c = 0; c < C; c++)
+            for (int i = lane(); i < FRAME; i += LANES) F.xf[c][i] = tsig(F, c)[OVL + i];
+        wave_sync();
+    }
     int pitch_index;
     i32 gain1;
     if (enabled) {
