@@ -129,3 +129,32 @@ def test_single_stream_decoder_shim_config1_plumbing(ca):
     assert L.opusgpu_decode(C.c_void_p(dec), None, 0, out.ctypes.data_as(C.c_void_p), 960, 0) == -5       # PLC not implemented
     L.opusgpu_encoder_destroy(C.c_void_p(enc))
     L.opusgpu_decoder_destroy(C.c_void_p(dec))
+
+
+def test_gpu_decodes_bit_file_written_by_reference_cli(ca, tmp_path):
+    """A .bit file produced by the reference's own opus_demo -e (oracle/_ref/opus_demo) goes through
+    concentus_amd.bitstream and the GPU decoder as one stream; PCM equals what the reference CLI decodes from the same
+    file (including the flush packet the CLI appends), final ranges equal the ones embedded in the file."""
+    import subprocess
+    import torch
+    demo = os.path.join(ROOT, "oracle", "_ref", "opus_demo")
+    if not os.path.exists(demo):
+        pytest.skip("oracle/_ref/opus_demo did not travel")
+    from concentus_amd import bitstream
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm("music", 50, 4242)
+    raw, bit, out = tmp_path / "in.pcm", tmp_path / "x.bit", tmp_path / "ref.pcm"
+    pcm.astype("<i2").tofile(str(raw))
+    for args in (["-e", "restricted-lowdelay", "48000", "2", "64000", str(raw), str(bit)], ["-d", "48000", "2", str(bit), str(out)]):
+        r = subprocess.run([demo] + args, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+    pk, ln, rg = bitstream.read_opus_demo_bit(str(bit), stride=1500)
+    want = np.fromfile(str(out), np.int16).reshape(-1, 960, 2)
+    assert want.shape[0] == len(ln)
+    dec = ca.OpusDecoderBatch(1)
+    for k in range(len(ln)):
+        o, r = dec.decode(torch.from_numpy(pk[k:k + 1]).cuda(), torch.from_numpy(ln[k:k + 1]).cuda())
+        torch.cuda.synchronize()
+        assert int(r.item()) == 960
+        assert np.uint32(dec.ctl(4031).cpu().numpy().view(np.uint32)[0]) == rg[k]
+        assert np.array_equal(o.cpu().numpy()[0], want[k]), k
