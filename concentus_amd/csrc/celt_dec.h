@@ -21,6 +21,10 @@ enum { DEC_BUF = 2048, DEC_MEM = DEC_BUF + OVL };           // DECODE_BUFFER_SIZ
 // per-packet working set (host memory in the emulation, private/global memory on the GPU)
 struct __attribute__((aligned(16))) DecWork {
     i16 *X;                        // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
+#if defined(CA_LANE_FRAME)
+    i32 *lds_pvq32;                // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
+    i16 *lds_pvq16;                // -> ... of the (de)interleave scratch (96 bins)
+#endif
     i16 norm[2 * 624];             // folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel
     i32 iy[176];
     i16 tmp[176];
@@ -164,9 +168,11 @@ CA_DEV void exp_rotation_inv(i16 *X, int len, int stride, int K, int spread)    
 }
 
 // cwrsi (cwrs.c:462-524): index -> pulse vector, returns sum y^2
-CA_DEV i32 cwrsi_dec(int n, int k, u32 i, i32 *y)
+template <class PY>
+CA_DEV i32 cwrsi_dec(int n, int k, u32 i, PY y)
 {
     i32 yy = 0;
+    int pos = 0;
     while (n > 2) {
         u32 p, q;
         int s, k0;
@@ -186,14 +192,14 @@ CA_DEV i32 cwrsi_dec(int n, int k, u32 i, i32 *y)
             }
             i -= p;
             val = (k0 - k + s) ^ s;
-            *y++ = val;
+            y[pos++] = val;
             yy = mac16_16(yy, val, val);
         } else {
             p = pvq_u(k, n);
             q = pvq_u(k + 1, n);
             if (p <= i && i < q) {
                 i -= p;
-                *y++ = 0;
+                y[pos++] = 0;
             } else {
                 s = -(int)(i >= q);
                 i -= q & (u32)s;
@@ -202,7 +208,7 @@ CA_DEV i32 cwrsi_dec(int n, int k, u32 i, i32 *y)
                 while (p > i);
                 i -= p;
                 val = (k0 - k + s) ^ s;
-                *y++ = val;
+                y[pos++] = val;
                 yy = mac16_16(yy, val, val);
             }
         }
@@ -216,12 +222,12 @@ CA_DEV i32 cwrsi_dec(int n, int k, u32 i, i32 *y)
         k = (int)((i + 1) >> 1);
         if (k) i -= 2 * (u32)k - 1;
         i32 val = (k0 - k + s) ^ s;
-        *y++ = val;
+        y[pos++] = val;
         yy = mac16_16(yy, val, val);
         // n == 1
         s = -(int)i;
         val = (k + s) ^ s;
-        *y = val;
+        y[pos] = val;
         yy = mac16_16(yy, val, val);
     }
     return yy;
@@ -248,7 +254,11 @@ CA_DEV void renormalise_vector_dec(i16 *X, int N, i32 gain)                     
 template <class D>
 CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain)   // vq.c:329-346
 {
+#if defined(CA_LANE_FRAME)
+    LP<i32> iy = N <= 48 ? lp_make(F.lds_pvq32, 64) : lp_make((i32 *)F.iy, 1);
+#else
     i32 *iy = F.iy;
+#endif
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
     i32 Ryy = cwrsi_dec(N, K, ec_dec_uint(dec, V), iy);
     {   // normalise_residual (vq.c:117-138)
@@ -256,10 +266,8 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
         i32 t = vshr32(Ryy, 2 * (k - 7));
         i32 g = (i16)mul16_16_p15(celt_rsqrt_norm(t), gain);
         {
-            i16 *__restrict__ xo = X;
-            const i32 *__restrict__ yi = iy;
 #pragma unroll 8
-            for (int i = 0; i < N; i++) xo[i] = (i16)pshr32(mul16_16(g, yi[i]), k + 1);
+            for (int i = 0; i < N; i++) X[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
         }
     }
     exp_rotation_inv(X, N, B, K, spread);
@@ -456,46 +464,50 @@ CA_DEV void haar1_ref(i16 *X, int N0, int stride)                               
 template <class D>
 CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)            // bands.c:524-549
 {
-    i16 *tmp = F.tmp;
     const int N = N0 * stride;
+#if defined(CA_LANE_FRAME)
+    LP<i16> tmp = N <= 96 ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.tmp, 1);
+#else
+    i16 *tmp = F.tmp;
+#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
-        i16 *__restrict__ t = tmp;
         const i16 *__restrict__ x = X;
         for (int i = 0; i < stride; i++) {
             const int d = hadamard ? ordery[i] : i;
 #pragma unroll 4
-            for (int j = 0; j < N0; j++) t[d * N0 + j] = x[j * stride + i];
+            for (int j = 0; j < N0; j++) tmp[d * N0 + j] = x[j * stride + i];
         }
     }
     {
         i16 *__restrict__ x = X;
-        const i16 *__restrict__ t = tmp;
 #pragma unroll 8
-        for (int k = 0; k < N; k++) x[k] = t[k];
+        for (int k = 0; k < N; k++) x[k] = tmp[k];
     }
 }
 
 template <class D>
 CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)              // bands.c:551-578
 {
-    i16 *tmp = F.tmp;
     const int N = N0 * stride;
+#if defined(CA_LANE_FRAME)
+    LP<i16> tmp = N <= 96 ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.tmp, 1);
+#else
+    i16 *tmp = F.tmp;
+#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
-        i16 *__restrict__ t = tmp;
         const i16 *__restrict__ x = X;
         for (int i = 0; i < stride; i++) {
             const int d = hadamard ? ordery[i] : i;
 #pragma unroll 4
-            for (int j = 0; j < N0; j++) t[j * stride + i] = x[d * N0 + j];
+            for (int j = 0; j < N0; j++) tmp[j * stride + i] = x[d * N0 + j];
         }
     }
     {
         i16 *__restrict__ x = X;
-        const i16 *__restrict__ t = tmp;
 #pragma unroll 8
-        for (int k = 0; k < N; k++) x[k] = t[k];
+        for (int k = 0; k < N; k++) x[k] = tmp[k];
     }
 }
 

@@ -23,6 +23,8 @@ __global__ __launch_bounds__(64) void celt_decode_lane_kernel(opusgpu_celt_dec_s
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n) return;
     DecWork F;
+    F.lds_pvq32 = g_lds_pvq32 + threadIdx.x;
+    F.lds_pvq16 = g_lds_pvq16 + threadIdx.x;
     DecResult r = celt_decode_front(F, states + k, packets + (size_t)k * packet_stride, len[k]);
     ret[k] = r.samples;
     rng[k] = r.final_range;
