@@ -38,6 +38,7 @@ CA_DEV void load_state(FrameCtx &fc, L &F, const opusgpu_celt_state *st, int C)
         fc.stereo_saving = st->stereo_saving;
         fc.intensity = st->intensity;
         fc.spec_avg = st->spec_avg;
+        fc.stereo_narrow = st->reserved[0];
         fc.hist = st->prefilter_mem;
         for (int k = lane(); k < 2 * NB; k += LANES) {
             F.oldBandE[k] = st->oldBandE[k];
@@ -64,6 +65,7 @@ CA_DEV void load_state(FrameCtx &fc, L &F, const opusgpu_celt_state *st, int C)
         fc.stereo_saving = 0;
         fc.intensity = 0;
         fc.spec_avg = 0;
+        fc.stereo_narrow = 0;
         fc.hist = nullptr;
         for (int k = lane(); k < 2 * NB; k += LANES) {
             F.oldBandE[k] = 0;
@@ -106,6 +108,7 @@ CA_DEV void store_state(const FrameCtx &fc, L &F, opusgpu_celt_state *st)
         st->stereo_saving = fc.stereo_saving;
         st->intensity = fc.intensity;
         st->spec_avg = fc.spec_avg;
+        st->reserved[0] = fc.stereo_narrow;
     }
     for (int k = lane(); k < C * NB; k += LANES) {
         st->oldBandE[k] = F.oldBandE[k];
@@ -184,6 +187,7 @@ CA_DEV void mid_store(L &F, FrameMid *mid, const RangeEnc &enc, const FrameCtx &
         mid->vbr_reservoir = fc.vbr_reservoir; mid->vbr_drift = fc.vbr_drift; mid->vbr_offset = fc.vbr_offset;
         mid->vbr_count = fc.vbr_count; mid->overlap_max = fc.overlap_max; mid->stereo_saving = fc.stereo_saving;
         mid->intensity = fc.intensity; mid->spec_avg = fc.spec_avg;
+        mid->pad[0] = fc.stereo_narrow;
     }
 }
 
@@ -202,6 +206,7 @@ CA_DEV void mid_load(L &F, const FrameMid *mid, RangeEnc &enc, FrameCtx &fc, Mid
     fc.vbr_reservoir = uni(mid->vbr_reservoir); fc.vbr_drift = uni(mid->vbr_drift); fc.vbr_offset = uni(mid->vbr_offset);
     fc.vbr_count = uni(mid->vbr_count); fc.overlap_max = uni(mid->overlap_max); fc.stereo_saving = uni(mid->stereo_saving);
     fc.intensity = uni(mid->intensity); fc.spec_avg = uni(mid->spec_avg);
+    fc.stereo_narrow = uni(mid->pad[0]);
     m.max_data_bytes = uni(mid->max_data_bytes); m.nbCompressedBytes = uni(mid->nbCompressedBytes);
     m.nbAvailableBytes = uni(mid->nbAvailableBytes); m.vbr_rate = uni(mid->vbr_rate); m.effectiveBytes = uni(mid->effectiveBytes);
     m.equiv_rate = uni(mid->equiv_rate); m.total_bits = uni(mid->total_bits);
@@ -284,6 +289,7 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
         wave_sync();
         dc_reject_wave(F, fc);
     }
+    stereo_width_wave(F, fc, bitrate_bps);
     CA_TRACE("dc_reject done");
 
     CA_STAMP(0);
@@ -557,6 +563,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     fc.vbr_reservoir = uni(mid->vbr_reservoir); fc.vbr_drift = uni(mid->vbr_drift); fc.vbr_offset = uni(mid->vbr_offset);
     fc.vbr_count = uni(mid->vbr_count); fc.overlap_max = uni(mid->overlap_max); fc.stereo_saving = uni(mid->stereo_saving);
     fc.intensity = uni(mid->intensity); fc.spec_avg = uni(mid->spec_avg);
+    fc.stereo_narrow = uni(mid->pad[0]);
     const int max_data_bytes = uni(mid->max_data_bytes);
     int nbCompressedBytes = uni(mid->nbCompressedBytes), nbAvailableBytes = uni(mid->nbAvailableBytes);
     const i32 vbr_rate = uni(mid->vbr_rate), equiv_rate = uni(mid->equiv_rate);

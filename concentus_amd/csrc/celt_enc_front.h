@@ -157,6 +157,7 @@ struct FrameCtx {
     i32 preemph_memE[2];
     i32 vbr_reservoir, vbr_drift, vbr_offset, vbr_count, overlap_max;
     int stereo_saving, intensity, spec_avg;
+    int stereo_narrow;             // 16384 - hybrid_stereo_width_Q14 of the Opus layer (src/opus_encoder.c:91): 0 = full width
     const i32 *hist;               // prefilter_mem of the stream in HBM, or nullptr (all zero)
 };
 
@@ -184,6 +185,34 @@ CA_DEV void dc_reject_wave(L &F, FrameCtx &fc)
     }
     wave_sync();
     for (int c = 0; c < C; c++) { fc.hp_mem[2 * c] = F.scal[2 * c]; fc.hp_mem[2 * c + 1] = F.scal[2 * c + 1]; }
+    wave_sync();
+}
+
+// Stereo width reduction of the Opus layer at low rates (src/opus_encoder.c:1790-1809 + stereo_fade :411-441):
+// below 38.2 kb/s the side signal is attenuated, cross-fading from the previous frame's width over the overlap.
+// Works on the planar dc-rejected PCM; equiv_rate == bitrate at 50 frames/s.
+template <class L>
+CA_DEV void stereo_width_wave(L &F, FrameCtx &fc, i32 bitrate_bps)
+{
+    const i32 width = imin(1 << 14, 2 * imax(0, bitrate_bps - 30000)), prev = (1 << 14) - fc.stereo_narrow;
+    if (!(prev < (1 << 14) || width < (1 << 14))) return;
+    i32 g1 = prev == 16384 ? 32767 : shl16(prev, 1), g2 = width == 16384 ? 32767 : shl16(width, 1);
+    g1 = (i16)(32767 - g1);
+    g2 = (i16)(32767 - g2);
+    i16 *pcmf = frame_pcmf(F);
+    for (int i = lane(); i < FRAME; i += LANES) {
+        i32 g = g2;
+        if (i < OVL) {
+            i32 w = (i16)mul16_16_q15(CLT_window120[i], CLT_window120[i]);
+            g = (i16)(mac16_16(mul16_16(w, g2), (i16)(32767 - w), g1) >> 15);
+        }
+        i32 l = pcmf[i], r = pcmf[FRAME + i];
+        i32 diff = (i16)((l - r) >> 1);
+        diff = mul16_16_q15(g, diff);
+        pcmf[i] = (i16)(l - diff);
+        pcmf[FRAME + i] = (i16)(r + diff);
+    }
+    fc.stereo_narrow = (1 << 14) - width;
     wave_sync();
 }
 

@@ -115,6 +115,9 @@ ENCODE_CASES = [
     ("noise_cvbr_stream", "noise", 32, 16, 8, (64000, 1, 1, 10)),
     ("music_cbr_stream_cx5", "music", 32, 16, 9, (128000, 0, 0, 5)),
     ("noise_vbr_stream_cx0", "noise", 16, 8, 10, (48000, 1, 0, 0)),
+    # 30-38.2 kb/s: the Opus layer narrows the stereo image (stereo_fade, src/opus_encoder.c:1790-1809)
+    ("music_34k_cbr_stream", "music", 16, 8, 11, (34000, 0, 0, 10)),
+    ("noise_33k_vbr_indep", "noise", 8, 1, 12, (33000, 1, 0, 7)),
 ]
 
 

@@ -13,6 +13,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BITRATE = int(os.environ.get("TD_BITRATE", 96000))      # optional overrides of the encoder settings
+COMPLEXITY = int(os.environ.get("TD_COMPLEXITY", 10))
 CODES = {"1f", "1g", "1h", "1j", "1k", "1l", "1m", "1n", "1p", "1q", "1r", "1s", "1t"}
 
 
@@ -39,7 +41,7 @@ def child_ref(nframes, fps, seed, kind, vbr):
     for s in range(nframes // fps):
         err = C.c_int()
         enc = C.c_void_p(lib.opus_encoder_create(48000, 2, 2051, C.byref(err)))
-        for req, v in ((4002, 96000), (4008, -1000), (4006, vbr), (4020, 0), (4010, 10), (4012, 0), (4022, -1000), (4016, 0), (4014, 0), (4036, 16), (4040, 5000)):
+        for req, v in ((4002, BITRATE), (4008, -1000), (4006, vbr), (4020, 0), (4010, COMPLEXITY), (4012, 0), (4022, -1000), (4016, 0), (4014, 0), (4036, 16), (4040, 5000)):
             lib.opus_encoder_ctl(enc, req, v)
         for f in range(fps):
             n = s * fps + f
@@ -53,7 +55,7 @@ def child_ref(nframes, fps, seed, kind, vbr):
 def child_emu(nframes, fps, seed, kind, vbr):
     emu = C.CDLL(os.path.join(ROOT, "tests", "emu", "libcelt_emu_trace.so"))
     pcm = make_pcm(nframes, seed, kind)
-    cfg = Cfg(2, 96000, vbr, 0, 10, 16, 0, 1500)
+    cfg = Cfg(2, BITRATE, vbr, 0, COMPLEXITY, 16, 0, 1500)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import emulib
     st = emulib.fresh_states(nframes // fps) if fps > 1 else None
