@@ -112,6 +112,12 @@ static int config_ok(const opusgpu_celt_config *c)
     // stereo kept stereo (equiv_rate > stereo threshold 30 kb/s +- 1 kb/s hysteresis, opus_encoder.c:1121-1131)
     // and bandwidth stays FULLBAND (stereo music/voice thresholds <= 30 kb/s, :1263-1305).
     if (c->channels != 2 || c->bitrate < 32000) return OPUSGPU_UNIMPLEMENTED;
+    // CBR: the packet size caps the rate the decisions see (cbrBytes, opus_encoder.c:1054-1061)
+    if (!c->vbr) {
+        int maxb = c->max_data_bytes < 1276 ? c->max_data_bytes : 1276;
+        int cbr = (3 * c->bitrate / 8 + 75) / 150;
+        if ((cbr < maxb ? cbr : maxb) * 400 < 32000) return OPUSGPU_UNIMPLEMENTED;
+    }
     // PLC-frame corner (opus_encoder.c:1056-1084) and too-small buffers
     if (c->max_data_bytes < 3 || c->bitrate > 510000) return OPUSGPU_UNIMPLEMENTED;
     return OPUSGPU_OK;

@@ -118,6 +118,10 @@ def test_bad_configs_rejected(ca):
     with pytest.raises(ca.lib.OpusGpuError) as e:
         ca.encode_independent(pcm, ca.CeltConfig(2, 96000, 1, 0, 11, 16, 0, 1500))
     assert e.value.code == -1
+    with pytest.raises(ca.lib.OpusGpuError) as e:          # CBR into 60-byte packets = 24 kb/s: the Opus layer would go mono
+        ca.encode_independent(pcm, ca.CeltConfig(2, 96000, 0, 0, 10, 16, 0, 60))
+    assert e.value.code == -5
+    ca.encode_independent(pcm, ca.CeltConfig(2, 96000, 1, 0, 10, 16, 0, 60))      # VBR with the same cap is inside the region
     with pytest.raises(ValueError):
         ca.encode_independent(torch.zeros((2, 480, 2), dtype=torch.int16, device="cuda"))
     out, lens, _ = ca.encode_independent(torch.zeros((0, 960, 2), dtype=torch.int16, device="cuda"))
