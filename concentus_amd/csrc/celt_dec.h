@@ -160,11 +160,12 @@ CA_DEV void exp_rotation_inv(i16 *X, int len, int stride, int K, int spread)    
         stride2 = 1;
         while ((stride2 * stride2 + stride2) * stride + (stride >> 2) < len) stride2++;
     }
-    len = (int)((u32)len / (u32)stride);
-    for (int i = 0; i < stride; i++) {
-        if (stride2) exp_rotation1_ref(X + i * len, len, stride2, s, c);
-        exp_rotation1_ref(X + i * len, len, 1, c, s);
-    }
+    // exp_rotation1 per block, as register-carried chains with look-ahead loads (the encoder's formulation,
+    // celt_enc_back.h): a literal exp_rotation1 reads back what it stored one step earlier, a round trip through
+    // memory per coefficient
+    const int blen = (int)((u32)len / (u32)stride);
+    if (stride2) exp_rotation1_chains(X, blen, stride, stride2, s, c);
+    exp_rotation1_chains(X, blen, stride, 1, c, s);
 }
 
 // cwrsi (cwrs.c:462-524): index -> pulse vector, returns sum y^2
@@ -259,8 +260,12 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
 #else
     i32 *iy = F.iy;
 #endif
+    CA_STAMP_F(F, 8);
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
-    i32 Ryy = cwrsi_dec(N, K, ec_dec_uint(dec, V), iy);
+    u32 idx = ec_dec_uint(dec, V);
+    CA_STAMP_F(F, 3);
+    i32 Ryy = cwrsi_dec(N, K, idx, iy);
+    CA_STAMP_F(F, 4);
     {   // normalise_residual (vq.c:117-138)
         int k = celt_ilog2(Ryy) >> 1;
         i32 t = vshr32(Ryy, 2 * (k - 7));
@@ -270,7 +275,9 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
             for (int i = 0; i < N; i++) X[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
         }
     }
+    CA_STAMP_F(F, 5);
     exp_rotation_inv(X, N, B, K, spread);
+    CA_STAMP_F(F, 6);
     if (B <= 1) return 1;                                                                     // extract_collapse_mask
     const int N0 = (int)((u32)N / (u32)B);
     unsigned mask = 0;
@@ -342,16 +349,30 @@ CA_DEV DecSplit compute_theta_dec(RangeDec &dec, DecBandCtx &ctx, int N, int *b,
     return sc;
 }
 
+// The folding source of a band ("lowband") needs the same TF recombination / time-division / de-interleaving the
+// band itself gets before it can be copied under a pulse-less partition (bands.c:1083-1134). That is three passes
+// over the band, and at ordinary rates no partition folds, so the passes are recorded here and only run when the
+// first partition asks for the data (the result is the same: the source is read-only until then).
+struct LowbandPrep {
+    i16 *src;          // norm + effective_lowband (nullptr: nothing to fold from)
+    i16 *scratch;      // where the transformed copy goes (nullptr: transform in place, last band)
+    int N, B, N_B, tf_change, recombine, longBlocks, need_copy;
+    int ready;
+    i16 *ptr;          // valid once ready
+};
+template <class D> CA_DEV void lowband_prepare(D &F, LowbandPrep &lp);
+
 // quant_partition (bands.c:864-1042), encode = 0. The reference recurses; here the second child of a split
 // is parked on a small stack (as in the encoder), each node carrying its own lowband, gain, fill and the
 // shift its collapse mask enters the parent's mask with.
 template <class D>
-CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int N, int b, int B, i16 *lowband,
+CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int N, int b, int B, LowbandPrep &lp,
                                     int LM, i32 gain, int fill)
 {
-    struct Parked { i16 *X, *lowband; int b, N, B, LM, first_bits, allow, fill, shift; i32 remaining, gain; };
+    struct Parked { i16 *X; int lowband; int b, N, B, LM, first_bits, allow, fill, shift; i32 remaining, gain; };
     Parked st[5];
     int sp = 0, shift = 0;
+    int lowband = lp.src ? 0 : -1;                  // offset into the (lazily prepared) folding source, -1: none
     unsigned cm_total = 0;
     for (;;) {
         while (LM != -1 && N > 2 && b > pulse_cache_max(ctx.i, LM) + 12) {
@@ -372,7 +393,7 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
             const int mbits = imax(0, imin(b, (b - delta) / 2));
             const int sbits = b - mbits;
             ctx.remaining_bits -= sc.qalloc;
-            i16 *lowband2 = lowband ? lowband + N : nullptr;
+            const int lowband2 = lowband >= 0 ? lowband + N : -1;
             const i32 gmid = (i16)mul16_16_p15(gain, mid), gside = (i16)mul16_16_p15(gain, side);
             const int mid_first = mbits >= sbits;
             Parked &p = st[sp++];
@@ -406,15 +427,16 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
             if (!fill) {
                 for (int j = 0; j < N; j++) X[j] = 0;
             } else {
-                if (lowband == nullptr) {
+                if (lowband < 0) {
                     for (int j = 0; j < N; j++) {
                         ctx.seed = celt_lcg_rand(ctx.seed);
                         X[j] = (i16)((i32)ctx.seed >> 20);
                     }
                     cm = cm_mask;
                 } else {
+                    if (!lp.ready) lowband_prepare(F, lp);
                     i16 *__restrict__ xo = X;
-                    const i16 *__restrict__ lb = lowband;
+                    const i16 *__restrict__ lb = lp.ptr + lowband;
 #pragma unroll 8
                     for (int j = 0; j < N; j++) {
                         ctx.seed = celt_lcg_rand(ctx.seed);
@@ -511,6 +533,32 @@ CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadama
     }
 }
 
+template <class D>
+CA_DEV void lowband_prepare(D &F, LowbandPrep &lp)
+{
+    i16 *lowband = lp.src;
+    if (lp.need_copy) {
+        i16 *__restrict__ d = lp.scratch;
+        const i16 *__restrict__ sQ = lp.src;
+#pragma unroll 8
+        for (int j = 0; j < lp.N; j++) d[j] = sQ[j];
+        lowband = lp.scratch;
+    }
+    int B = lp.B, N_B = lp.N_B, tf_change = lp.tf_change;
+    for (int k = 0; k < lp.recombine; k++) haar1_ref(lowband, lp.N >> k, 1 << k);
+    B >>= lp.recombine;
+    N_B <<= lp.recombine;
+    while ((N_B & 1) == 0 && tf_change < 0) {
+        haar1_ref(lowband, N_B, B);
+        B <<= 1;
+        N_B >>= 1;
+        tf_change++;
+    }
+    if (B > 1) deinterleave_hadamard_ref(F, lowband, N_B >> lp.recombine, B << lp.recombine, lp.longBlocks);
+    lp.ptr = lowband;
+    lp.ready = 1;
+}
+
 // quant_band_n1 (bands.c:819-862), encode = 0
 CA_DEV unsigned quant_band_n1_dec(RangeDec &dec, DecBandCtx &ctx, i16 *X, i16 *Y, i16 *lowband_out)
 {
@@ -540,23 +588,18 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     int tf_change = ctx.tf_change;
     if (N == 1) return quant_band_n1_dec(dec, ctx, X, nullptr, lowband_out);
     if (tf_change > 0) recombine = tf_change;
-    if (lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1)) {
-        {
-            i16 *__restrict__ d = lowband_scratch;
-            const i16 *__restrict__ sQ = lowband;
-#pragma unroll 8
-            for (int j = 0; j < N; j++) d[j] = sQ[j];
-        }
-        lowband = lowband_scratch;
-    }
-    for (int k = 0; k < recombine; k++) {
-        if (lowband) haar1_ref(lowband, N >> k, 1 << k);
+    LowbandPrep lp;
+    lp.src = lowband;
+    lp.scratch = lowband_scratch;
+    lp.N = N; lp.B = B; lp.N_B = N_B; lp.tf_change = tf_change; lp.recombine = recombine; lp.longBlocks = longBlocks;
+    lp.need_copy = lowband_scratch && lowband && (recombine || ((N_B & 1) == 0 && tf_change < 0) || B0 > 1);
+    lp.ready = 0;
+    lp.ptr = lowband;
+    for (int k = 0; k < recombine; k++)
         fill = CLT_bit_interleave_table[fill & 0xF] | CLT_bit_interleave_table[fill >> 4] << 2;
-    }
     B >>= recombine;
     N_B <<= recombine;
     while ((N_B & 1) == 0 && tf_change < 0) {
-        if (lowband) haar1_ref(lowband, N_B, B);
         fill |= fill << B;
         B <<= 1;
         N_B >>= 1;
@@ -565,8 +608,9 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     }
     B0 = B;
     const int N_B0 = N_B;
-    if (B0 > 1 && lowband) deinterleave_hadamard_ref(F, lowband, N_B >> recombine, B0 << recombine, longBlocks);
-    unsigned cm = quant_partition_dec(F, dec, ctx, X, N, b, B, lowband, LM, gain, fill);
+    CA_STAMP_F(F, 7);
+    unsigned cm = quant_partition_dec(F, dec, ctx, X, N, b, B, lp, LM, gain, fill);
+    CA_STAMP_F(F, 8);
     // resynthesis
     if (B0 > 1) interleave_hadamard_ref(F, X, N_B >> recombine, B0 << recombine, longBlocks);
     N_B = N_B0;
@@ -592,6 +636,7 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
         }
     }
     cm &= (1u << B) - 1;
+    CA_STAMP_F(F, 9);
     return cm;
 }
 
@@ -614,11 +659,18 @@ CA_DEV void stereo_merge_dec(i16 *X, i16 *Y, i32 mid, int N)                    
     i32 rgain = celt_rsqrt_norm(t);
     if (kl < 7) kl = 7;
     if (kr < 7) kr = 7;
-    for (int j = 0; j < N; j++) {
-        i32 l = (i16)mul16_16_p15(mid, X[j]);
-        i32 r = Y[j];
-        X[j] = (i16)pshr32(mul16_16(lgain, sub16(l, r)), kl + 1);
-        Y[j] = (i16)pshr32(mul16_16(rgain, add16(l, r)), kr + 1);
+    for (int j = 0; j < N; j += 4) {                 // loads of a group before its stores
+        i32 xv[4], yv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { xv[u] = j + u < N ? (i32)X[j + u] : 0; yv[u] = j + u < N ? (i32)Y[j + u] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (j + u >= N) continue;
+            i32 l = (i16)mul16_16_p15(mid, xv[u]);
+            i32 r = yv[u];
+            X[j + u] = (i16)pshr32(mul16_16(lgain, sub16(l, r)), kl + 1);
+            Y[j + u] = (i16)pshr32(mul16_16(rgain, add16(l, r)), kr + 1);
+        }
     }
 }
 
@@ -918,7 +970,9 @@ CA_DEV DecResult celt_decode_front(D &F, opusgpu_celt_dec_state *st, const u8 *d
     }
     const int shortBlocks = isTransient ? M : 0;
     const int intra_ener = tell + 3 <= total_bits ? ec_dec_bit_logp(dec, 3) : 0;
+    CA_STAMP_F(F, 0);
     unquant_coarse_energy_dec(oldBandE, intra_ener, dec, C);
+    CA_STAMP_F(F, 1);
     tf_decode_dec(isTransient, F.tf_res, dec);
     tell = ec_tell(dec);
     int spread_decision = SPREAD_NORMAL;
@@ -951,11 +1005,13 @@ CA_DEV DecResult celt_decode_front(D &F, opusgpu_celt_dec_state *st, const u8 *d
     bits -= anti_collapse_rsv;
     AllocOut al = compute_allocation_wave(F, dec, C, alloc_trim, 0, 0, bits, 0, 0);
     unquant_fine_energy_dec(oldBandE, F.fine_quant, dec, C);
+    CA_STAMP_F(F, 2);
 
     u32 rng = st->rng;
     quant_all_bands_dec(F, dec, shortBlocks, spread_decision, al.dual_stereo, al.intensity,
                         len * (8 << BITRES) - anti_collapse_rsv, al.balance, al.codedBands, &rng);
     st->rng = rng;
+    CA_STAMP_F(F, 10);
     int anti_collapse_on = 0;
     if (anti_collapse_rsv > 0) anti_collapse_on = (int)ec_dec_bits(dec, 1);
     unquant_energy_finalise_dec(oldBandE, F.fine_quant, F.fine_priority, len * 8 - ec_tell(dec), dec, C);
@@ -989,6 +1045,7 @@ CA_DEV DecResult celt_decode_front(D &F, opusgpu_celt_dec_state *st, const u8 *d
     st->rng = dec.rng;
 
     st->loss_count = 0;
+    CA_STAMP_F(F, 11);
     if (ec_tell(dec) > 8 * len) { res.samples = OPUSGPU_INTERNAL_ERROR; return res; }
     if (dec.error) st->error = 1;
     res.samples = N;

@@ -40,6 +40,7 @@ SYMBOLS = [
     ("opusgpu_decode", _i, [_vp, _vp, _i, _vp, _i, _i]),
     ("opusgpu_decoder_ctl", _i, None),          # variadic
     ("opusgpu_decoder_destroy", None, [_vp]),
+    ("opusgpu_decode_lane_diag", _i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_back_lane_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
