@@ -26,7 +26,10 @@ def ca():
     return concentus_amd
 
 
-@pytest.mark.parametrize("seed", [11, 22])
+SEEDS = [int(x) for x in os.environ.get("CONCENTUS_FUZZ_SEEDS", "11,22").split(",")]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_gpu_random_settings_match_reference(ca, seed):
     gm = ec.golden_module()
     rng = np.random.default_rng(seed)
