@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "decode"])
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("CONCENTUS_BENCH_STREAMS", "1")),
+                    help="celt: HIP streams the consecutive batches (steps) alternate over (each with its own workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL packet gather (N > 1)")
     return ap.parse_args()
@@ -373,10 +375,28 @@ def main():
         L.opusgpu_kernel_timing_enable(1)          # HIP events around each kernel, on the launch stream
         barrier()
         t0 = time.perf_counter()
+        side = [torch.cuda.Stream(device=dev) for _ in range(max(a.streams, 1))] if a.streams > 1 else None
+        if side:
+            for s_ in side:                        # workspaces of the side streams exist before the clock starts
+                s_.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s_):
+                    ca.encode_independent(pcm, cfg)
+            torch.cuda.synchronize()
+            L.opusgpu_kernel_timing_read((ctypes.c_double * 8)(), (ctypes.c_int * 8)(), 8)
+            barrier()
+            t0 = time.perf_counter()
         for k in range(steps):
-            out, lens, _r = ca.encode_independent(pcm, cfg)
+            if side:
+                # consecutive batches on alternating streams: the next batch's front kernels fill the CUs the
+                # back kernel's last wavefronts leave idle
+                with torch.cuda.stream(side[k % len(side)]):
+                    out, lens, _r = ca.encode_independent(pcm, cfg)
+            else:
+                out, lens, _r = ca.encode_independent(pcm, cfg)
             if world > 1 and not a.no_gather:
                 # the only exchange of the path: packets + lengths to rank 0 over RCCL/xGMI
+                if side:
+                    torch.cuda.current_stream().wait_stream(side[k % len(side)])
                 gathered = gather_packets(out, lens, _r, world)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0

@@ -8,20 +8,30 @@
 #include "celt_lane_tables.h"
 #include "celt_enc.h"
 #include "opusgpu_internal.h"
+#include <stdlib.h>
 
 namespace ca {
 
-__global__ __launch_bounds__(64) void celt_back_lane_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
+// A = frames per wavefront. A == 64 fills every lane; A == 32 / 16 leave the upper lanes of each wavefront idle and
+// put 2 / 4 wavefronts into the 64-frame workgroup instead (same LDS footprint, [element][64] slots shared by the
+// workgroup's waves): the back phase is bound by the latency of one frame's serial chain and by the divergence of the
+// lanes' partition walks, so at a fixed batch size half-filled waves, two per SIMD, hide each other's latency and
+// diverge less than one full wave per SIMD.
+template <int A>
+__global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
                                                             FrameMid *mid, u8 *out, int out_stride,
                                                             int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
 {
     fill_lds_tables();
-    const int n = blockIdx.x * 64 + threadIdx.x;
+    const int l = threadIdx.x & 63;
+    if (l >= A) return;
+    const int slot = (threadIdx.x >> 6) * A + l;
+    const int n = blockIdx.x * 64 + slot;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = g_lds_pvq16 + threadIdx.x;
-    F.lds_pvq32 = g_lds_pvq32 + threadIdx.x;
-    F.lds_xs = g_lds_xs + threadIdx.x;
+    F.lds_pvq16 = g_lds_pvq16 + slot;
+    F.lds_pvq32 = g_lds_pvq32 + slot;
+    F.lds_xs = g_lds_xs + slot;
     opusgpu_celt_state *st = states ? states + n : nullptr;
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;
@@ -30,9 +40,25 @@ __global__ __launch_bounds__(64) void celt_back_lane_kernel(opusgpu_celt_config 
 
 }  // namespace ca
 
+// frames per wavefront of the lane kernels: OPUSGPU_LANE_FRAMES = 64 | 32 | 16 (default below)
+extern "C" int opusgpu_lane_frames(void)
+{
+    // measured on MI355X at 65 536 frames: back kernel 5.91 ms (64) / 5.53 ms (32) / 9.87 ms (16: 218 VGPRs allow two
+    // wavefronts per SIMD, so four quarter-filled ones take two rounds). Read per call so tests can compare the mappings.
+    const char *e = getenv("OPUSGPU_LANE_FRAMES");
+    const int v = e ? atoi(e) : 32;
+    return (v == 16 || v == 32 || v == 64) ? v : 32;
+}
+
 extern "C" void opusgpu_launch_back_lane(const opusgpu_celt_config *cfg, void *states, const void *mid, unsigned char *out,
                                          int out_stride, int32_t *out_len, uint32_t *out_rng, int n, hipStream_t s)
 {
-    hipLaunchKernelGGL(ca::celt_back_lane_kernel, dim3((n + 63) / 64), dim3(64), 0, s, *cfg, (opusgpu_celt_state *)states,
-                       (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n);
+    const int a = opusgpu_lane_frames();
+    const dim3 grid((n + 63) / 64), block(64 * (64 / a));
+#define CA_LAUNCH(A) hipLaunchKernelGGL(ca::celt_back_lane_kernel<A>, grid, block, 0, s, *cfg, (opusgpu_celt_state *)states, \
+                                        (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n)
+    if (a == 32) CA_LAUNCH(32);
+    else if (a == 16) CA_LAUNCH(16);
+    else CA_LAUNCH(64);
+#undef CA_LAUNCH
 }

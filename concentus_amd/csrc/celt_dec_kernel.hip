@@ -15,16 +15,22 @@
 
 namespace ca {
 
-__global__ __launch_bounds__(64) void celt_decode_lane_kernel(opusgpu_celt_dec_state *states, const u8 *__restrict__ packets,
+// A = streams per wavefront (64, or 32 / 16 with 2 / 4 partly filled waves per 64-stream workgroup; see
+// celt_back_lane_kernel.hip)
+template <int A>
+__global__ __launch_bounds__(64 * (64 / A)) void celt_decode_lane_kernel(opusgpu_celt_dec_state *states, const u8 *__restrict__ packets,
                                                               int packet_stride, const int *__restrict__ len,
                                                               int *__restrict__ ret, u32 *__restrict__ rng, int n)
 {
     fill_lds_tables();
-    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int l = threadIdx.x & 63;
+    if (l >= A) return;
+    const int slot = (threadIdx.x >> 6) * A + l;
+    const int k = blockIdx.x * 64 + slot;
     if (k >= n) return;
     DecWork F;
-    F.lds_pvq32 = g_lds_pvq32 + threadIdx.x;
-    F.lds_pvq16 = g_lds_pvq16 + threadIdx.x;
+    F.lds_pvq32 = g_lds_pvq32 + slot;
+    F.lds_pvq16 = g_lds_pvq16 + slot;
     DecResult r = celt_decode_front(F, states + k, packets + (size_t)k * packet_stride, len[k]);
     ret[k] = r.samples;
     rng[k] = r.final_range;
@@ -75,8 +81,16 @@ extern "C" int opusgpu_decode_batch(void *d_states, const unsigned char *d_packe
     if (!d_states || !d_packets || !d_len || !d_pcm || !d_ret || !d_rng || packet_stride <= 0) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_LANE, s);
-    hipLaunchKernelGGL(ca::celt_decode_lane_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, s,
-                       (opusgpu_celt_dec_state *)d_states, d_packets, packet_stride, d_len, d_ret, d_rng, n_streams);
+    {
+        const int a = opusgpu_lane_frames();
+        const dim3 grid((n_streams + 63) / 64), block(64 * (64 / a));
+#define CA_LAUNCH(A) hipLaunchKernelGGL(ca::celt_decode_lane_kernel<A>, grid, block, 0, s, (opusgpu_celt_dec_state *)d_states, \
+                                        d_packets, packet_stride, d_len, d_ret, d_rng, n_streams)
+        if (a == 32) CA_LAUNCH(32);
+        else if (a == 16) CA_LAUNCH(16);
+        else CA_LAUNCH(64);
+#undef CA_LAUNCH
+    }
     opusgpu_timing_end(slot, s);
     slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_SYNTH, s);
     opusgpu_launch_dec_synth(d_states, n_streams, s);

@@ -9,3 +9,5 @@ extern "C" int opusgpu_check_launch(void);
 // optional per-kernel timing (see opusgpu_kernel_timing_enable); slot -1 = timing off
 extern "C" int opusgpu_timing_begin(int kernel, hipStream_t s);
 extern "C" void opusgpu_timing_end(int slot, hipStream_t s);
+// frames (streams) per wavefront of the lane-per-frame kernels: 64, 32 or 16 (OPUSGPU_LANE_FRAMES)
+extern "C" int opusgpu_lane_frames(void);

@@ -61,14 +61,16 @@ WORKSPACE_FRAMES = int(os.environ.get("CONCENTUS_WS_FRAMES", 262144))      # han
 
 
 def _workspace(device, n_frames):
-    """Per-device scratch for the hand-off between the two kernels (allocated once, reused)."""
+    """Scratch for the hand-off between the kernels of one batch, per (device, stream): allocated once and
+    reused; batches launched on different streams (double-buffered callers) must not share it."""
     import torch
     L = _lib.load()
     need = L.opusgpu_encode_workspace_bytes(min(max(n_frames, 1), WORKSPACE_FRAMES))
-    ws = _WORKSPACE.get(device)
+    key = (device, _lib.current_stream_handle().value)
+    ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty((need,), dtype=torch.uint8, device=device)
-        _WORKSPACE[device] = ws
+        _WORKSPACE[key] = ws
     return ws
 
 

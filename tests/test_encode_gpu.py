@@ -144,6 +144,29 @@ def test_wave_per_frame_back_kernel_agrees_with_lane_per_frame(ca, monkeypatch):
     ec.assert_packets_equal(w[0], w[1], w[2], pk, ln, rg, "wave back kernel vs golden")
 
 
+def test_frames_per_wavefront_of_the_lane_kernels(ca, monkeypatch):
+    """The lane-per-frame kernels (encoder back phase, decoder front) run 64, 32 (default) or 16 frames per wavefront
+    (OPUSGPU_LANE_FRAMES; 2 / 4 partly filled waves share the 64-frame workgroup). Same packets, same PCM; the batch
+    size 1000 leaves a ragged last workgroup."""
+    import torch
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm("music", 1000, 5)
+    res = {}
+    for a in (64, 32, 16):
+        monkeypatch.setenv("OPUSGPU_LANE_FRAMES", str(a))
+        pk, ln, rg = _gpu_encode(ca, pcm, 1, (64000, 1, 1, 10))
+        dpcm, ret, drng = ca.decode_independent(torch.from_numpy(pk).cuda(), torch.from_numpy(ln).cuda())
+        res[a] = (pk, ln, rg, dpcm.cpu().numpy(), ret.cpu().numpy(), drng.cpu().numpy().view(np.uint32))
+    monkeypatch.delenv("OPUSGPU_LANE_FRAMES")
+    for a in (64, 16):
+        ec.assert_packets_equal(*res[a][:3], *res[32][:3], "lane frames %d vs 32" % a)
+        assert np.array_equal(res[a][3], res[32][3]) and np.array_equal(res[a][5], res[32][5])
+    assert (res[32][4] == 960).all() and np.array_equal(res[32][5], res[32][2])
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        want = gm.ref_encode(gm._Cfg(2, 64000, 1, 1, 10, 16, 0, 1500), pcm, 1, threads=8)
+        ec.assert_packets_equal(*res[32][:3], *want, "lane frames 32 vs reference")
+
+
 def test_small_workspace_chunks_the_batch(ca, monkeypatch):
     """A workspace smaller than the batch is legal (include/opusgpu.h): the library then runs the pipeline over
     chunks of workspace_bytes / opusgpu_encode_workspace_bytes(1) frames. Same packets, and the fused
