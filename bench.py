@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched Opus frame path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload celt|mdct] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload celt|mdct|silk|decode|mixed] [--frames F]
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM.
 
@@ -12,6 +12,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
                   (~255 B) + 8 B (len, rng) per frame (~4 090 B/frame).
   silk            BASELINE.json configs[3]: 65 536 function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
+  mixed           BASELINE.json configs[4]: per GPU 131 072 units = 7/8 CELT frames (as celt) + 1/8 SILK records (as silk);
+                  with --gpus 8 that is the 1 M-unit corpus sharded over the node.
+  decode          the packets of configs[2] through opusgpu_decode_batch (fresh decoder each).
   mdct            BASELINE.json configs[1]: 4 096 frames, clt_mdct_forward + clt_mdct_backward only
                   (33 600 algorithmic bytes per stereo frame) -- the HBM-bound slice.
 
@@ -47,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "decode"])
+    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "decode", "mixed"])
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("CONCENTUS_BENCH_STREAMS", "1")),
                     help="celt: HIP streams the consecutive batches (steps) alternate over (each with its own workspace)")
@@ -200,6 +203,22 @@ def cpu_baseline_silk(rec, n):
                       "%d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
+def silk_records(F, rank, dev):
+    """F function-boundary records on the device: the 80 captured from the reference encoder (tests/golden), tiled, the
+    Burg inputs dithered per record."""
+    import torch
+    g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz"))
+    rec = {k[5:]: g[k] for k in g.files}
+    reps = F // 80 + 1
+    rng = np.random.default_rng(4 + rank)
+    bi_h = np.tile(rec["burg_in"], (reps, 1))[:F].copy()
+    bi_h[:, :768].view(np.int16)[...] += rng.integers(-3, 4, size=(F, 384), dtype=np.int16)
+    ni_h = np.tile(rec["nsq_in"], (reps, 1))[:F].copy()
+    st_h = np.tile(rec["nsq_state_in"], (reps, 1))[:F].copy()
+    bi, ni, st0 = (torch.from_numpy(x).to(dev) for x in (bi_h, ni_h, st_h))
+    return rec, bi, ni, st0
+
+
 def main():
     a = parse()
     import torch
@@ -319,15 +338,7 @@ def main():
         F = a.frames or 65536
         steps = a.steps or 20
         warm = a.warmup if a.warmup is not None else 3
-        g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz"))
-        rec = {k[5:]: g[k] for k in g.files}
-        reps = F // 80 + 1
-        rng = np.random.default_rng(4 + rank)
-        bi_h = np.tile(rec["burg_in"], (reps, 1))[:F].copy()
-        bi_h[:, :768].view(np.int16)[...] += rng.integers(-3, 4, size=(F, 384), dtype=np.int16)
-        ni_h = np.tile(rec["nsq_in"], (reps, 1))[:F].copy()
-        st_h = np.tile(rec["nsq_state_in"], (reps, 1))[:F].copy()
-        bi, ni, st0 = (torch.from_numpy(x).to(dev) for x in (bi_h, ni_h, st_h))
+        rec, bi, ni, st0 = silk_records(F, rank, dev)
         st = st0.clone()
         bo = torch.empty((F, 72), dtype=torch.uint8, device=dev)
         pulses = torch.empty((F, 320), dtype=torch.int8, device=dev)
@@ -358,16 +369,40 @@ def main():
         extra = {"burg_kernel_ms": round(burg_ms, 5), "burg_GBps": round(F * 856 / (burg_ms * 1e-3) / 1e9, 2)}
         cpu = (lambda: cpu_baseline_silk(rec, 8192))
     else:
-        F = a.frames or 65536
-        steps = a.steps or 10
+        mixed = a.workload == "mixed"
+        # mixed = BASELINE configs[4]: per GPU a shard of 131 072 units, 7/8 CELT frames (config #3's kind) and 1/8 SILK
+        # records (config #4's kind); the 8-GPU job is then the 1 M-unit corpus
+        FT = a.frames or (131072 if mixed else 65536)
+        from concentus_amd.sharding import mixed_counts
+        F, NS = mixed_counts(FT) if mixed else (FT, 0)
+        steps = a.steps or (5 if mixed else 10)
         warm = a.warmup if a.warmup is not None else 2
         cfg = ca.default_config(2, 96000)          # opus_demo restricted-lowdelay 48000 2 96000, complexity 10, VBR
-        rng = np.random.default_rng(3 + rank)      # seed 3, uniform int16 in [-8192, 8191]
+        rng = np.random.default_rng((5 if mixed else 3) + rank)      # seed 3 (config #3) / 5 (config #5), uniform int16 in [-8192, 8191]
         host = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
         pcm = torch.from_numpy(host).to(dev)
         out = lens = None
+        if mixed:
+            _rec, s_bi, s_ni, s_st = silk_records(NS, rank, dev)
+            s_bo = torch.empty((NS, 72), dtype=torch.uint8, device=dev)
+            s_pulses = torch.empty((NS, 320), dtype=torch.int8, device=dev)
+            silk_stream = torch.cuda.Stream(device=dev)
+
+            def silk_part():
+                # the SILK records are independent of the CELT frames: their two small kernels go to a stream of their own
+                silk_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(silk_stream):
+                    ca.silk_burg_modified(s_bi, s_bo)
+                    ca.silk_NSQ(s_ni, s_st, s_pulses)
+
+            def silk_join():
+                torch.cuda.current_stream().wait_stream(silk_stream)
         for _ in range(warm):
+            if mixed:
+                silk_part()
             out, lens, _r = ca.encode_independent(pcm, cfg)
+            if mixed:
+                silk_join()
         torch.cuda.synchronize()
         from concentus_amd.sharding import gather_packets
         import ctypes
@@ -392,12 +427,18 @@ def main():
                 with torch.cuda.stream(side[k % len(side)]):
                     out, lens, _r = ca.encode_independent(pcm, cfg)
             else:
+                if mixed:
+                    silk_part()
                 out, lens, _r = ca.encode_independent(pcm, cfg)
+                if mixed:
+                    silk_join()
             if world > 1 and not a.no_gather:
                 # the only exchange of the path: packets + lengths to rank 0 over RCCL/xGMI
                 if side:
                     torch.cuda.current_stream().wait_stream(side[k % len(side)])
                 gathered = gather_packets(out, lens, _r, world)
+                if mixed:
+                    gathered_silk = gather_packets(s_pulses, s_bo, s_bo[:, :4], world)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
@@ -442,6 +483,14 @@ def main():
         extra = {"mean_packet_bytes": round(mean_len, 2), "frames_per_launch": dom["frames_per_launch"],
                  "other_kernels": kern[1:], "realtime_factor": None}
         cpu = (lambda: cpu_baseline_celt(host[:4096], (2, 96000, 1, 0, 10, 16, 0, 1500)))
+        if mixed:
+            metric = "mixed CELT/SILK 20ms frames processed/sec (configs[4]: 7/8 CELT encode, 1/8 SILK burg+NSQ records)"
+            workload = ("configs[4]: %d units per GPU = %d independent 48 kHz stereo CELT frames (full encode, 96 kb/s VBR "
+                        "complexity 10, mean packet %.1f B) + %d SILK function-boundary records (silk_burg_modified + silk_NSQ), "
+                        "bit-exact vs FIXED_POINT; the SILK kernels run on a side stream" % (FT, F, mean_len, NS))
+            extra["celt_frames_per_gpu"], extra["silk_records_per_gpu"] = F, NS
+            extra.pop("realtime_factor", None)
+            F = FT
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:

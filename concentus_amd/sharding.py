@@ -43,3 +43,12 @@ def gather_packets(out, lens, rng, world=None, dst=0):
         if rank == dst:
             results.append(torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0))
     return tuple(results) if rank == dst else None
+
+
+def mixed_counts(n_units, silk_eighths=1):
+    """BASELINE configs[4] / SURVEY 8d config #5: a shard of n_units mixed units holds 7/8 CELT frames and 1/8 SILK
+    records (silk_eighths / 8 in general). Returns (n_celt, n_silk) with n_celt + n_silk == n_units."""
+    if n_units < 0 or not 0 <= silk_eighths <= 8:
+        raise ValueError("mixed_counts")
+    n_celt = n_units * (8 - silk_eighths) // 8
+    return n_celt, n_units - n_celt

@@ -74,6 +74,28 @@ size_t opusgpu_silk_nsq_workspace_bytes(int n);
 int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, int n,
                            void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* ---- silk_NSQ_del_dec(): the quantizer the reference uses at complexity >= 4 (silk/fixed/encode_frame_FIX.c:311,
+ * silk/control_codec.c:345-377: 2, 3 or 4 delayed-decision states, warped noise shaping) ----
+ *   silk_NSQ_del_dec_c                    opus-fix/silk/NSQ_del_dec.c:112-318 (macro silk_NSQ_del_dec, silk/main.h:271-296)
+ *   silk_noise_shape_quantizer_del_dec    :324-630,   silk_nsq_del_dec_scale_states :632-724
+ * One record = the arguments of one call: everything silk_NSQ() takes plus the two psEncC fields only this
+ * quantizer reads. The NSQ state record is the same opusgpu_nsq_state. */
+#define OPUSGPU_SILK_MAX_DEL_DEC_STATES 4    /* MAX_DEL_DEC_STATES, silk/define.h:160 */
+typedef struct opusgpu_nsq_dd_in {
+    opusgpu_nsq_in base;
+    int32_t nStatesDelayedDecision;          /* 1..4 */
+    int32_t warping_Q16;
+} opusgpu_nsq_dd_in;
+
+typedef struct opusgpu_nsq_dd_out {
+    int8_t pulses[OPUSGPU_SILK_MAX_FRAME];
+    int32_t Seed;                            /* psIndices->Seed after the call (the winner's initial seed, NSQ_del_dec.c:297) */
+} opusgpu_nsq_dd_out;
+
+size_t opusgpu_silk_nsq_del_dec_workspace_bytes(int n);
+int opusgpu_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_dd_out *d_out, int n,
+                                   void *d_workspace, size_t workspace_bytes, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
  *   silk_nsq_scale_states       opus-fix/silk/NSQ.c:423-496
  *   silk_LPC_analysis_filter    opus-fix/silk/LPC_analysis_filter.c:47-108 (FIXED_POINT branch -> celt_fir, celt/celt_lpc.c:93-150)
  *   silk_DIV32_varQ / silk_INVERSE32_varQ / silk_SQRT_APPROX   opus-fix/silk/Inlines.h:68-186
+ *   silk_NSQ_del_dec_c (+ its quantizer and state scaling)  opus-fix/silk/NSQ_del_dec.c:112-724
  * with the 64-bit macro forms the x86-64 reference build uses (OPUS_FAST_INT64, silk/macros.h:47-102).
  * Pinned bit-exact against records captured from the compiled reference (tests/test_oracle_silk.py).
  */
@@ -430,6 +431,299 @@ void orc_silk_nsq(const opusgpu_nsq_in *in, opusgpu_nsq_state *NSQ, opusgpu_nsq_
     NSQ->lagPrev = in->pitchL[nb_subfr - 1];
     memmove(NSQ->xq, &NSQ->xq[frame_length], ltp_mem_length * sizeof(i16));
     memmove(NSQ->sLTP_shp_Q14, &NSQ->sLTP_shp_Q14[frame_length], ltp_mem_length * sizeof(i32));
+}
+
+/* ---- silk_NSQ_del_dec_c and its helpers: opus-fix/silk/NSQ_del_dec.c:112-318 (driver), :324-630 (quantizer of one
+ * subframe), :632-724 (state scaling). One candidate path ("delayed-decision state") is a DdState; the field order is the
+ * reference's NSQ_del_dec_struct (:35-47) because the survivor copy at :583-584 is a memcpy from int32 offset i to the
+ * end of the struct. ---- */
+#define DD_DELAY 32                                     /* DECISION_DELAY, silk/define.h:157 */
+typedef struct {
+    i32 lpc[80 + 32];                                   /* sLPC_Q14 */
+    i32 rnd[DD_DELAY], q[DD_DELAY], xq[DD_DELAY], pred[DD_DELAY], shape[DD_DELAY];
+    i32 ar2[16];
+    i32 lf_ar, seed, seed0, rd;
+} DdState;
+typedef struct { i32 q, rd, xq, lf_ar, shp, exc; } DdCand;      /* NSQ_sample_struct :49-56 */
+
+static int dd_winner(const DdState *dd, int n)          /* :193-201, :285-292: first strict minimum */
+{
+    int w = 0;
+    for (int k = 1; k < n; k++) if (dd[k].rd < dd[w].rd) w = k;
+    return w;
+}
+
+void orc_silk_nsq_del_dec(const opusgpu_nsq_dd_in *din, opusgpu_nsq_state *NSQ, opusgpu_nsq_dd_out *outp)
+{
+    const opusgpu_nsq_in *in = &din->base;
+    const int nst = din->nStatesDelayedDecision, warping_Q16 = din->warping_Q16;
+    const int nb_subfr = in->nb_subfr, L = in->subfr_length, frame_length = in->frame_length;
+    const int ltp_mem = in->ltp_mem_length, pord = in->predictLPCOrder, sord = in->shapingLPCOrder;
+    const int voiced = in->signalType == 2;
+    i32 sLTP_Q15[640], x_sc_Q10[80], delayedGain_Q10[DD_DELAY];
+    i16 sLTP[640];
+    DdState dd[4];
+    DdCand cand[4][2];
+    const i32 *x_Q3 = in->x_Q3;
+    i8 *pulses = outp->pulses;
+    int lag = NSQ->lagPrev, k, i, j;
+
+    memset(dd, 0, sizeof(dd));
+    memset(delayedGain_Q10, 0, sizeof(delayedGain_Q10));
+    for (k = 0; k < nst; k++) {
+        dd[k].seed = dd[k].seed0 = (k + in->Seed) & 3;
+        dd[k].lf_ar = NSQ->sLF_AR_shp_Q14;
+        dd[k].shape[0] = NSQ->sLTP_shp_Q14[ltp_mem - 1];
+        memcpy(dd[k].lpc, NSQ->sLPC_Q14, 32 * sizeof(i32));
+        memcpy(dd[k].ar2, NSQ->sAR2_Q14, sizeof(dd[k].ar2));
+    }
+    const int offset_Q10 = QUANT_OFFSETS_Q10[in->signalType >> 1][in->quantOffsetType];
+    int smpl = 0;                                       /* index of the oldest entry of the 32-deep rings */
+    int delay = L < DD_DELAY ? L : DD_DELAY;
+    if (voiced) {
+        for (k = 0; k < nb_subfr; k++) if (in->pitchL[k] - 5 / 2 - 1 < delay) delay = in->pitchL[k] - 5 / 2 - 1;
+    } else if (lag > 0 && lag - 5 / 2 - 1 < delay) {
+        delay = lag - 5 / 2 - 1;
+    }
+    const int interp = in->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
+    i16 *pxq = &NSQ->xq[ltp_mem];
+    NSQ->sLTP_shp_buf_idx = ltp_mem;
+    NSQ->sLTP_buf_idx = ltp_mem;
+    int subfr = 0;
+    for (k = 0; k < nb_subfr; k++) {
+        const i16 *A_Q12 = &in->PredCoef_Q12[((k >> 1) | (1 - interp)) * 16];
+        const i16 *B_Q14 = &in->LTPCoef_Q14[k * 5];
+        const i16 *AR_Q13 = &in->AR2_Q13[k * 16];
+        i32 harm = in->HarmShapeGain_Q14[k] >> 2;
+        harm |= s_lshift((i32)(in->HarmShapeGain_Q14[k] >> 1), 16);
+        NSQ->rewhite_flag = 0;
+        if (voiced) {
+            lag = in->pitchL[k];
+            if ((k & (3 - (interp << 1))) == 0) {
+                if (k == 2) {                           /* :190-221: flush the survivor before the filters change */
+                    int w = dd_winner(dd, nst);
+                    for (i = 0; i < nst; i++) if (i != w) dd[i].rd = (i32)((u32)dd[i].rd + (0x7FFFFFFF >> 4));
+                    int last = smpl + delay;
+                    for (i = 0; i < delay; i++) {
+                        last = (last - 1) & (DD_DELAY - 1);
+                        pulses[i - delay] = (i8)s_rshift_round(dd[w].q[last], 10);
+                        i32 v = s_rshift_round(s_smulww(dd[w].xq[last], in->Gains_Q16[1]), 14);
+                        pxq[i - delay] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+                        NSQ->sLTP_shp_Q14[NSQ->sLTP_shp_buf_idx - delay + i] = dd[w].shape[last];
+                    }
+                    subfr = 0;
+                }
+                int start_idx = ltp_mem - lag - pord - 5 / 2;
+                lpc_analysis_filter(&sLTP[start_idx], &NSQ->xq[start_idx + k * L], A_Q12, ltp_mem - start_idx, pord);
+                NSQ->sLTP_buf_idx = ltp_mem;
+                NSQ->rewhite_flag = 1;
+            }
+        }
+        /* ---- silk_nsq_del_dec_scale_states :632-724 ---- */
+        {
+            const int lg = in->pitchL[k];
+            const i32 gain = in->Gains_Q16[k];
+            i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
+            const i32 adj = gain != NSQ->prev_gain_Q16 ? s_div32_varq(NSQ->prev_gain_Q16, gain, 16) : (i32)1 << 16;
+            const i32 inv_gain_Q23 = s_rshift_round(inv_gain_Q31, 8);
+            for (i = 0; i < L; i++) x_sc_Q10[i] = s_smulww(x_Q3[i], inv_gain_Q23);
+            NSQ->prev_gain_Q16 = gain;
+            if (NSQ->rewhite_flag) {
+                if (k == 0) inv_gain_Q31 = s_lshift(s_smulwb(inv_gain_Q31, in->LTP_scale_Q14), 2);
+                for (i = NSQ->sLTP_buf_idx - lg - 5 / 2; i < NSQ->sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
+            }
+            if (adj != (i32)1 << 16) {
+                for (i = NSQ->sLTP_shp_buf_idx - ltp_mem; i < NSQ->sLTP_shp_buf_idx; i++)
+                    NSQ->sLTP_shp_Q14[i] = s_smulww(adj, NSQ->sLTP_shp_Q14[i]);
+                if (voiced && NSQ->rewhite_flag == 0)
+                    for (i = NSQ->sLTP_buf_idx - lg - 5 / 2; i < NSQ->sLTP_buf_idx - delay; i++) sLTP_Q15[i] = s_smulww(adj, sLTP_Q15[i]);
+                for (j = 0; j < nst; j++) {
+                    dd[j].lf_ar = s_smulww(adj, dd[j].lf_ar);
+                    for (i = 0; i < 32; i++) dd[j].lpc[i] = s_smulww(adj, dd[j].lpc[i]);
+                    for (i = 0; i < 16; i++) dd[j].ar2[i] = s_smulww(adj, dd[j].ar2[i]);
+                    for (i = 0; i < DD_DELAY; i++) {
+                        dd[j].pred[i] = s_smulww(adj, dd[j].pred[i]);
+                        dd[j].shape[i] = s_smulww(adj, dd[j].shape[i]);
+                    }
+                }
+            }
+        }
+        /* ---- silk_noise_shape_quantizer_del_dec :324-630 ---- */
+        {
+            const i32 Gain_Q10 = in->Gains_Q16[k] >> 6;
+            const int Tilt_Q14 = in->Tilt_Q14[k], Lambda_Q10 = in->Lambda_Q10;
+            const i32 LF_shp_Q14 = in->LF_shp_Q14[k];
+            const i32 *shp_lag = &NSQ->sLTP_shp_Q14[NSQ->sLTP_shp_buf_idx - lag + 3 / 2];
+            const i32 *pred_lag = &sLTP_Q15[NSQ->sLTP_buf_idx - lag + 5 / 2];
+            for (i = 0; i < L; i++) {
+                i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
+                if (voiced) {
+                    LTP_pred_Q14 = 2;
+                    for (j = 0; j < 5; j++) LTP_pred_Q14 = s_smlawb(LTP_pred_Q14, pred_lag[-j], B_Q14[j]);
+                    LTP_pred_Q14 = s_lshift(LTP_pred_Q14, 1);
+                    pred_lag++;
+                }
+                if (lag > 0) {
+                    n_LTP_Q14 = s_smulwb((i32)((u32)shp_lag[0] + (u32)shp_lag[-2]), harm);
+                    n_LTP_Q14 = s_smlawt(n_LTP_Q14, shp_lag[-1], harm);
+                    n_LTP_Q14 = (i32)((u32)LTP_pred_Q14 - ((u32)n_LTP_Q14 << 2));
+                    shp_lag++;
+                }
+                for (int s = 0; s < nst; s++) {
+                    DdState *d = &dd[s];
+                    DdCand *c = cand[s];
+                    d->seed = (i32)(907633515u + (u32)d->seed * 196314165u);
+                    const i32 *lp = &d->lpc[32 - 1 + i];
+                    i32 LPC_pred_Q14 = pord >> 1;
+                    for (j = 0; j < pord; j++) LPC_pred_Q14 = s_smlawb(LPC_pred_Q14, lp[-j], A_Q12[j]);
+                    LPC_pred_Q14 = s_lshift(LPC_pred_Q14, 4);
+                    /* warped noise-shaping filter: a chain of first-order all-pass sections (:419-440) */
+                    i32 tmp2 = s_smlawb(lp[0], d->ar2[0], warping_Q16);
+                    i32 tmp1 = s_smlawb(d->ar2[0], (i32)((u32)d->ar2[1] - (u32)tmp2), warping_Q16);
+                    d->ar2[0] = tmp2;
+                    i32 n_AR_Q14 = sord >> 1;
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[0]);
+                    for (j = 2; j < sord; j += 2) {
+                        tmp2 = s_smlawb(d->ar2[j - 1], (i32)((u32)d->ar2[j] - (u32)tmp1), warping_Q16);
+                        d->ar2[j - 1] = tmp1;
+                        n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[j - 1]);
+                        tmp1 = s_smlawb(d->ar2[j], (i32)((u32)d->ar2[j + 1] - (u32)tmp2), warping_Q16);
+                        d->ar2[j] = tmp2;
+                        n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[j]);
+                    }
+                    d->ar2[sord - 1] = tmp1;
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[sord - 1]);
+                    n_AR_Q14 = s_lshift(n_AR_Q14, 1);
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, d->lf_ar, Tilt_Q14);
+                    n_AR_Q14 = s_lshift(n_AR_Q14, 2);
+                    i32 n_LF_Q14 = s_smulwb(d->shape[smpl], LF_shp_Q14);
+                    n_LF_Q14 = s_smlawt(n_LF_Q14, d->lf_ar, LF_shp_Q14);
+                    n_LF_Q14 = s_lshift(n_LF_Q14, 2);
+                    tmp1 = (i32)((u32)n_AR_Q14 + (u32)n_LF_Q14);
+                    tmp2 = (i32)((u32)n_LTP_Q14 + (u32)LPC_pred_Q14);
+                    tmp1 = (i32)((u32)tmp2 - (u32)tmp1);
+                    tmp1 = s_rshift_round(tmp1, 4);
+                    i32 r_Q10 = (i32)((u32)x_sc_Q10[i] - (u32)tmp1);
+                    if (d->seed < 0) r_Q10 = (i32)(0u - (u32)r_Q10);
+                    r_Q10 = s_limit(r_Q10, -(31 << 10), 30 << 10);
+                    i32 q1_Q10 = r_Q10 - offset_Q10, q2_Q10, rd1, rd2;
+                    i32 q1_Q0 = q1_Q10 >> 10;
+                    if (q1_Q0 > 0) {
+                        q1_Q10 = s_lshift(q1_Q0, 10) - 80 + offset_Q10;
+                        q2_Q10 = q1_Q10 + 1024;
+                        rd1 = s_smulbb(q1_Q10, Lambda_Q10);
+                        rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else if (q1_Q0 == 0) {
+                        q1_Q10 = offset_Q10;
+                        q2_Q10 = q1_Q10 + (1024 - 80);
+                        rd1 = s_smulbb(q1_Q10, Lambda_Q10);
+                        rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else if (q1_Q0 == -1) {
+                        q2_Q10 = offset_Q10;
+                        q1_Q10 = q2_Q10 - (1024 - 80);
+                        rd1 = s_smulbb(-q1_Q10, Lambda_Q10);
+                        rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else {
+                        q1_Q10 = s_lshift(q1_Q0, 10) + 80 + offset_Q10;
+                        q2_Q10 = q1_Q10 + 1024;
+                        rd1 = s_smulbb(-q1_Q10, Lambda_Q10);
+                        rd2 = s_smulbb(-q2_Q10, Lambda_Q10);
+                    }
+                    i32 rr = r_Q10 - q1_Q10;
+                    rd1 = (rd1 + s_smulbb(rr, rr)) >> 10;
+                    rr = r_Q10 - q2_Q10;
+                    rd2 = (rd2 + s_smulbb(rr, rr)) >> 10;
+                    const int first_is_q1 = rd1 < rd2;
+                    c[0].rd = (i32)((u32)d->rd + (u32)(first_is_q1 ? rd1 : rd2));
+                    c[1].rd = (i32)((u32)d->rd + (u32)(first_is_q1 ? rd2 : rd1));
+                    c[0].q = first_is_q1 ? q1_Q10 : q2_Q10;
+                    c[1].q = first_is_q1 ? q2_Q10 : q1_Q10;
+                    for (j = 0; j < 2; j++) {
+                        i32 exc_Q14 = s_lshift(c[j].q, 4);
+                        if (d->seed < 0) exc_Q14 = -exc_Q14;
+                        c[j].exc = (i32)((u32)exc_Q14 + (u32)LTP_pred_Q14);
+                        c[j].xq = (i32)((u32)c[j].exc + (u32)LPC_pred_Q14);
+                        c[j].lf_ar = (i32)((u32)c[j].xq - (u32)n_AR_Q14);
+                        c[j].shp = (i32)((u32)c[j].lf_ar - (u32)n_LF_Q14);
+                    }
+                }
+                smpl = (smpl - 1) & (DD_DELAY - 1);
+                const int last = (smpl + delay) & (DD_DELAY - 1);
+                int w = 0;
+                for (j = 1; j < nst; j++) if (cand[j][0].rd < cand[w][0].rd) w = j;
+                const i32 wrand = dd[w].rnd[last];
+                for (j = 0; j < nst; j++) {
+                    if (dd[j].rnd[last] != wrand) {      /* paths that disagree with the winner on the expiring sample (:544-552) */
+                        cand[j][0].rd = (i32)((u32)cand[j][0].rd + (0x7FFFFFFF >> 4));
+                        cand[j][1].rd = (i32)((u32)cand[j][1].rd + (0x7FFFFFFF >> 4));
+                    }
+                }
+                int worst = 0, best2 = 0;
+                for (j = 1; j < nst; j++) {
+                    if (cand[j][0].rd > cand[worst][0].rd) worst = j;
+                    if (cand[j][1].rd < cand[best2][1].rd) best2 = j;
+                }
+                if (cand[best2][1].rd < cand[worst][0].rd) {
+                    memcpy((i32 *)&dd[worst] + i, (i32 *)&dd[best2] + i, sizeof(DdState) - i * sizeof(i32));
+                    cand[worst][0] = cand[best2][1];
+                }
+                if (subfr > 0 || i >= delay) {
+                    const DdState *d = &dd[w];
+                    pulses[i - delay] = (i8)s_rshift_round(d->q[last], 10);
+                    i32 v = s_rshift_round(s_smulww(d->xq[last], delayedGain_Q10[last]), 8);
+                    pxq[i - delay] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+                    NSQ->sLTP_shp_Q14[NSQ->sLTP_shp_buf_idx - delay] = d->shape[last];
+                    sLTP_Q15[NSQ->sLTP_buf_idx - delay] = d->pred[last];
+                }
+                NSQ->sLTP_shp_buf_idx++;
+                NSQ->sLTP_buf_idx++;
+                for (j = 0; j < nst; j++) {
+                    DdState *d = &dd[j];
+                    const DdCand *c = &cand[j][0];
+                    d->lf_ar = c->lf_ar;
+                    d->lpc[32 + i] = c->xq;
+                    d->xq[smpl] = c->xq;
+                    d->q[smpl] = c->q;
+                    d->pred[smpl] = s_lshift(c->exc, 1);
+                    d->shape[smpl] = c->shp;
+                    d->seed = (i32)((u32)d->seed + (u32)s_rshift_round(c->q, 10));
+                    d->rnd[smpl] = d->seed;
+                    d->rd = c->rd;
+                }
+                delayedGain_Q10[smpl] = Gain_Q10;
+            }
+            for (j = 0; j < nst; j++) memcpy(dd[j].lpc, &dd[j].lpc[L], 32 * sizeof(i32));
+        }
+        subfr++;
+        x_Q3 += L;
+        pulses += L;
+        pxq += L;
+    }
+    {   /* :285-309: flush the last `delay` samples of the winning path */
+        const int w = dd_winner(dd, nst);
+        const DdState *d = &dd[w];
+        outp->Seed = d->seed0;
+        int last = smpl + delay;
+        const i32 Gain_Q10 = in->Gains_Q16[nb_subfr - 1] >> 6;
+        for (i = 0; i < delay; i++) {
+            last = (last - 1) & (DD_DELAY - 1);
+            pulses[i - delay] = (i8)s_rshift_round(d->q[last], 10);
+            i32 v = s_rshift_round(s_smulww(d->xq[last], Gain_Q10), 8);
+            pxq[i - delay] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+            NSQ->sLTP_shp_Q14[NSQ->sLTP_shp_buf_idx - delay + i] = d->shape[last];
+        }
+        memcpy(NSQ->sLPC_Q14, &d->lpc[L], 32 * sizeof(i32));
+        memcpy(NSQ->sAR2_Q14, d->ar2, sizeof(d->ar2));
+        NSQ->sLF_AR_shp_Q14 = d->lf_ar;
+    }
+    NSQ->lagPrev = in->pitchL[nb_subfr - 1];
+    memmove(NSQ->xq, &NSQ->xq[frame_length], ltp_mem * sizeof(i16));
+    memmove(NSQ->sLTP_shp_Q14, &NSQ->sLTP_shp_Q14[frame_length], ltp_mem * sizeof(i32));
+}
+
+void orc_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *in, opusgpu_nsq_state *st, opusgpu_nsq_dd_out *out, int n)
+{
+    for (int i = 0; i < n; i++) orc_silk_nsq_del_dec(&in[i], &st[i], &out[i]);
 }
 
 void orc_silk_burg_batch(const opusgpu_burg_in *in, opusgpu_burg_out *out, int n)

@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -91,5 +91,64 @@ void __wrap_silk_NSQ_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, Si
         memcpy(&g_nst_out[rec], NSQ, sizeof(*NSQ));
         memcpy(g_nout[rec].pulses, pulses, psEncC->frame_length);
         g_nn++;
+    }
+}
+
+/* ---- silk_NSQ_del_dec_c (opus-fix/silk/NSQ_del_dec.c:112) ---- */
+static opusgpu_nsq_dd_in *g_din; static opusgpu_nsq_state *g_dst_in, *g_dst_out; static opusgpu_nsq_dd_out *g_dout;
+static int g_nd, g_capd;
+void refcap_start_dd(int max_records)
+{
+    g_capd = max_records; g_nd = 0; g_on = 1;
+    g_din = (opusgpu_nsq_dd_in *)calloc(max_records, sizeof(*g_din));
+    g_dst_in = (opusgpu_nsq_state *)calloc(max_records, sizeof(*g_dst_in));
+    g_dst_out = (opusgpu_nsq_state *)calloc(max_records, sizeof(*g_dst_out));
+    g_dout = (opusgpu_nsq_dd_out *)calloc(max_records, sizeof(*g_dout));
+}
+int refcap_count_dd(void) { return g_nd; }
+int refcap_sizes_dd(int which) { return which == 0 ? sizeof(opusgpu_nsq_dd_in) : which == 1 ? sizeof(opusgpu_nsq_state) : sizeof(opusgpu_nsq_dd_out); }
+void refcap_get_dd(void *din, void *st_in, void *st_out, void *dout)
+{
+    memcpy(din, g_din, (size_t)g_nd * sizeof(*g_din)); memcpy(st_in, g_dst_in, (size_t)g_nd * sizeof(*g_dst_in));
+    memcpy(st_out, g_dst_out, (size_t)g_nd * sizeof(*g_dst_out)); memcpy(dout, g_dout, (size_t)g_nd * sizeof(*g_dout));
+}
+
+void __real_silk_NSQ_del_dec_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, SideInfoIndices *psIndices, const opus_int32 x_Q3[],
+                       opus_int8 pulses[], const opus_int16 PredCoef_Q12[], const opus_int16 LTPCoef_Q14[], const opus_int16 AR2_Q13[],
+                       const opus_int HarmShapeGain_Q14[], const opus_int Tilt_Q14[], const opus_int32 LF_shp_Q14[],
+                       const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14);
+void __wrap_silk_NSQ_del_dec_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, SideInfoIndices *psIndices, const opus_int32 x_Q3[],
+                       opus_int8 pulses[], const opus_int16 PredCoef_Q12[], const opus_int16 LTPCoef_Q14[], const opus_int16 AR2_Q13[],
+                       const opus_int HarmShapeGain_Q14[], const opus_int Tilt_Q14[], const opus_int32 LF_shp_Q14[],
+                       const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14)
+{
+    int rec = (g_on && g_din && g_nd < g_capd && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nd : -1;
+    if (rec >= 0) {
+        opusgpu_nsq_in *r = &g_din[rec].base;
+        r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
+        r->ltp_mem_length = psEncC->ltp_mem_length; r->predictLPCOrder = psEncC->predictLPCOrder;
+        r->shapingLPCOrder = psEncC->shapingLPCOrder;
+        r->signalType = psIndices->signalType; r->quantOffsetType = psIndices->quantOffsetType;
+        r->NLSFInterpCoef_Q2 = psIndices->NLSFInterpCoef_Q2; r->Seed = psIndices->Seed;
+        r->Lambda_Q10 = Lambda_Q10; r->LTP_scale_Q14 = LTP_scale_Q14;
+        for (int k = 0; k < 4; k++) {
+            r->HarmShapeGain_Q14[k] = HarmShapeGain_Q14[k]; r->Tilt_Q14[k] = Tilt_Q14[k]; r->LF_shp_Q14[k] = LF_shp_Q14[k];
+            r->Gains_Q16[k] = Gains_Q16[k]; r->pitchL[k] = pitchL[k];
+        }
+        memcpy(r->x_Q3, x_Q3, sizeof(opus_int32) * psEncC->frame_length);
+        memcpy(r->PredCoef_Q12, PredCoef_Q12, sizeof(r->PredCoef_Q12));
+        memcpy(r->LTPCoef_Q14, LTPCoef_Q14, sizeof(r->LTPCoef_Q14));
+        memcpy(r->AR2_Q13, AR2_Q13, sizeof(r->AR2_Q13));
+        g_din[rec].nStatesDelayedDecision = psEncC->nStatesDelayedDecision;
+        g_din[rec].warping_Q16 = psEncC->warping_Q16;
+        memcpy(&g_dst_in[rec], NSQ, sizeof(*NSQ));
+    }
+    __real_silk_NSQ_del_dec_c(psEncC, NSQ, psIndices, x_Q3, pulses, PredCoef_Q12, LTPCoef_Q14, AR2_Q13, HarmShapeGain_Q14, Tilt_Q14,
+                      LF_shp_Q14, Gains_Q16, pitchL, Lambda_Q10, LTP_scale_Q14);
+    if (rec >= 0) {
+        memcpy(&g_dst_out[rec], NSQ, sizeof(*NSQ));
+        memcpy(g_dout[rec].pulses, pulses, psEncC->frame_length);
+        g_dout[rec].Seed = psIndices->Seed;
+        g_nd++;
     }
 }

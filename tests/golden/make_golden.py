@@ -237,6 +237,44 @@ def silk_capture(pcm16k, max_records=200000, complexity=3, bitrate=32000):
     return dict(burg_in=bufs[0], burg_out=bufs[1], nsq_in=bufs[2], nsq_state_in=bufs[3], nsq_state_out=bufs[4], nsq_out=bufs[5])
 
 
+def silk_dd_capture(pcm16k, complexity, max_records=200000, bitrate=32000):
+    """As silk_capture, for silk_NSQ_del_dec (the quantizer of complexity >= 4): records of include/opusgpu_silk.h
+    (opusgpu_nsq_dd_in, state in/out, opusgpu_nsq_dd_out)."""
+    lib = C.CDLL(os.path.join(os.path.dirname(HERE), "..", "oracle", "_ref", "libopus_ref_silkcap.so"))
+    lib.opus_encoder_create.restype = C.c_void_p
+    lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.refcap_start_dd(max_records)
+    err = C.c_int()
+    enc = C.c_void_p(lib.opus_encoder_create(16000, 1, 2048, C.byref(err)))
+    for req, v in ((4002, bitrate), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
+        lib.opus_encoder_ctl(enc, req, v)
+    out = (C.c_ubyte * 1500)()
+    for f in range(len(pcm16k) // 320):
+        fr = np.ascontiguousarray(pcm16k[f * 320:(f + 1) * 320])
+        assert lib.opus_encode(enc, fr.ctypes.data_as(C.c_void_p), 320, out, 1500) > 0
+    n = lib.refcap_count_dd()
+    sz = [lib.refcap_sizes_dd(i) for i in range(3)]
+    bufs = [np.zeros((n, sz[0]), np.uint8), np.zeros((n, sz[1]), np.uint8), np.zeros((n, sz[1]), np.uint8), np.zeros((n, sz[2]), np.uint8)]
+    lib.refcap_get_dd(*[_p(b) for b in bufs])
+    return dict(dd_in=bufs[0], dd_state_in=bufs[1], dd_state_out=bufs[2], dd_out=bufs[3])
+
+
+def silk_dd_vectors(per_source=14):
+    srcs = [synth_voice(16000 * 6, 41)]
+    raw = "/root/reference/Java/ConcentusTestConsole/src/main/resources/AudioData/16Khz Mono.raw"
+    if os.path.exists(raw):
+        srcs.append(np.fromfile(raw, dtype="<i2")[:16000 * 6])
+    parts = [silk_dd_capture(s_, cx) for cx in (5, 7, 10) for s_ in srcs]      # 2, 3 and 4 delayed-decision states
+    out = {}
+    for k in parts[0]:
+        sel = []
+        for p in parts:
+            n = p[k].shape[0]
+            sel.append(p[k][np.linspace(0, n - 1, per_source).astype(int)])
+        out["silk_" + k] = np.concatenate(sel)
+    return out
+
+
 def silk_vectors():
     parts = []
     parts.append(silk_capture(synth_voice(16000 * 6, 41)))
@@ -257,3 +295,5 @@ def silk_vectors():
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "silk_golden.npz"), **silk_vectors())
     print("wrote silk_golden.npz")
+    np.savez_compressed(os.path.join(HERE, "silk_dd_golden.npz"), **silk_dd_vectors())
+    print("wrote silk_dd_golden.npz")

@@ -44,3 +44,41 @@ def test_oracle_silk_matches_fresh_capture():
     rec = gm.silk_capture(gm.synth_voice(16000 * 3, 99))
     assert rec["nsq_in"].shape[0] >= 100
     _check(rec)
+
+
+# ---- silk_NSQ_del_dec (opus-fix/silk/NSQ_del_dec.c): 2, 3 and 4 delayed-decision states ----
+GOLD_DD = os.path.join(os.path.dirname(GOLD), "silk_dd_golden.npz")
+
+
+def _check_dd(rec):
+    orc = oraclelib.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    di = np.ascontiguousarray(rec["dd_in"])
+    st = np.ascontiguousarray(rec["dd_state_in"]).copy()
+    do = np.zeros_like(rec["dd_out"])
+    orc.orc_silk_nsq_del_dec_batch(p(di), p(st), p(do), di.shape[0])
+    nfr = di[:, 8:12].copy().view(np.int32).ravel()                     # frame_length of each record
+    for r in range(di.shape[0]):
+        assert np.array_equal(do[r, :nfr[r]], rec["dd_out"][r, :nfr[r]]), ("pulses differ in record", r)
+        assert np.array_equal(do[r, 320:324], rec["dd_out"][r, 320:324]), ("Seed differs in record", r)
+    bad = np.nonzero((st != rec["dd_state_out"]).any(1))[0]
+    assert bad.size == 0, ("NSQ state differs in records", bad[:8])
+
+
+def test_oracle_del_dec_matches_golden_records():
+    g = np.load(GOLD_DD)
+    rec = {k[5:]: g[k] for k in g.files}
+    assert set(rec["dd_in"][:, 1640:1644].copy().view(np.int32).ravel().tolist()) == {2, 3, 4}
+    _check_dd(rec)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("complexity", [4, 8])
+def test_oracle_del_dec_matches_fresh_capture(complexity):
+    import encode_cases as ec
+    gm = ec.golden_module()
+    if not os.path.exists(os.path.join(os.path.dirname(GOLD), "..", "..", "oracle", "_ref", "libopus_ref_silkcap.so")):
+        pytest.skip("capture library not built")
+    rec = gm.silk_dd_capture(gm.synth_voice(16000 * 3, 77 + complexity), complexity)
+    assert rec["dd_in"].shape[0] >= 100
+    _check_dd(rec)

@@ -22,6 +22,18 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_mixed_corpus_counts():
+    """configs[4]: 1 M units over 8 ranks -> 131 072 per rank = 114 688 CELT frames + 16 384 SILK records."""
+    from concentus_amd.sharding import mixed_counts, shard_range
+    lo, hi = shard_range(1 << 20, 3, 8)
+    assert hi - lo == 131072 and mixed_counts(hi - lo) == (114688, 16384)
+    for n in (0, 1, 7, 8, 9, 65535):
+        c, s = mixed_counts(n)
+        assert c + s == n and c == n * 7 // 8
+    with pytest.raises(ValueError):
+        mixed_counts(-1)
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
