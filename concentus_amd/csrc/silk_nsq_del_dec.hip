@@ -1,0 +1,392 @@
+// silk_nsq_del_dec.hip -- silk_NSQ_del_dec(), the noise-shaping quantizer of the reference at complexity >= 4,
+// batched over function-boundary records (include/opusgpu_silk.h: opusgpu_nsq_dd_in / opusgpu_nsq_state / opusgpu_nsq_dd_out).
+//
+//   silk_NSQ_del_dec_c                    opus-fix/silk/NSQ_del_dec.c:112-318
+//   silk_noise_shape_quantizer_del_dec    opus-fix/silk/NSQ_del_dec.c:324-630
+//   silk_nsq_del_dec_scale_states         opus-fix/silk/NSQ_del_dec.c:632-724
+//
+// Mapping: the quantizer keeps up to four candidate paths ("delayed-decision states") per record, all advanced by
+// the same per-sample filter arithmetic and then compared with each other. FOUR ADJACENT LANES OWN ONE RECORD, lane k
+// of the quad = path k: the per-path work (16-tap prediction, warped 16-tap shaping, two quantization candidates) is
+// the parallel part, the per-sample tournament between the paths (winner, expiry, worst-of-first / best-of-second
+// replacement) is a handful of quad broadcasts (DPP quad_perm), and a wavefront advances 16 records.
+//   * per path, in registers: the 16 newest sLPC_Q14 samples (a shift register), sAR2_Q14[16], LF_AR, Seed, SeedInit, RD;
+//   * per path, in LDS ([row][lane], row stride 65 words): the five 32-deep decision rings RandState / Q / Xq / Pred /
+//     Shape and the per-record delayed-gain ring;
+//   * per record, in HBM: the NSQ state (xq, sLTP_shp_Q14: read at the pitch lag by all four lanes, written by the
+//     winner's lane) and the re-whitening scratch sLTP / sLTP_Q15 (workspace).
+// The reference's survivor copy (memcpy of the struct tail, :583-584) becomes: registers through ds_bpermute, the 160
+// ring rows by the four lanes of the quad together (40 read+write pairs).
+// sLPC_Q14[0..32) of the state output is rebuilt from the winner's Xq ring: after the last subframe (length >= 32)
+// both hold the last 32 xq_Q14 values (:307).
+#include "silk_math.h"
+#include "opusgpu_internal.h"
+#include "../../include/opusgpu_silk.h"
+
+namespace ca {
+
+namespace dd {
+enum { DELAY = 32, MASK = 31, STRIDE = 65, R_RND = 0, R_Q = 32, R_XQ = 64, R_PRED = 96, R_SHAPE = 128, R_COPY = 160, R_GAIN = 160, ROWS = 192 };
+struct Scratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
+struct Cand { i32 q, rd, xq, lf_ar, shp, exc; };
+
+// value of quad lane J (compile-time) / j (run-time, quad-uniform) in every lane of the quad
+template <int J> CA_DEV i32 qb(i32 v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
+CA_DEV i32 qsel(i32 v, int quad_base, int j) { return __shfl(v, quad_base + j, 64); }
+// orders the quad's traffic through LDS and (workgroup scope: one CU, one L1) through global memory
+CA_DEV void quad_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+CA_DEV i16 sat16(i32 v) { return (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
+}  // namespace dd
+
+__global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_dd_in *__restrict__ recs, opusgpu_nsq_state *states,
+                                                              opusgpu_nsq_dd_out *__restrict__ outs, dd::Scratch *ws, int n_rec)
+{
+    using namespace dd;
+    __shared__ i32 ring[ROWS * STRIDE];
+    const int ln = threadIdx.x, k = ln & 3, quad = ln & ~3;
+    const int r = blockIdx.x * 16 + (ln >> 2);
+    if (r >= n_rec) return;                       // whole quads leave together
+    const opusgpu_nsq_in &in = recs[r].base;
+    const int nst = recs[r].nStatesDelayedDecision, warping_Q16 = recs[r].warping_Q16;
+    opusgpu_nsq_state &NSQ = states[r];
+    i32 *sLTP_Q15 = ws[r].sLTP_Q15;
+    i16 *sLTP = ws[r].sLTP;
+    i32 *col = ring + ln;                         // row e of this lane: col[e * STRIDE]
+    const int nb_subfr = in.nb_subfr, L = in.subfr_length, frame_length = in.frame_length;
+    const int ltp_mem = in.ltp_mem_length, pord = in.predictLPCOrder, sord = in.shapingLPCOrder;
+    const int voiced = in.signalType == 2;
+    const int Lambda_Q10 = in.Lambda_Q10;
+    i8 *pulses = outs[r].pulses;
+
+    for (int e = 0; e < ROWS; e++) col[e * STRIDE] = 0;
+    i32 lp[16], ar[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { lp[j] = NSQ.sLPC_Q14[31 - j]; ar[j] = NSQ.sAR2_Q14[j]; }
+    i32 seed = (k + in.Seed) & 3, seed0 = seed, rd = 0, lf_ar = NSQ.sLF_AR_shp_Q14;
+    col[(R_SHAPE + 0) * STRIDE] = NSQ.sLTP_shp_Q14[ltp_mem - 1];
+    i32 prev_gain_Q16 = NSQ.prev_gain_Q16;
+    int lag = NSQ.lagPrev;
+    const int offset_Q10 = voiced ? (in.quantOffsetType ? 100 : 32) : (in.quantOffsetType ? 240 : 100);   // silk/tables_other.c:95-97
+    int smpl = 0;
+    int delay = L < DELAY ? L : DELAY;
+    if (voiced) {
+        for (int s = 0; s < nb_subfr; s++) delay = imin(delay, in.pitchL[s] - 5 / 2 - 1);
+    } else if (lag > 0) {
+        delay = imin(delay, lag - 5 / 2 - 1);
+    }
+    const int interp = in.NLSFInterpCoef_Q2 == 4 ? 0 : 1;
+    int shp_idx = ltp_mem, ltp_idx = ltp_mem;     // NSQ->sLTP_shp_buf_idx, NSQ->sLTP_buf_idx
+    int rewhite = 0, subfr = 0;
+    quad_fence();
+
+    for (int sf = 0; sf < nb_subfr; sf++) {
+        const i16 *A_Q12 = &in.PredCoef_Q12[((sf >> 1) | (1 - interp)) * 16];
+        const i16 *B_Q14 = &in.LTPCoef_Q14[sf * 5];
+        const i16 *AR_Q13 = &in.AR2_Q13[sf * 16];
+        const i32 *x_Q3 = &in.x_Q3[sf * L];
+        i8 *pl = pulses + sf * L;
+        i16 *pxq = &NSQ.xq[ltp_mem + sf * L];
+        i32 harm = in.HarmShapeGain_Q14[sf] >> 2;
+        harm |= shl32(in.HarmShapeGain_Q14[sf] >> 1, 16);
+        rewhite = 0;
+        if (voiced) {
+            lag = in.pitchL[sf];
+            if ((sf & (3 - (interp << 1))) == 0) {
+                if (sf == 2) {
+                    // NSQ_del_dec.c:190-221: before the prediction filter changes, flush the surviving path
+                    int w = 0;
+                    i32 best = qb<0>(rd);
+                    { i32 v = qb<1>(rd); if (nst > 1 && v < best) { best = v; w = 1; } }
+                    { i32 v = qb<2>(rd); if (nst > 2 && v < best) { best = v; w = 2; } }
+                    { i32 v = qb<3>(rd); if (nst > 3 && v < best) { best = v; w = 3; } }
+                    if (k != w) rd = s_addw(rd, 0x7FFFFFFF >> 4);
+                    const i32 *wcol = ring + quad + w;
+                    for (int i = k; i < delay; i += 4) {
+                        const int last = (smpl + delay - 1 - i) & MASK;
+                        pl[i - delay] = (i8)s_rshift_round(wcol[(R_Q + last) * STRIDE], 10);
+                        pxq[i - delay] = sat16(s_rshift_round(s_smulww(wcol[(R_XQ + last) * STRIDE], in.Gains_Q16[1]), 14));
+                        NSQ.sLTP_shp_Q14[shp_idx - delay + i] = wcol[(R_SHAPE + last) * STRIDE];
+                    }
+                    subfr = 0;
+                    quad_fence();
+                }
+                // re-whitening: silk_LPC_analysis_filter (celt_fir form), the output samples shared out over the quad
+                const int start_idx = ltp_mem - lag - pord - 5 / 2;
+                const i16 *inp = &NSQ.xq[start_idx + sf * L];
+                i16 *outp = &sLTP[start_idx];
+                const int len = ltp_mem - start_idx;
+                for (int ix = pord + k; ix < len; ix += 4) {
+                    i32 sum = 0;
+                    for (int m = 0; m < pord; m++) sum = s_addw(sum, __mul24((i32)(i16)(-A_Q12[m]), (i32)inp[ix - 1 - m]));
+                    outp[ix] = sat16((i32)inp[ix] + pshr32(sum, 12));
+                }
+                for (int j = k; j < pord; j += 4) outp[j] = 0;
+                ltp_idx = ltp_mem;
+                rewhite = 1;
+                quad_fence();
+            }
+        }
+        // ---- silk_nsq_del_dec_scale_states (NSQ_del_dec.c:632-724) ----
+        const i32 gain = in.Gains_Q16[sf];
+        i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
+        const i32 adj = gain != prev_gain_Q16 ? s_div32_varq(prev_gain_Q16, gain, 16) : (i32)1 << 16;
+        const i32 inv_gain_Q23 = s_rshift_round(inv_gain_Q31, 8);
+        prev_gain_Q16 = gain;
+        {
+            const int lg = in.pitchL[sf];
+            if (rewhite) {
+                if (sf == 0) inv_gain_Q31 = shl32(s_smulwb(inv_gain_Q31, in.LTP_scale_Q14), 2);
+                for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx; i += 4) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
+            }
+            if (adj != (i32)1 << 16) {
+                for (int i = shp_idx - ltp_mem + k; i < shp_idx; i += 4) NSQ.sLTP_shp_Q14[i] = s_smulww(adj, NSQ.sLTP_shp_Q14[i]);
+                if (voiced && rewhite == 0)
+                    for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx - delay; i += 4) sLTP_Q15[i] = s_smulww(adj, sLTP_Q15[i]);
+                lf_ar = s_smulww(adj, lf_ar);
+#pragma unroll
+                for (int j = 0; j < 16; j++) { lp[j] = s_smulww(adj, lp[j]); ar[j] = s_smulww(adj, ar[j]); }
+                for (int i = 0; i < DELAY; i++) {
+                    col[(R_PRED + i) * STRIDE] = s_smulww(adj, col[(R_PRED + i) * STRIDE]);
+                    col[(R_SHAPE + i) * STRIDE] = s_smulww(adj, col[(R_SHAPE + i) * STRIDE]);
+                }
+            }
+            quad_fence();
+        }
+        // ---- silk_noise_shape_quantizer_del_dec (NSQ_del_dec.c:324-630) ----
+        const i32 Gain_Q10 = gain >> 6;
+        const int Tilt_Q14 = in.Tilt_Q14[sf];
+        const i32 LF_shp_Q14 = in.LF_shp_Q14[sf];
+        const i32 *shp_lag = &NSQ.sLTP_shp_Q14[shp_idx - lag + 3 / 2];
+        const i32 *pred_lag = &sLTP_Q15[ltp_idx - lag + 5 / 2];
+        for (int i = 0; i < L; i++) {
+            // common to the paths of a record (computed by each of its lanes)
+            i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
+            if (voiced) {
+                LTP_pred_Q14 = 2;
+#pragma unroll
+                for (int j = 0; j < 5; j++) LTP_pred_Q14 = s_smlawb(LTP_pred_Q14, pred_lag[-j], B_Q14[j]);
+                LTP_pred_Q14 = shl32(LTP_pred_Q14, 1);
+                pred_lag++;
+            }
+            if (lag > 0) {
+                n_LTP_Q14 = s_smulwb(s_addw(shp_lag[0], shp_lag[-2]), harm);
+                n_LTP_Q14 = s_smlawt(n_LTP_Q14, shp_lag[-1], harm);
+                n_LTP_Q14 = s_subw(LTP_pred_Q14, shl32(n_LTP_Q14, 2));
+                shp_lag++;
+            }
+            const i32 x_sc_Q10 = s_smulww(x_Q3[i], inv_gain_Q23);
+            // this lane's path
+            seed = (i32)(907633515u + (u32)seed * 196314165u);                  // silk_RAND
+            i32 LPC_pred_Q14 = pord >> 1;
+#pragma unroll
+            for (int j = 0; j < 16; j++) if (j < pord) LPC_pred_Q14 = s_smlawb(LPC_pred_Q14, lp[j], A_Q12[j]);
+            LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
+            i32 tmp2 = s_smlawb(lp[0], ar[0], warping_Q16);
+            i32 tmp1 = s_smlawb(ar[0], s_subw(ar[1], tmp2), warping_Q16);
+            ar[0] = tmp2;
+            i32 n_AR_Q14 = sord >> 1;
+            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[0]);
+#pragma unroll
+            for (int j = 2; j < 16; j += 2) {
+                if (j < sord) {
+                    tmp2 = s_smlawb(ar[j - 1], s_subw(ar[j], tmp1), warping_Q16);
+                    ar[j - 1] = tmp1;
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[j - 1]);
+                    tmp1 = s_smlawb(ar[j], s_subw(ar[j + 1], tmp2), warping_Q16);
+                    ar[j] = tmp2;
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 1; j < 16; j += 2) if (j == sord - 1) ar[j] = tmp1;
+            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[sord - 1]);
+            n_AR_Q14 = shl32(n_AR_Q14, 1);
+            n_AR_Q14 = s_smlawb(n_AR_Q14, lf_ar, Tilt_Q14);
+            n_AR_Q14 = shl32(n_AR_Q14, 2);
+            i32 n_LF_Q14 = s_smulwb(col[(R_SHAPE + smpl) * STRIDE], LF_shp_Q14);
+            n_LF_Q14 = s_smlawt(n_LF_Q14, lf_ar, LF_shp_Q14);
+            n_LF_Q14 = shl32(n_LF_Q14, 2);
+            tmp1 = s_addw(n_AR_Q14, n_LF_Q14);
+            tmp2 = s_addw(n_LTP_Q14, LPC_pred_Q14);
+            tmp1 = s_rshift_round(s_subw(tmp2, tmp1), 4);
+            i32 r_Q10 = s_subw(x_sc_Q10, tmp1);
+            if (seed < 0) r_Q10 = (i32)(0u - (u32)r_Q10);
+            r_Q10 = s_limit(r_Q10, -(31 << 10), 30 << 10);
+            i32 q1_Q10 = r_Q10 - offset_Q10, q2_Q10, rd1, rd2;
+            const i32 q1_Q0 = q1_Q10 >> 10;
+            if (q1_Q0 > 0) {
+                q1_Q10 = shl32(q1_Q0, 10) - 80 + offset_Q10;
+                q2_Q10 = q1_Q10 + 1024;
+                rd1 = s_smulbb(q1_Q10, Lambda_Q10);
+                rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else if (q1_Q0 == 0) {
+                q1_Q10 = offset_Q10;
+                q2_Q10 = q1_Q10 + (1024 - 80);
+                rd1 = s_smulbb(q1_Q10, Lambda_Q10);
+                rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else if (q1_Q0 == -1) {
+                q2_Q10 = offset_Q10;
+                q1_Q10 = q2_Q10 - (1024 - 80);
+                rd1 = s_smulbb(-q1_Q10, Lambda_Q10);
+                rd2 = s_smulbb(q2_Q10, Lambda_Q10);
+            } else {
+                q1_Q10 = shl32(q1_Q0, 10) + 80 + offset_Q10;
+                q2_Q10 = q1_Q10 + 1024;
+                rd1 = s_smulbb(-q1_Q10, Lambda_Q10);
+                rd2 = s_smulbb(-q2_Q10, Lambda_Q10);
+            }
+            i32 rr = r_Q10 - q1_Q10;
+            rd1 = s_addw(rd1, s_smulbb(rr, rr)) >> 10;
+            rr = r_Q10 - q2_Q10;
+            rd2 = s_addw(rd2, s_smulbb(rr, rr)) >> 10;
+            Cand c0, c1;
+            const bool q1_first = rd1 < rd2;
+            c0.rd = s_addw(rd, q1_first ? rd1 : rd2);
+            c1.rd = s_addw(rd, q1_first ? rd2 : rd1);
+            c0.q = q1_first ? q1_Q10 : q2_Q10;
+            c1.q = q1_first ? q2_Q10 : q1_Q10;
+            {
+                i32 e0 = shl32(c0.q, 4), e1 = shl32(c1.q, 4);
+                if (seed < 0) { e0 = -e0; e1 = -e1; }
+                c0.exc = s_addw(e0, LTP_pred_Q14);
+                c1.exc = s_addw(e1, LTP_pred_Q14);
+                c0.xq = s_addw(c0.exc, LPC_pred_Q14);
+                c1.xq = s_addw(c1.exc, LPC_pred_Q14);
+                c0.lf_ar = s_subw(c0.xq, n_AR_Q14);
+                c1.lf_ar = s_subw(c1.xq, n_AR_Q14);
+                c0.shp = s_subw(c0.lf_ar, n_LF_Q14);
+                c1.shp = s_subw(c1.lf_ar, n_LF_Q14);
+            }
+            // ---- tournament between the paths of the record (:530-586) ----
+            smpl = (smpl - 1) & MASK;
+            const int last = (smpl + delay) & MASK;
+            int w = 0;
+            {
+                i32 best = qb<0>(c0.rd);
+                { i32 v = qb<1>(c0.rd); if (nst > 1 && v < best) { best = v; w = 1; } }
+                { i32 v = qb<2>(c0.rd); if (nst > 2 && v < best) { best = v; w = 2; } }
+                { i32 v = qb<3>(c0.rd); if (nst > 3 && v < best) { best = v; w = 3; } }
+            }
+            const i32 my_rand = col[(R_RND + last) * STRIDE];
+            const i32 wrand = qsel(my_rand, quad, w);
+            if (my_rand != wrand) {             // paths that disagree with the winner on the sample that expires now
+                c0.rd = s_addw(c0.rd, 0x7FFFFFFF >> 4);
+                c1.rd = s_addw(c1.rd, 0x7FFFFFFF >> 4);
+            }
+            int worst = 0, best2 = 0;
+            {
+                i32 mx = qb<0>(c0.rd), mn = qb<0>(c1.rd);
+                { i32 a = qb<1>(c0.rd), b = qb<1>(c1.rd); if (nst > 1) { if (a > mx) { mx = a; worst = 1; } if (b < mn) { mn = b; best2 = 1; } } }
+                { i32 a = qb<2>(c0.rd), b = qb<2>(c1.rd); if (nst > 2) { if (a > mx) { mx = a; worst = 2; } if (b < mn) { mn = b; best2 = 2; } } }
+                { i32 a = qb<3>(c0.rd), b = qb<3>(c1.rd); if (nst > 3) { if (a > mx) { mx = a; worst = 3; } if (b < mn) { mn = b; best2 = 3; } } }
+                const bool replace = mn < mx;
+                // the survivor copy: path `worst` continues as a copy of path `best2` with its second candidate
+                const int src = quad + best2;
+                const bool me = replace && k == worst;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const i32 a = __shfl(lp[j], src, 64), b = __shfl(ar[j], src, 64);
+                    if (me) { lp[j] = a; ar[j] = b; }
+                }
+                {
+                    const i32 a = __shfl(seed, src, 64), b = __shfl(seed0, src, 64);
+                    const i32 q = __shfl(c1.q, src, 64), d = __shfl(c1.rd, src, 64), x = __shfl(c1.xq, src, 64);
+                    const i32 f = __shfl(c1.lf_ar, src, 64), s = __shfl(c1.shp, src, 64), e = __shfl(c1.exc, src, 64);
+                    if (me) { seed = a; seed0 = b; c0.q = q; c0.rd = d; c0.xq = x; c0.lf_ar = f; c0.shp = s; c0.exc = e; }
+                }
+                if (replace && worst != best2) {
+                    const i32 *from = ring + quad + best2;
+                    i32 *to = ring + quad + worst;
+                    for (int e = k; e < R_COPY; e += 4) to[e * STRIDE] = from[e * STRIDE];
+                }
+                quad_fence();
+            }
+            // the winner's lane releases the sample that is `delay` old
+            if (k == w && (subfr > 0 || i >= delay)) {
+                pl[i - delay] = (i8)s_rshift_round(col[(R_Q + last) * STRIDE], 10);
+                pxq[i - delay] = sat16(s_rshift_round(s_smulww(col[(R_XQ + last) * STRIDE], col[(R_GAIN + last) * STRIDE]), 8));
+                NSQ.sLTP_shp_Q14[shp_idx - delay] = col[(R_SHAPE + last) * STRIDE];
+                sLTP_Q15[ltp_idx - delay] = col[(R_PRED + last) * STRIDE];
+            }
+            shp_idx++;
+            ltp_idx++;
+            // every path advances with its first candidate
+            lf_ar = c0.lf_ar;
+#pragma unroll
+            for (int j = 15; j > 0; j--) lp[j] = lp[j - 1];
+            lp[0] = c0.xq;
+            col[(R_XQ + smpl) * STRIDE] = c0.xq;
+            col[(R_Q + smpl) * STRIDE] = c0.q;
+            col[(R_PRED + smpl) * STRIDE] = shl32(c0.exc, 1);
+            col[(R_SHAPE + smpl) * STRIDE] = c0.shp;
+            seed = s_addw(seed, s_rshift_round(c0.q, 10));
+            col[(R_RND + smpl) * STRIDE] = seed;
+            rd = c0.rd;
+            col[(R_GAIN + smpl) * STRIDE] = Gain_Q10;
+            quad_fence();
+        }
+        subfr++;
+    }
+    // ---- NSQ_del_dec.c:285-317: flush the last `delay` samples of the winning path, write the state back ----
+    {
+        int w = 0;
+        i32 best = qb<0>(rd);
+        { i32 v = qb<1>(rd); if (nst > 1 && v < best) { best = v; w = 1; } }
+        { i32 v = qb<2>(rd); if (nst > 2 && v < best) { best = v; w = 2; } }
+        { i32 v = qb<3>(rd); if (nst > 3 && v < best) { best = v; w = 3; } }
+        const i32 *wcol = ring + quad + w;
+        const i32 Gain_Q10 = in.Gains_Q16[nb_subfr - 1] >> 6;
+        i8 *pl = pulses + nb_subfr * L;
+        i16 *pxq = &NSQ.xq[ltp_mem + nb_subfr * L];
+        for (int i = k; i < delay; i += 4) {
+            const int last = (smpl + delay - 1 - i) & MASK;
+            pl[i - delay] = (i8)s_rshift_round(wcol[(R_Q + last) * STRIDE], 10);
+            pxq[i - delay] = sat16(s_rshift_round(s_smulww(wcol[(R_XQ + last) * STRIDE], Gain_Q10), 8));
+            NSQ.sLTP_shp_Q14[shp_idx - delay + i] = wcol[(R_SHAPE + last) * STRIDE];
+        }
+        for (int m = k; m < 32; m += 4) NSQ.sLPC_Q14[31 - m] = wcol[(R_XQ + ((smpl + m) & MASK)) * STRIDE];
+        if (k == w) {
+            outs[r].Seed = seed0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) NSQ.sAR2_Q14[j] = ar[j];
+            NSQ.sLF_AR_shp_Q14 = lf_ar;
+            NSQ.lagPrev = in.pitchL[nb_subfr - 1];
+            NSQ.sLTP_buf_idx = ltp_idx;
+            NSQ.sLTP_shp_buf_idx = shp_idx;
+            NSQ.prev_gain_Q16 = prev_gain_Q16;
+            NSQ.rewhite_flag = rewhite;
+        }
+        quad_fence();
+        // silk_memmove of the two histories by frame_length (:315-316), shared out over the quad: element m takes
+        // m + frame_length; a forward copy only overwrites what earlier iterations have already read
+        for (int m = k; m < ltp_mem; m += 4) {
+            const i16 a = NSQ.xq[m + frame_length];
+            const i32 b = NSQ.sLTP_shp_Q14[m + frame_length];
+            NSQ.xq[m] = a;
+            NSQ.sLTP_shp_Q14[m] = b;
+        }
+    }
+}
+
+}  // namespace ca
+
+using namespace ca;
+
+extern "C" size_t opusgpu_silk_nsq_del_dec_workspace_bytes(int n) { return n <= 0 ? 0 : (size_t)n * sizeof(dd::Scratch); }
+
+extern "C" int opusgpu_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_dd_out *d_out, int n,
+                                              void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_state || !d_out || !d_workspace) return OPUSGPU_BAD_ARG;
+    if (workspace_bytes < (size_t)n * sizeof(dd::Scratch)) return OPUSGPU_BUFFER_TOO_SMALL;
+    hipLaunchKernelGGL(silk_nsq_del_dec_kernel, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
+                       (dd::Scratch *)d_workspace, n);
+    return opusgpu_check_launch();
+}

@@ -76,3 +76,34 @@ def silk_NSQ(nsq_in, nsq_state, pulses=None):
                                   _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_nsq_batch")
     return pulses
+
+
+class NsqDdIn(C.Structure):
+    """opusgpu_nsq_dd_in: the silk_NSQ() arguments + nStatesDelayedDecision, warping_Q16."""
+    _fields_ = [("base", NsqIn), ("nStatesDelayedDecision", C.c_int32), ("warping_Q16", C.c_int32)]
+
+
+SIZES["nsq_dd_in"] = C.sizeof(NsqDdIn)
+SIZES["nsq_dd_out"] = 324
+
+
+def silk_NSQ_del_dec(dd_in, nsq_state, dd_out=None):
+    """silk_NSQ_del_dec() (opus-fix/silk/main.h:271-296, NSQ_del_dec.c:112) over a batch of records:
+    dd_in uint8 [N][1648], nsq_state uint8 [N][4380] (updated in place) -> dd_out uint8 [N][324] (pulses int8[320], Seed)."""
+    import torch
+    _check(dd_in, SIZES["nsq_dd_in"], "dd_in")
+    _check(nsq_state, SIZES["nsq_state"], "nsq_state")
+    n = dd_in.shape[0]
+    if dd_out is None:
+        dd_out = torch.zeros((n, SIZES["nsq_dd_out"]), dtype=torch.uint8, device=dd_in.device)
+    _check(dd_out, SIZES["nsq_dd_out"], "dd_out")
+    L = _lib.load()
+    need = L.opusgpu_silk_nsq_del_dec_workspace_bytes(n)
+    ws = _WS.get(dd_in.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=dd_in.device)
+        _WS[dd_in.device] = ws
+    rc = L.opusgpu_silk_nsq_del_dec_batch(dd_in.data_ptr(), nsq_state.data_ptr(), dd_out.data_ptr(), n, ws.data_ptr(), ws.numel(),
+                                          _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_nsq_del_dec_batch")
+    return dd_out

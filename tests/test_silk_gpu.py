@@ -93,3 +93,66 @@ def test_silk_empty_and_bad_args(ca):
     assert out.shape == (0, 72)
     with pytest.raises(ValueError):
         ca.silk_burg_modified(torch.zeros((4, 100), dtype=torch.uint8, device="cuda"))
+
+
+# ---- silk_NSQ_del_dec: four lanes per record, one per delayed-decision state ----
+GOLD_DD = os.path.join(os.path.dirname(GOLD), "silk_dd_golden.npz")
+
+
+def _check_dd_gpu(ca, rec, what):
+    import torch
+    st = _dev(rec["dd_state_in"])
+    out = ca.silk_NSQ_del_dec(_dev(rec["dd_in"]), st)
+    torch.cuda.synchronize()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    nfr = rec["dd_in"][:, 8:12].copy().view(np.int32).ravel()
+    for r in range(out.shape[0]):
+        assert np.array_equal(out[r, :nfr[r]], rec["dd_out"][r, :nfr[r]]), (what, "pulses differ in record", r,
+                                                                            np.nonzero(out[r, :nfr[r]] != rec["dd_out"][r, :nfr[r]])[0][:8])
+        assert np.array_equal(out[r, 320:324], rec["dd_out"][r, 320:324]), (what, "Seed differs in record", r)
+    bad = np.nonzero((st != rec["dd_state_out"]).any(1))[0]
+    assert bad.size == 0, (what, "NSQ state differs", bad[:8], [np.nonzero(st[b] != rec["dd_state_out"][b])[0][:6] for b in bad[:3]])
+
+
+def test_del_dec_matches_golden_records(ca):
+    g = np.load(GOLD_DD)
+    _check_dd_gpu(ca, {k[5:]: g[k] for k in g.files}, "golden")
+
+
+def test_del_dec_full_size_vs_oracle(ca):
+    """65 536 records: the 84 captured ones (2 / 3 / 4 states; unvoiced, voiced, inactive) tiled with the dither seed,
+    the number of states and the input perturbed per record, against the CPU oracle on a 2 048-record sample; ragged
+    batch sizes (not a multiple of the 16 records of a wavefront)."""
+    import torch
+    g = np.load(GOLD_DD)
+    rec = {k[5:]: g[k] for k in g.files}
+    n = 65536 + 7
+    rng = np.random.default_rng(9)
+    reps = n // 84 + 1
+    di = np.tile(rec["dd_in"], (reps, 1))[:n].copy()
+    di[:, 36:40].view(np.int32)[:, 0] = rng.integers(0, 4, size=n)            # Seed
+    di[:, 1640:1644].view(np.int32)[:, 0] = rng.integers(1, 5, size=n)        # nStatesDelayedDecision 1..4
+    x = di[:, 128:128 + 1280].view(np.int32)                                    # x_Q3
+    x += rng.integers(-40, 41, size=x.shape, dtype=np.int32)
+    st0 = np.tile(rec["dd_state_in"], (reps, 1))[:n].copy()
+    st = _dev(st0)
+    out = ca.silk_NSQ_del_dec(_dev(di), st)
+    torch.cuda.synchronize()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    idx = np.concatenate([rng.choice(n, 2040, replace=False), np.arange(n - 8, n)])
+    orc = oraclelib.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    sdi = np.ascontiguousarray(di[idx]); sst = np.ascontiguousarray(st0[idx]).copy(); sdo = np.zeros((idx.size, 324), np.uint8)
+    orc.orc_silk_nsq_del_dec_batch(p(sdi), p(sst), p(sdo), idx.size)
+    assert np.array_equal(out[idx], sdo), np.nonzero((out[idx] != sdo).any(1))[0][:8]
+    assert np.array_equal(st[idx], sst), np.nonzero((st[idx] != sst).any(1))[0][:8]
+
+
+def test_del_dec_matches_fresh_capture_if_present(ca):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libopus_ref_silkcap.so")):
+        pytest.skip("capture library did not travel")
+    import encode_cases as ec
+    gm = ec.golden_module()
+    for cx in (4, 6, 9):
+        _check_dd_gpu(ca, gm.silk_dd_capture(gm.synth_voice(16000 * 3, 50 + cx), cx), "fresh capture complexity %d" % cx)
