@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "decode", "mixed"])
+    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "silk_deldec", "decode", "mixed"])
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("CONCENTUS_BENCH_STREAMS", "1")),
                     help="celt: HIP streams the consecutive batches (steps) alternate over (each with its own workspace)")
@@ -203,6 +203,36 @@ def cpu_baseline_silk(rec, n):
                       "%d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
+def cpu_baseline_silk_dd(rec, n):
+    """CPU baseline for the silk_NSQ_del_dec records: the C restatement (oracle/oracle_silk.c, kind "port"), chunks on a
+    thread pool."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oraclelib
+    from concurrent.futures import ThreadPoolExecutor
+    orc = oraclelib.lib()
+    cores = host_threads()
+    m = rec["dd_in"].shape[0]
+    di = np.ascontiguousarray(np.tile(rec["dd_in"], (n // m + 1, 1))[:n])
+    st0 = np.ascontiguousarray(np.tile(rec["dd_state_in"], (n // m + 1, 1))[:n])
+    do = np.zeros((n, 324), np.uint8)
+
+    def work(lo, hi):
+        st = st0[lo:hi].copy()
+        orc.orc_silk_nsq_del_dec_batch(C.c_void_p(di.ctypes.data + lo * 1648), _p(st), C.c_void_p(do.ctypes.data + lo * 324), hi - lo)
+
+    def run(threads):
+        if threads == 1:
+            work(0, n)
+            return
+        per = (n + threads - 1) // threads
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port",
+            "sample": "%d silk_NSQ_del_dec records per pass through oracle/oracle_silk.c, repeated ~8 s on %d thread(s); "
+                      "1 thread: %.0f records/s" % (n, cores, one)}
+
+
 def silk_records(F, rank, dev):
     """F function-boundary records on the device: the 80 captured from the reference encoder (tests/golden), tiled, the
     Burg inputs dithered per record."""
@@ -334,6 +364,43 @@ def main():
         extra = {"mean_packet_bytes": round(mean_len, 2), "other_kernels": kern[1:], "state_bytes_per_stream": STATE}
         pk_h, ln_h = pk[:4096].cpu().numpy(), ln[:4096].cpu().numpy()
         cpu = (lambda: cpu_baseline_decode(pk_h, ln_h))
+    elif a.workload == "silk_deldec":
+        # silk_NSQ_del_dec (the quantizer of complexity >= 4) over records captured at complexity 5/7/10
+        F = a.frames or 65536
+        steps = a.steps or 10
+        warm = a.warmup if a.warmup is not None else 2
+        g = np.load(os.path.join(ROOT, "tests", "golden", "silk_dd_golden.npz"))
+        rec = {k[5:]: g[k] for k in g.files}
+        m = rec["dd_in"].shape[0]
+        rng = np.random.default_rng(6 + rank)
+        di_h = np.tile(rec["dd_in"], (F // m + 1, 1))[:F].copy()
+        di_h[:, 36:40].view(np.int32)[:, 0] = rng.integers(0, 4, size=F)              # dither seed per record
+        di = torch.from_numpy(di_h).to(dev)
+        st0 = torch.from_numpy(np.tile(rec["dd_state_in"], (F // m + 1, 1))[:F].copy()).to(dev)
+        st = st0.clone()
+        do = torch.empty((F, 324), dtype=torch.uint8, device=dev)
+        for _ in range(warm):
+            st.copy_(st0)
+            ca.silk_NSQ_del_dec(di, st, do)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.silk_NSQ_del_dec(di, st, do)       # states keep evolving from step to step, as a stream would
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_nsq_del_dec_kernel"
+        kbytes = F * (1648 + 2 * 4380 + 324)
+        metric = "SILK 16kHz mono 20ms frames/sec (silk_NSQ_del_dec records)"
+        workload = ("%d function-boundary records per GPU (84 captured from the reference encoder on 16 kHz mono voice at "
+                    "32 kb/s, complexity 5/7/10 = 2/3/4 delayed-decision states, tiled), silk_NSQ_del_dec, bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {}
+        cpu = (lambda: cpu_baseline_silk_dd(rec, 4096))
     elif a.workload == "silk":
         F = a.frames or 65536
         steps = a.steps or 20
@@ -505,7 +572,7 @@ def main():
         out_line = {
             "metric": metric,
             "value": round(value, 1),
-            "unit": "records/s" if a.workload == "silk" else "frames/s",
+            "unit": "records/s" if a.workload.startswith("silk") else "frames/s",
             "n_gpus": world,
             "steps": steps,
             "warmup": warm,

@@ -33,12 +33,14 @@ struct Cand { i32 q, rd, xq, lf_ar, shp, exc; };
 // value of quad lane J (compile-time) / j (run-time, quad-uniform) in every lane of the quad
 template <int J> CA_DEV i32 qb(i32 v) { return __builtin_amdgcn_update_dpp(0, v, J * 0x55, 0xf, 0xf, false); }
 CA_DEV i32 qsel(i32 v, int quad_base, int j) { return __shfl(v, quad_base + j, 64); }
-// orders the quad's traffic through LDS and (workgroup scope: one CU, one L1) through global memory
+// Orders the quad's traffic through LDS and through global memory. The four lanes of a record sit in ONE wavefront
+// (a workgroup is one wavefront here), whose LDS and vector-memory operations are performed in program order, so
+// wavefront scope is enough: the fence constrains the compiler and costs no s_waitcnt.
 CA_DEV void quad_fence()
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 CA_DEV i16 sat16(i32 v) { return (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
 }  // namespace dd
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 lf_ar = s_smulww(adj, lf_ar);
 #pragma unroll
                 for (int j = 0; j < 16; j++) { lp[j] = s_smulww(adj, lp[j]); ar[j] = s_smulww(adj, ar[j]); }
+#pragma unroll 8
                 for (int i = 0; i < DELAY; i++) {
                     col[(R_PRED + i) * STRIDE] = s_smulww(adj, col[(R_PRED + i) * STRIDE]);
                     col[(R_SHAPE + i) * STRIDE] = s_smulww(adj, col[(R_SHAPE + i) * STRIDE]);
@@ -163,48 +166,72 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
         const i32 LF_shp_Q14 = in.LF_shp_Q14[sf];
         const i32 *shp_lag = &NSQ.sLTP_shp_Q14[shp_idx - lag + 3 / 2];
         const i32 *pred_lag = &sLTP_Q15[ltp_idx - lag + 5 / 2];
+        // the filter coefficients of the subframe in registers (zero beyond the order: a zero tap adds nothing)
+        i32 cA[16], cAR[16], cB[5];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { cA[j] = j < pord ? (i32)A_Q12[j] : 0; cAR[j] = j < sord ? (i32)AR_Q13[j] : 0; }
+#pragma unroll
+        for (int j = 0; j < 5; j++) cB[j] = B_Q14[j];
+        const i32 cAR_last = AR_Q13[sord - 1];
+        // The pitch-lag taps slide by one sample per step: pt[j] = pred_lag[-j], st[j] = shp_lag[-j] are kept in registers
+        // and only the newest tap is loaded. What a step stores (position idx - delay) is read as a newest tap no earlier
+        // than one step later (prediction: idx - lag + 2, delay <= lag - 3) or two steps later (shaping: idx - lag + 1), so
+        // the next shaping tap is always fetched a whole step ahead, the next prediction tap when delay <= lag - 4.
+        i32 pt[5] = {0, 0, 0, 0, 0}, st[3] = {0, 0, 0}, pn = 0, sn = 0;
+        if (voiced) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) pt[j] = pred_lag[-j];
+        }
+        if (lag > 0) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) st[j] = shp_lag[-j];
+        }
+        const bool pred_ahead = delay <= lag - 4;
+        i32 xn = x_Q3[0];
         for (int i = 0; i < L; i++) {
+            const i32 xcur = xn;
+            xn = x_Q3[i + 1 < L ? i + 1 : i];
+            if (voiced && pred_ahead) pn = pred_lag[1];
+            if (lag > 0) sn = shp_lag[1];
             // common to the paths of a record (computed by each of its lanes)
             i32 LTP_pred_Q14 = 0, n_LTP_Q14 = 0;
             if (voiced) {
                 LTP_pred_Q14 = 2;
 #pragma unroll
-                for (int j = 0; j < 5; j++) LTP_pred_Q14 = s_smlawb(LTP_pred_Q14, pred_lag[-j], B_Q14[j]);
+                for (int j = 0; j < 5; j++) LTP_pred_Q14 = s_smlawb(LTP_pred_Q14, pt[j], cB[j]);
                 LTP_pred_Q14 = shl32(LTP_pred_Q14, 1);
-                pred_lag++;
             }
             if (lag > 0) {
-                n_LTP_Q14 = s_smulwb(s_addw(shp_lag[0], shp_lag[-2]), harm);
-                n_LTP_Q14 = s_smlawt(n_LTP_Q14, shp_lag[-1], harm);
+                n_LTP_Q14 = s_smulwb(s_addw(st[0], st[2]), harm);
+                n_LTP_Q14 = s_smlawt(n_LTP_Q14, st[1], harm);
                 n_LTP_Q14 = s_subw(LTP_pred_Q14, shl32(n_LTP_Q14, 2));
-                shp_lag++;
             }
-            const i32 x_sc_Q10 = s_smulww(x_Q3[i], inv_gain_Q23);
+            const i32 x_sc_Q10 = s_smulww(xcur, inv_gain_Q23);
             // this lane's path
             seed = (i32)(907633515u + (u32)seed * 196314165u);                  // silk_RAND
             i32 LPC_pred_Q14 = pord >> 1;
 #pragma unroll
-            for (int j = 0; j < 16; j++) if (j < pord) LPC_pred_Q14 = s_smlawb(LPC_pred_Q14, lp[j], A_Q12[j]);
+            for (int j = 0; j < 16; j++) LPC_pred_Q14 = s_smlawb(LPC_pred_Q14, lp[j], cA[j]);
             LPC_pred_Q14 = shl32(LPC_pred_Q14, 4);
             i32 tmp2 = s_smlawb(lp[0], ar[0], warping_Q16);
             i32 tmp1 = s_smlawb(ar[0], s_subw(ar[1], tmp2), warping_Q16);
             ar[0] = tmp2;
             i32 n_AR_Q14 = sord >> 1;
-            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[0]);
+            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, cAR[0]);
 #pragma unroll
             for (int j = 2; j < 16; j += 2) {
                 if (j < sord) {
                     tmp2 = s_smlawb(ar[j - 1], s_subw(ar[j], tmp1), warping_Q16);
                     ar[j - 1] = tmp1;
-                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[j - 1]);
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, cAR[j - 1]);
                     tmp1 = s_smlawb(ar[j], s_subw(ar[j + 1], tmp2), warping_Q16);
                     ar[j] = tmp2;
-                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, AR_Q13[j]);
+                    n_AR_Q14 = s_smlawb(n_AR_Q14, tmp2, cAR[j]);
                 }
             }
 #pragma unroll
             for (int j = 1; j < 16; j += 2) if (j == sord - 1) ar[j] = tmp1;
-            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, AR_Q13[sord - 1]);
+            n_AR_Q14 = s_smlawb(n_AR_Q14, tmp1, cAR_last);
             n_AR_Q14 = shl32(n_AR_Q14, 1);
             n_AR_Q14 = s_smlawb(n_AR_Q14, lf_ar, Tilt_Q14);
             n_AR_Q14 = shl32(n_AR_Q14, 2);
@@ -302,7 +329,15 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 if (replace && worst != best2) {
                     const i32 *from = ring + quad + best2;
                     i32 *to = ring + quad + worst;
-                    for (int e = k; e < R_COPY; e += 4) to[e * STRIDE] = from[e * STRIDE];
+                    // 40 rows per lane, read in two batches of 20 so the LDS latency is paid twice, not forty times
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        i32 t[20];
+#pragma unroll
+                        for (int u = 0; u < 20; u++) t[u] = from[(h * 80 + 4 * u + k) * STRIDE];
+#pragma unroll
+                        for (int u = 0; u < 20; u++) to[(h * 80 + 4 * u + k) * STRIDE] = t[u];
+                    }
                 }
                 quad_fence();
             }
@@ -329,6 +364,13 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
             rd = c0.rd;
             col[(R_GAIN + smpl) * STRIDE] = Gain_Q10;
             quad_fence();
+            if (voiced && !pred_ahead) pn = pred_lag[1];
+            pred_lag++;
+            shp_lag++;
+#pragma unroll
+            for (int j = 4; j > 0; j--) pt[j] = pt[j - 1];
+            pt[0] = pn;
+            st[2] = st[1]; st[1] = st[0]; st[0] = sn;
         }
         subfr++;
     }
