@@ -18,6 +18,7 @@
 //
 // Arithmetic: the reference's x86-64 build uses the 64-bit macro forms (OPUS_FAST_INT64, silk/macros.h:47-102);
 // 16x32 products are evaluated on split halves (full-rate 24-bit multiplier), 32x32 ones as 64-bit.
+#include <string.h>
 #include "silk_math.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
@@ -468,4 +469,40 @@ extern "C" int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_st
     hipLaunchKernelGGL(silk_nsq_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
                        (NsqScratch *)d_workspace, n);
     return opusgpu_check_launch();
+}
+
+// Per-call hook with the reference's own signature (macro silk_burg_modified -> silk_burg_modified_c,
+// opus-fix/silk/SigProc_FIX.h:601-602, fixed/burg_modified_FIX.c:45): host pointers, one record, synchronous.
+// Plumbing / parity only -- a launch per call is latency-bound; throughput comes from the batch entry point.
+extern "C" void opusgpu_silk_burg_modified_c(int32_t *res_nrg, int *res_nrg_Q, int32_t A_Q16[], const int16_t x[],
+                                             const int32_t minInvGain_Q30, const int subfr_length, const int nb_subfr,
+                                             const int D, int arch)
+{
+    (void)arch;
+    if (!res_nrg || !res_nrg_Q || !A_Q16 || !x || D < 1 || D > OPUSGPU_SILK_MAX_ORDER || nb_subfr < 1 || subfr_length <= D ||
+        subfr_length * nb_subfr > OPUSGPU_SILK_BURG_MAX_X) {
+        opusgpu_set_last_error(OPUSGPU_BAD_ARG);
+        return;
+    }
+    opusgpu_burg_in h_in;
+    memset(&h_in, 0, sizeof(h_in));
+    memcpy(h_in.x, x, sizeof(int16_t) * (size_t)subfr_length * nb_subfr);
+    h_in.minInvGain_Q30 = minInvGain_Q30; h_in.subfr_length = subfr_length; h_in.nb_subfr = nb_subfr; h_in.D = D;
+    opusgpu_burg_in *d_in = nullptr;
+    opusgpu_burg_out *d_out = nullptr, h_out;
+    if (hipMalloc(&d_in, sizeof(h_in)) != hipSuccess || hipMalloc(&d_out, sizeof(h_out)) != hipSuccess) {
+        opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL);
+        if (d_in) (void)hipFree(d_in);
+        return;
+    }
+    (void)hipMemcpy(d_in, &h_in, sizeof(h_in), hipMemcpyHostToDevice);
+    int rc = opusgpu_silk_burg_modified_batch(d_in, d_out, 1, nullptr);
+    if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    opusgpu_set_last_error(rc);
+    if (rc != OPUSGPU_OK) return;
+    *res_nrg = h_out.res_nrg;
+    *res_nrg_Q = h_out.res_nrg_Q;
+    memcpy(A_Q16, h_out.A_Q16, sizeof(int32_t) * (size_t)D);
 }

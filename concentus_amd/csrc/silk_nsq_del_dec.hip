@@ -11,8 +11,8 @@
 // the parallel part, the per-sample tournament between the paths (winner, expiry, worst-of-first / best-of-second
 // replacement) is a handful of quad broadcasts (DPP quad_perm), and a wavefront advances 16 records.
 //   * per path, in registers: the 16 newest sLPC_Q14 samples (a shift register), sAR2_Q14[16], LF_AR, Seed, SeedInit, RD;
-//   * per path, in LDS ([row][lane], row stride 65 words): the five 32-deep decision rings RandState / Q / Xq / Pred /
-//     Shape and the per-record delayed-gain ring;
+//   * per path, in LDS ([row][lane], lanes rotated per row): the five 32-deep decision rings RandState / Q / Xq /
+//     Pred / Shape (40 KB per wavefront);
 //   * per record, in HBM: the NSQ state (xq, sLTP_shp_Q14: read at the pitch lag by all four lanes, written by the
 //     winner's lane) and the re-whitening scratch sLTP / sLTP_Q15 (workspace).
 // The reference's survivor copy (memcpy of the struct tail, :583-584) becomes: registers through ds_bpermute, the 160
@@ -26,7 +26,11 @@
 namespace ca {
 
 namespace dd {
-enum { DELAY = 32, MASK = 31, STRIDE = 65, R_RND = 0, R_Q = 32, R_XQ = 64, R_PRED = 96, R_SHAPE = 128, R_COPY = 160, R_GAIN = 160, ROWS = 192 };
+enum { DELAY = 32, MASK = 31, R_RND = 0, R_Q = 32, R_XQ = 64, R_PRED = 96, R_SHAPE = 128, ROWS = 160 };
+// ring element (row, lane): 64 words per row, the lane rotated by the row number -- a row read by all lanes and a column
+// walked by the four lanes of a quad (the survivor copy) both spread over the banks. 160 rows x 256 B = 40 KB per
+// wavefront, four workgroups per CU.
+CA_DEV int ridx(int row, int lanecol) { return row * 64 + ((lanecol + row) & 63); }
 struct Scratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
 struct Cand { i32 q, rd, xq, lf_ar, shp, exc; };
 
@@ -49,7 +53,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                                                               opusgpu_nsq_dd_out *__restrict__ outs, dd::Scratch *ws, int n_rec)
 {
     using namespace dd;
-    __shared__ i32 ring[ROWS * STRIDE];
+    __shared__ i32 ring[ROWS * 64];
     const int ln = threadIdx.x, k = ln & 3, quad = ln & ~3;
     const int r = blockIdx.x * 16 + (ln >> 2);
     if (r >= n_rec) return;                       // whole quads leave together
@@ -58,19 +62,18 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
     opusgpu_nsq_state &NSQ = states[r];
     i32 *sLTP_Q15 = ws[r].sLTP_Q15;
     i16 *sLTP = ws[r].sLTP;
-    i32 *col = ring + ln;                         // row e of this lane: col[e * STRIDE]
     const int nb_subfr = in.nb_subfr, L = in.subfr_length, frame_length = in.frame_length;
     const int ltp_mem = in.ltp_mem_length, pord = in.predictLPCOrder, sord = in.shapingLPCOrder;
     const int voiced = in.signalType == 2;
     const int Lambda_Q10 = in.Lambda_Q10;
     i8 *pulses = outs[r].pulses;
 
-    for (int e = 0; e < ROWS; e++) col[e * STRIDE] = 0;
+    for (int e = 0; e < ROWS; e++) ring[ridx(e, ln)] = 0;
     i32 lp[16], ar[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) { lp[j] = NSQ.sLPC_Q14[31 - j]; ar[j] = NSQ.sAR2_Q14[j]; }
     i32 seed = (k + in.Seed) & 3, seed0 = seed, rd = 0, lf_ar = NSQ.sLF_AR_shp_Q14;
-    col[(R_SHAPE + 0) * STRIDE] = NSQ.sLTP_shp_Q14[ltp_mem - 1];
+    ring[ridx(R_SHAPE + 0, ln)] = NSQ.sLTP_shp_Q14[ltp_mem - 1];
     i32 prev_gain_Q16 = NSQ.prev_gain_Q16;
     int lag = NSQ.lagPrev;
     const int offset_Q10 = voiced ? (in.quantOffsetType ? 100 : 32) : (in.quantOffsetType ? 240 : 100);   // silk/tables_other.c:95-97
@@ -107,12 +110,11 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                     { i32 v = qb<2>(rd); if (nst > 2 && v < best) { best = v; w = 2; } }
                     { i32 v = qb<3>(rd); if (nst > 3 && v < best) { best = v; w = 3; } }
                     if (k != w) rd = s_addw(rd, 0x7FFFFFFF >> 4);
-                    const i32 *wcol = ring + quad + w;
                     for (int i = k; i < delay; i += 4) {
                         const int last = (smpl + delay - 1 - i) & MASK;
-                        pl[i - delay] = (i8)s_rshift_round(wcol[(R_Q + last) * STRIDE], 10);
-                        pxq[i - delay] = sat16(s_rshift_round(s_smulww(wcol[(R_XQ + last) * STRIDE], in.Gains_Q16[1]), 14));
-                        NSQ.sLTP_shp_Q14[shp_idx - delay + i] = wcol[(R_SHAPE + last) * STRIDE];
+                        pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, quad + w)], 10);
+                        pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, quad + w)], in.Gains_Q16[1]), 14));
+                        NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, quad + w)];
                     }
                     subfr = 0;
                     quad_fence();
@@ -154,14 +156,16 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 for (int j = 0; j < 16; j++) { lp[j] = s_smulww(adj, lp[j]); ar[j] = s_smulww(adj, ar[j]); }
 #pragma unroll 8
                 for (int i = 0; i < DELAY; i++) {
-                    col[(R_PRED + i) * STRIDE] = s_smulww(adj, col[(R_PRED + i) * STRIDE]);
-                    col[(R_SHAPE + i) * STRIDE] = s_smulww(adj, col[(R_SHAPE + i) * STRIDE]);
+                    ring[ridx(R_PRED + i, ln)] = s_smulww(adj, ring[ridx(R_PRED + i, ln)]);
+                    ring[ridx(R_SHAPE + i, ln)] = s_smulww(adj, ring[ridx(R_SHAPE + i, ln)]);
                 }
             }
             quad_fence();
         }
         // ---- silk_noise_shape_quantizer_del_dec (NSQ_del_dec.c:324-630) ----
-        const i32 Gain_Q10 = gain >> 6;
+        // delayedGain_Q10[] of the reference (:596, :610): the sample released at step i is `delay` (<= subframe length) old,
+        // so its gain is this subframe's or the previous one's -- no ring needed
+        const i32 Gain_Q10 = gain >> 6, prev_Gain_Q10 = sf > 0 ? in.Gains_Q16[sf - 1] >> 6 : 0;
         const int Tilt_Q14 = in.Tilt_Q14[sf];
         const i32 LF_shp_Q14 = in.LF_shp_Q14[sf];
         const i32 *shp_lag = &NSQ.sLTP_shp_Q14[shp_idx - lag + 3 / 2];
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
             n_AR_Q14 = shl32(n_AR_Q14, 1);
             n_AR_Q14 = s_smlawb(n_AR_Q14, lf_ar, Tilt_Q14);
             n_AR_Q14 = shl32(n_AR_Q14, 2);
-            i32 n_LF_Q14 = s_smulwb(col[(R_SHAPE + smpl) * STRIDE], LF_shp_Q14);
+            i32 n_LF_Q14 = s_smulwb(ring[ridx(R_SHAPE + smpl, ln)], LF_shp_Q14);
             n_LF_Q14 = s_smlawt(n_LF_Q14, lf_ar, LF_shp_Q14);
             n_LF_Q14 = shl32(n_LF_Q14, 2);
             tmp1 = s_addw(n_AR_Q14, n_LF_Q14);
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 { i32 v = qb<2>(c0.rd); if (nst > 2 && v < best) { best = v; w = 2; } }
                 { i32 v = qb<3>(c0.rd); if (nst > 3 && v < best) { best = v; w = 3; } }
             }
-            const i32 my_rand = col[(R_RND + last) * STRIDE];
+            const i32 my_rand = ring[ridx(R_RND + last, ln)];
             const i32 wrand = qsel(my_rand, quad, w);
             if (my_rand != wrand) {             // paths that disagree with the winner on the sample that expires now
                 c0.rd = s_addw(c0.rd, 0x7FFFFFFF >> 4);
@@ -327,26 +331,24 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                     if (me) { seed = a; seed0 = b; c0.q = q; c0.rd = d; c0.xq = x; c0.lf_ar = f; c0.shp = s; c0.exc = e; }
                 }
                 if (replace && worst != best2) {
-                    const i32 *from = ring + quad + best2;
-                    i32 *to = ring + quad + worst;
                     // 40 rows per lane, read in two batches of 20 so the LDS latency is paid twice, not forty times
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
                         i32 t[20];
 #pragma unroll
-                        for (int u = 0; u < 20; u++) t[u] = from[(h * 80 + 4 * u + k) * STRIDE];
+                        for (int u = 0; u < 20; u++) t[u] = ring[ridx(h * 80 + 4 * u + k, quad + best2)];
 #pragma unroll
-                        for (int u = 0; u < 20; u++) to[(h * 80 + 4 * u + k) * STRIDE] = t[u];
+                        for (int u = 0; u < 20; u++) ring[ridx(h * 80 + 4 * u + k, quad + worst)] = t[u];
                     }
                 }
                 quad_fence();
             }
             // the winner's lane releases the sample that is `delay` old
             if (k == w && (subfr > 0 || i >= delay)) {
-                pl[i - delay] = (i8)s_rshift_round(col[(R_Q + last) * STRIDE], 10);
-                pxq[i - delay] = sat16(s_rshift_round(s_smulww(col[(R_XQ + last) * STRIDE], col[(R_GAIN + last) * STRIDE]), 8));
-                NSQ.sLTP_shp_Q14[shp_idx - delay] = col[(R_SHAPE + last) * STRIDE];
-                sLTP_Q15[ltp_idx - delay] = col[(R_PRED + last) * STRIDE];
+                pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, ln)], 10);
+                pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, ln)], i >= delay ? Gain_Q10 : prev_Gain_Q10), 8));
+                NSQ.sLTP_shp_Q14[shp_idx - delay] = ring[ridx(R_SHAPE + last, ln)];
+                sLTP_Q15[ltp_idx - delay] = ring[ridx(R_PRED + last, ln)];
             }
             shp_idx++;
             ltp_idx++;
@@ -355,14 +357,13 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
 #pragma unroll
             for (int j = 15; j > 0; j--) lp[j] = lp[j - 1];
             lp[0] = c0.xq;
-            col[(R_XQ + smpl) * STRIDE] = c0.xq;
-            col[(R_Q + smpl) * STRIDE] = c0.q;
-            col[(R_PRED + smpl) * STRIDE] = shl32(c0.exc, 1);
-            col[(R_SHAPE + smpl) * STRIDE] = c0.shp;
+            ring[ridx(R_XQ + smpl, ln)] = c0.xq;
+            ring[ridx(R_Q + smpl, ln)] = c0.q;
+            ring[ridx(R_PRED + smpl, ln)] = shl32(c0.exc, 1);
+            ring[ridx(R_SHAPE + smpl, ln)] = c0.shp;
             seed = s_addw(seed, s_rshift_round(c0.q, 10));
-            col[(R_RND + smpl) * STRIDE] = seed;
+            ring[ridx(R_RND + smpl, ln)] = seed;
             rd = c0.rd;
-            col[(R_GAIN + smpl) * STRIDE] = Gain_Q10;
             quad_fence();
             if (voiced && !pred_ahead) pn = pred_lag[1];
             pred_lag++;
@@ -381,17 +382,16 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
         { i32 v = qb<1>(rd); if (nst > 1 && v < best) { best = v; w = 1; } }
         { i32 v = qb<2>(rd); if (nst > 2 && v < best) { best = v; w = 2; } }
         { i32 v = qb<3>(rd); if (nst > 3 && v < best) { best = v; w = 3; } }
-        const i32 *wcol = ring + quad + w;
         const i32 Gain_Q10 = in.Gains_Q16[nb_subfr - 1] >> 6;
         i8 *pl = pulses + nb_subfr * L;
         i16 *pxq = &NSQ.xq[ltp_mem + nb_subfr * L];
         for (int i = k; i < delay; i += 4) {
             const int last = (smpl + delay - 1 - i) & MASK;
-            pl[i - delay] = (i8)s_rshift_round(wcol[(R_Q + last) * STRIDE], 10);
-            pxq[i - delay] = sat16(s_rshift_round(s_smulww(wcol[(R_XQ + last) * STRIDE], Gain_Q10), 8));
-            NSQ.sLTP_shp_Q14[shp_idx - delay + i] = wcol[(R_SHAPE + last) * STRIDE];
+            pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, quad + w)], 10);
+            pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, quad + w)], Gain_Q10), 8));
+            NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, quad + w)];
         }
-        for (int m = k; m < 32; m += 4) NSQ.sLPC_Q14[31 - m] = wcol[(R_XQ + ((smpl + m) & MASK)) * STRIDE];
+        for (int m = k; m < 32; m += 4) NSQ.sLPC_Q14[31 - m] = ring[ridx(R_XQ + ((smpl + m) & MASK), quad + w)];
         if (k == w) {
             outs[r].Seed = seed0;
 #pragma unroll

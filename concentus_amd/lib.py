@@ -27,6 +27,7 @@ SYMBOLS = [
     ("opusgpu_encode_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_encode_batch", _i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     ("opusgpu_silk_burg_modified_batch", _i, [_vp, _vp, _i, _vp]),
+    ("opusgpu_silk_burg_modified_c", None, [_vp, _vp, _vp, _vp, C.c_int32, _i, _i, _i, _i]),
     ("opusgpu_silk_nsq_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_silk_nsq_batch", _i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     ("opusgpu_silk_nsq_del_dec_workspace_bytes", C.c_size_t, [_i]),

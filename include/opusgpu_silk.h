@@ -74,6 +74,13 @@ size_t opusgpu_silk_nsq_workspace_bytes(int n);
 int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, int n,
                            void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* Per-call hook with the reference's own signature (host pointers, one call = one record, synchronous): what the macro
+ * silk_burg_modified (opus-fix/silk/SigProc_FIX.h:601-602) would be pointed at. Plumbing / parity only. Errors are
+ * reported through opusgpu_get_last_error(). */
+void opusgpu_silk_burg_modified_c(int32_t *res_nrg, int *res_nrg_Q, int32_t A_Q16[], const int16_t x[],
+                                  const int32_t minInvGain_Q30, const int subfr_length, const int nb_subfr,
+                                  const int D, int arch);
+
 /* ---- silk_NSQ_del_dec(): the quantizer the reference uses at complexity >= 4 (silk/fixed/encode_frame_FIX.c:311,
  * silk/control_codec.c:345-377: 2, 3 or 4 delayed-decision states, warped noise shaping) ----
  *   silk_NSQ_del_dec_c                    opus-fix/silk/NSQ_del_dec.c:112-318 (macro silk_NSQ_del_dec, silk/main.h:271-296)

@@ -156,3 +156,21 @@ def test_del_dec_matches_fresh_capture_if_present(ca):
     gm = ec.golden_module()
     for cx in (4, 6, 9):
         _check_dd_gpu(ca, gm.silk_dd_capture(gm.synth_voice(16000 * 3, 50 + cx), cx), "fresh capture complexity %d" % cx)
+
+
+def test_burg_per_call_hook_with_reference_signature(ca):
+    """opusgpu_silk_burg_modified_c(res_nrg, res_nrg_Q, A_Q16, x, minInvGain_Q30, subfr_length, nb_subfr, D, arch):
+    host pointers, the reference's argument list (silk/SigProc_FIX.h:601); against the captured reference outputs."""
+    g = np.load(GOLD)
+    L = ca.lib.load()
+    for r in range(0, 80, 9):
+        rec = ca.silk.BurgIn.from_buffer_copy(g["silk_burg_in"][r].tobytes())
+        want = ca.silk.BurgOut.from_buffer_copy(g["silk_burg_out"][r].tobytes())
+        nrg, nrg_q = C.c_int32(), C.c_int()
+        A = (C.c_int32 * 16)()
+        x = (C.c_int16 * 384)(*rec.x)
+        L.opusgpu_silk_burg_modified_c(C.byref(nrg), C.byref(nrg_q), A, x, rec.minInvGain_Q30, rec.subfr_length, rec.nb_subfr, rec.D, 0)
+        assert L.opusgpu_get_last_error() == 0
+        assert (nrg.value, nrg_q.value, list(A)[:rec.D]) == (want.res_nrg, want.res_nrg_Q, list(want.A_Q16)[:rec.D]), r
+    L.opusgpu_silk_burg_modified_c(C.byref(nrg), C.byref(nrg_q), A, x, 0, 10, 4, 17, 0)      # order > 16
+    assert L.opusgpu_get_last_error() == -1
