@@ -20,8 +20,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
 
 With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes its own shard of F
 frames -- the frame corpus partitions with no data-path collective -- then the packets are gathered to
-rank 0 over RCCL (outside the timed region's hot loop but inside the timed region, once per step), so
-scaling is "weak" and `value` is the whole-job frames/s.
+rank 0 over RCCL (inside the timed region, once per step; rows trimmed to the longest packet, the exchange of step k
+overlapping the encode of step k+1), so scaling is "weak" and `value` is the whole-job frames/s.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
 timed with events on the launch stream) and `cpu_baseline` (the reference's own C code timed on this
@@ -487,6 +487,7 @@ def main():
             L.opusgpu_kernel_timing_read((ctypes.c_double * 8)(), (ctypes.c_int * 8)(), 8)
             barrier()
             t0 = time.perf_counter()
+        pending = []
         for k in range(steps):
             if side:
                 # consecutive batches on alternating streams: the next batch's front kernels fill the CUs the
@@ -500,12 +501,17 @@ def main():
                 if mixed:
                     silk_join()
             if world > 1 and not a.no_gather:
-                # the only exchange of the path: packets + lengths to rank 0 over RCCL/xGMI
+                # the only exchange of the path: packets + lengths to rank 0 over RCCL/xGMI. Rows are trimmed to the
+                # longest packet and the exchange of step k is left pending while step k+1 is encoded.
                 if side:
                     torch.cuda.current_stream().wait_stream(side[k % len(side)])
-                gathered = gather_packets(out, lens, _r, world)
+                for pg in pending:
+                    gathered = pg.wait()
+                pending = [gather_packets(out, lens, _r, world, sizes=[F] * world, trim=True, async_op=True)]
                 if mixed:
-                    gathered_silk = gather_packets(s_pulses, s_bo, s_bo[:, :4], world)
+                    pending.append(gather_packets(s_pulses, s_bo, s_bo[:, :4], world, sizes=[NS] * world, async_op=True))
+        for pg in pending:
+            gathered = pg.wait()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()

@@ -14,19 +14,47 @@ def shard_range(n_frames, rank, world):
     return lo, hi
 
 
-def gather_packets(out, lens, rng, world=None, dst=0):
+class PendingGather:
+    """Handle of a gather started with async_op=True: wait() blocks the current stream on the exchange and returns
+    (out, lens, rng) on the destination rank (None elsewhere). The exchange runs on the backend's own stream, so kernels
+    launched between gather_packets(...) and wait() overlap it."""
+
+    def __init__(self, works, finish):
+        self._works, self._finish = works, finish
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        return self._finish()
+
+
+def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, async_op=False):
     """Gather the per-rank packet slabs / lengths / final ranges to rank `dst`.
-    Shards may differ in size by one frame, so every rank pads to the largest shard first.
-    Returns (out, lens, rng) concatenated in rank order on `dst`, None elsewhere."""
+    Shards may differ in size by one frame, so every rank pads to the largest shard first. `sizes` = the shard sizes of
+    all ranks when the caller knows them (they follow from shard_range); otherwise they are exchanged first.
+    `trim`: send only the first max(lens) bytes of every packet row (rounded up to 16) instead of the whole stride -- a
+    VBR slab is mostly padding (mean packet ~320 B in a 1500-byte row); costs one device->host read of the maximum.
+    Returns (out, lens, rng) concatenated in rank order on `dst`, None elsewhere; with async_op=True a PendingGather."""
     import torch
     import torch.distributed as dist
     world = world or dist.get_world_size()
     rank = dist.get_rank()
-    n_local = torch.tensor([out.shape[0]], dtype=torch.int64, device=out.device)
-    sizes = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n_local = torch.tensor([out.shape[0]], dtype=torch.int64, device=out.device)
+        got = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(got, n_local)
+        sizes = [int(s.item()) for s in got]
+    sizes = list(sizes)
+    if len(sizes) != world or sizes[rank] != out.shape[0]:
+        raise ValueError("gather_packets: sizes do not describe this job")
     n_max = max(sizes)
+    width = out.shape[1] if out.dim() == 2 else None
+    if trim and width is not None:
+        w = torch.tensor([int(lens.max().item()) if lens.numel() else 0], dtype=torch.int64, device=out.device)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)              # one width for the job
+        w = min(width, max(16, (int(w.item()) + 15) & ~15))
+        out = out[:, :w]
 
     def pad(t):
         if t.shape[0] == n_max:
@@ -35,14 +63,28 @@ def gather_packets(out, lens, rng, world=None, dst=0):
         p[:t.shape[0]] = t
         return p
 
-    results = []
+    works, bufs_all = [], []
     for t in (out, lens, rng):
         t = pad(t)
         bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst)
-        if rank == dst:
-            results.append(torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0))
-    return tuple(results) if rank == dst else None
+        w = dist.gather(t, bufs, dst=dst, async_op=async_op)
+        if async_op:
+            works.append(w)
+        bufs_all.append((t, bufs))      # keep the send buffers alive until the exchange has completed
+
+    def finish():
+        if rank != dst:
+            return None
+        res = [torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0) for _t, bufs in bufs_all]
+        if trim and width is not None and res[0].shape[1] != width:      # back to the caller's row stride
+            full = torch.zeros((res[0].shape[0], width), dtype=res[0].dtype, device=res[0].device)
+            full[:, :res[0].shape[1]] = res[0]
+            res[0] = full
+        return tuple(res)
+
+    if async_op:
+        return PendingGather(works, finish)
+    return finish()
 
 
 def mixed_counts(n_units, silk_eighths=1):

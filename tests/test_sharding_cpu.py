@@ -57,14 +57,23 @@ def _worker(rank, world, port, q):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     shard = np.ascontiguousarray(pcm[lo:hi])
     emu.emu_celt_encode_frames(C.byref(cfg), None, p(shard), m, 1, p(out), 1280, p(lens), p(rng))
-    res = gather_packets(torch.from_numpy(out), torch.from_numpy(lens), torch.from_numpy(rng.view(np.int32)), world)
+    t_out, t_lens, t_rng = torch.from_numpy(out), torch.from_numpy(lens), torch.from_numpy(rng.view(np.int32))
+    res = gather_packets(t_out, t_lens, t_rng, world)
+    # the bench's form: shard sizes known up front, rows trimmed to the longest packet, exchange left pending
+    sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    pending = gather_packets(t_out, t_lens, t_rng, world, sizes=sizes, trim=True, async_op=True)
+    res2 = pending.wait()
     if rank == 0:
-        o, l, r = (t.numpy() for t in res)
         try:
-            ec.assert_packets_equal(o, l, r.view(np.uint32), pk[:n], ln[:n], rg[:n], "sharded")
+            for what, rr in (("sharded", res), ("sharded, trimmed + async", res2)):
+                o, l, r = (t.numpy() for t in rr)
+                assert o.shape == (n, 1280)
+                ec.assert_packets_equal(o, l, r.view(np.uint32), pk[:n], ln[:n], rg[:n], what)
             q.put("ok")
         except AssertionError as e:
             q.put("FAIL: %s" % e)
+    else:
+        assert res is None and res2 is None
     dist.barrier()
     dist.destroy_process_group()
 
