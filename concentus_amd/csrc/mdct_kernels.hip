@@ -96,6 +96,35 @@ __global__ __launch_bounds__(64) void mdct_backward_single_kernel(const i32 *in,
     for (int i = lane; i < N2 + 60; i += 64) out[i] = S.out[i];
 }
 
+// opus_fft_c (opus-fix/celt/kiss_fft.c:580-599): scaled, bit-reversing, out-of-place forward FFT of 480 >> SHIFT complex
+// points, one wavefront per transform; fin / fout hold [re, im] int32 pairs.
+struct __align__(16) FftLds {
+    MdctLds tab;
+    __align__(16) int2 x[480];
+};
+
+template <int SHIFT>
+__global__ __launch_bounds__(64) void fft_kernel(const int2 *__restrict__ fin, int2 *__restrict__ fout, int ntransforms)
+{
+    constexpr int NFFT = 480 >> SHIFT, SCALE_SHIFT = (8 - SHIFT) - 1;    // kiss_fft_state.scale = 17476, scale_shift = 8 - shift
+    __shared__ FftLds S;
+    const int lane = threadIdx.x;
+    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
+    wave_sync();
+    for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
+        const int2 *src = fin + (size_t)t * NFFT;
+        for (int i = lane; i < NFFT; i += 64) {
+            const int2 v = src[i];
+            S.x[T.bitrev[i]] = make_int2(mul16_32_q16(17476, v.x) >> SCALE_SHIFT, mul16_32_q16(17476, v.y) >> SCALE_SHIFT);
+        }
+        wave_sync();
+        fft_wave<SHIFT, 1>(S.x, T.tw, lane);
+        int2 *dst = fout + (size_t)t * NFFT;
+        for (int i = lane; i < NFFT; i += 64) dst[i] = S.x[i];
+        wave_sync();
+    }
+}
+
 static int grid_for(int ntransforms, int waves_per_cu)
 {
     int cap = opusgpu_num_cus() * waves_per_cu;
@@ -136,6 +165,53 @@ extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig
     if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     else            hipLaunchKernelGGL(mdct_backward_kernel<3>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     return opusgpu_check_launch();
+}
+
+extern "C" int opusgpu_fft_batch(const int32_t *d_fin, int32_t *d_fout, int n_transforms, int shift, void *stream)
+{
+    if (n_transforms < 0 || shift < 0 || shift > 3) return OPUSGPU_BAD_ARG;
+    if (n_transforms == 0) return OPUSGPU_OK;
+    if (!d_fin || !d_fout || d_fin == d_fout) return OPUSGPU_BAD_ARG;          // out of place, as opus_fft_c asserts
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n_transforms, 12);
+    const int2 *fin = (const int2 *)d_fin;
+    int2 *fout = (int2 *)d_fout;
+    switch (shift) {
+    case 0: hipLaunchKernelGGL(fft_kernel<0>, dim3(grid), dim3(64), 0, s, fin, fout, n_transforms); break;
+    case 1: hipLaunchKernelGGL(fft_kernel<1>, dim3(grid), dim3(64), 0, s, fin, fout, n_transforms); break;
+    case 2: hipLaunchKernelGGL(fft_kernel<2>, dim3(grid), dim3(64), 0, s, fin, fout, n_transforms); break;
+    default: hipLaunchKernelGGL(fft_kernel<3>, dim3(grid), dim3(64), 0, s, fin, fout, n_transforms); break;
+    }
+    return opusgpu_check_launch();
+}
+
+// opus_fft(cfg, fin, fout) with the reference's argument list (macro at celt/kiss_fft.h:135-178 -> opus_fft_c): host
+// pointers, one transform, synchronous. `cfg` must be one of the four states of the static 48 kHz mode
+// (nfft 480 / 240 / 120 / 60, scale 17476, scale_shift 8 - shift); the head of kiss_fft_state is validated, its
+// tables are not read. Plumbing / parity only.
+struct ref_kiss_fft_state_head { int nfft; int16_t scale; int scale_shift; int shift; };
+
+extern "C" void opusgpu_opus_fft(const void *cfg, const void *fin, void *fout)
+{
+    const ref_kiss_fft_state_head *h = (const ref_kiss_fft_state_head *)cfg;
+    int shift = -1;
+    if (h && fin && fout && fin != fout)
+        for (int k = 0; k < 4; k++)
+            if (h->nfft == (480 >> k) && h->scale == 17476 && h->scale_shift == 8 - k) shift = k;
+    if (shift < 0) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+    const size_t bytes = (size_t)(480 >> shift) * 8;
+    int32_t *d_in = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_in, bytes) != hipSuccess || hipMalloc(&d_out, bytes) != hipSuccess) {
+        opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL);
+        if (d_in) (void)hipFree(d_in);
+        return;
+    }
+    (void)hipMemcpy(d_in, fin, bytes, hipMemcpyHostToDevice);
+    int rc = opusgpu_fft_batch(d_in, d_out, 1, shift, nullptr);
+    if (rc == OPUSGPU_OK && hipMemcpy(fout, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    opusgpu_set_last_error(rc);
 }
 
 // ---- per-call hooks with the reference's own signature (host pointers) ---------------------------

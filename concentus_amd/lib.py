@@ -22,6 +22,9 @@ SYMBOLS = [
     ("opusgpu_mdct_backward_batch", _i, [_vp, _vp, _i, _i, _i, _vp]),
     ("opusgpu_clt_mdct_forward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_clt_mdct_backward", None, [_vp, _vp, _vp, _vp, _i, _i, _i, _i]),
+    ("opusgpu_fft_batch", _i, [_vp, _vp, _i, _i, _vp]),
+    ("opusgpu_opus_fft", None, [_vp, _vp, _vp]),
+    ("opusgpu_celt_pitch_xcorr", C.c_int32, [_vp, _vp, _vp, _i, _i, _i]),
     ("opusgpu_celt_state_size", _i, []),
     ("opusgpu_celt_state_init", _i, [_vp, _i, _vp]),
     ("opusgpu_encode_workspace_bytes", C.c_size_t, [_i]),

@@ -92,3 +92,34 @@ def mdct_backward_batch(freq, sig, shift=0):
                                                  shift, _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_mdct_backward_batch")
     return sig
+
+
+class _KissFftStateHead(C.Structure):
+    # leading fields of kiss_fft_state (celt/kiss_fft.h:75-85, FIXED_POINT) -- all the device path validates
+    _fields_ = [("nfft", C.c_int), ("scale", C.c_int16), ("scale_shift", C.c_int), ("shift", C.c_int)]
+
+
+def opus_fft(fin, shift=0, cfg=None):
+    """opus_fft(cfg, fin, fout) for one transform of 480 >> shift complex points: fin int32 [nfft][2] (host) -> fout.
+    `cfg`: a pointer to one of the static mode's kiss_fft_state objects; by default a head with the same leading fields."""
+    nfft = 480 >> shift
+    fin = _np32(fin, 2 * nfft, "fin")
+    fout = np.zeros(2 * nfft, np.int32)
+    head = _KissFftStateHead(nfft, 17476, 8 - shift, shift if shift else -1)
+    L = _lib.load()
+    L.opusgpu_opus_fft(cfg if cfg is not None else C.byref(head), fin.ctypes.data, fout.ctypes.data)
+    _lib.check(L.opusgpu_get_last_error(), "opusgpu_opus_fft")
+    return fout.reshape(nfft, 2)
+
+
+def fft_batch(fin, shift=0, fout=None):
+    """Batched opus_fft: fin int32 CUDA tensor [n][480 >> shift][2] -> fout of the same shape (out of place)."""
+    import torch
+    nfft = 480 >> shift
+    if not (fin.is_cuda and fin.dtype == torch.int32 and fin.is_contiguous() and fin.dim() == 3 and tuple(fin.shape[1:]) == (nfft, 2)):
+        raise ValueError("fin must be a contiguous int32 CUDA tensor [n][%d][2]" % nfft)
+    if fout is None:
+        fout = torch.empty_like(fin)
+    _lib.check(_lib.load().opusgpu_fft_batch(fin.data_ptr(), fout.data_ptr(), fin.shape[0], shift, _lib.current_stream_handle()),
+               "opusgpu_fft_batch")
+    return fout

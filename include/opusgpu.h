@@ -88,6 +88,19 @@ void opusgpu_clt_mdct_forward(const void *l, int32_t *in, int32_t *out, const in
 void opusgpu_clt_mdct_backward(const void *l, int32_t *in, int32_t *out, const int16_t *window,
                                int overlap, int shift, int stride, int arch);
 
+/* ---- kiss_fft forward transform (opus_fft_c, opus-fix/celt/kiss_fft.c:580-599) ---------------------------
+ * Batched: n_transforms independent FFTs of 480 >> shift complex points, d_fin / d_fout int32 [n][nfft][2] (re, im)
+ * device pointers, out of place; scaling and bit reversal as opus_fft_c with the static mode's states.
+ * Per call: the argument list of the opus_fft macro (celt/kiss_fft.h:135-178), host pointers; `cfg` must be one of
+ * mode48000_960_120's four kiss_fft_state objects (validated by nfft / scale / scale_shift). */
+int opusgpu_fft_batch(const int32_t *d_fin, int32_t *d_fout, int n_transforms, int shift, void *hip_stream);
+void opusgpu_opus_fft(const void *cfg, const void *fin, void *fout);
+
+/* ---- celt_pitch_xcorr, per call (opus-fix/celt/pitch.c:214-258; CELT_PITCH_XCORR_IMPL[] entry, celt/pitch.h:186-204) --
+ * The reference's argument list, host pointers: xcorr[i] = sum_j x[j]*y[i+j] for i < max_pitch, j < len (y holds
+ * len + max_pitch - 1 samples); returns max(1, max xcorr), 0 with opusgpu_get_last_error() set on failure. len <= 2048. */
+int32_t opusgpu_celt_pitch_xcorr(const int16_t *x, const int16_t *y, int32_t *xcorr, int len, int max_pitch, int arch);
+
 /* ---- Opus CELT-only frame encode, batched (BASELINE config #3) -------------------------------------
  * Replaces opus_encode() (opus-fix/src/opus_encoder.c:2007-2025 -> opus_encode_native :938 ->
  * celt_encode_with_ec, opus-fix/celt/celt_encoder.c:1379) for encoders created as

@@ -182,3 +182,72 @@ def test_config2_full_size_properties(ca):
     gain = float(np.sum(r * y) / np.sum(r * r))
     snr = 10 * np.log10(np.sum((gain * r) ** 2) / np.sum((y - gain * r) ** 2))
     assert snr > 60.0, snr
+
+
+@pytest.mark.parametrize("shift", [0, 1, 2, 3])
+def test_fft_batch_and_per_call_hook_match_oracle(ca, shift):
+    """opus_fft_c (celt/kiss_fft.c:580): the batched kernel over 1 000 transforms (noise in celt_sig range and
+    full-scale wrap-around inputs) and the per-call hook with the reference's argument list, against the oracle."""
+    import torch
+    orc = oraclelib.lib()
+    nfft = 480 >> shift
+    rng = np.random.default_rng(300 + shift)
+    x = _noise(rng, (1000, nfft, 2))
+    x[500:] = rng.integers(-(1 << 28), 1 << 28, size=(500, nfft, 2), dtype=np.int64).astype(np.int32)
+    got = ca.fft_batch(_dev(x), shift=shift)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    for t in list(range(0, 1000, 37)) + [999]:
+        exp = np.zeros((nfft, 2), np.int32)
+        orc.orc_fft(oraclelib.ptr(np.ascontiguousarray(x[t])), oraclelib.ptr(exp), shift)
+        assert np.array_equal(got[t], exp), t
+    one = ca.opus_fft(x[3], shift=shift)
+    assert np.array_equal(one, got[3])
+
+
+def test_fft_hook_takes_the_reference_state_objects_if_present(ca):
+    """The per-call hook reads the head of the reference's own kiss_fft_state (mode->mdct.kfft[shift]) and must agree
+    with opus_fft_c run on it; a foreign state is rejected."""
+    import reflib
+    if not reflib.available():
+        pytest.skip("oracle/_ref/libopus_ref.so did not travel")
+    ref = reflib.lib()
+    m = reflib.mode()
+    rng = np.random.default_rng(301)
+    for shift in range(4):
+        nfft = 480 >> shift
+        x = _noise(rng, 2 * nfft)
+        want = np.zeros(2 * nfft, np.int32)
+        ref.opus_fft_c(m.mdct.kfft[shift], oraclelib.ptr(x), oraclelib.ptr(want))
+        got = ca.opus_fft(x, shift=shift, cfg=m.mdct.kfft[shift])
+        assert np.array_equal(got.ravel(), want)
+    L = ca.lib.load()
+    bad = ca.mdct._KissFftStateHead(512, 17476, 8, -1)
+    buf = np.zeros(1024, np.int32)
+    out = np.zeros(1024, np.int32)
+    L.opusgpu_opus_fft(C.byref(bad), buf.ctypes.data, out.ctypes.data)
+    assert L.opusgpu_get_last_error() == -1
+
+
+@pytest.mark.parametrize("len_,max_pitch", [(240, 128), (480, 257), (1024, 979), (17, 3)])
+def test_celt_pitch_xcorr_hook(ca, len_, max_pitch):
+    """opusgpu_celt_pitch_xcorr(x, y, xcorr, len, max_pitch, arch) -- celt/pitch.c:214: wrapping 32-bit sums and
+    max(1, max), against a numpy restatement and, when it travelled, the compiled reference's celt_pitch_xcorr."""
+    rng = np.random.default_rng(len_ + max_pitch)
+    x = rng.integers(-32768, 32768, size=len_, dtype=np.int16)
+    y = rng.integers(-32768, 32768, size=len_ + max_pitch - 1, dtype=np.int16)
+    L = ca.lib.load()
+    got = np.zeros(max_pitch, np.int32)
+    mx = L.opusgpu_celt_pitch_xcorr(x.ctypes.data, y.ctypes.data, got.ctypes.data, len_, max_pitch, 0)
+    assert L.opusgpu_get_last_error() == 0
+    win = np.lib.stride_tricks.sliding_window_view(y.astype(np.int64), len_)[:max_pitch]
+    exp = ((win * x.astype(np.int64)).sum(1) & 0xffffffff).astype(np.uint32).view(np.int32)
+    assert np.array_equal(got, exp)
+    assert mx == max(1, int(exp.max()))
+    import reflib
+    if reflib.available():
+        ref = reflib.lib()
+        want = np.zeros(max_pitch, np.int32)
+        ref.celt_pitch_xcorr.restype = C.c_int32
+        rmx = ref.celt_pitch_xcorr(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_void_p(want.ctypes.data), len_, max_pitch, 0)
+        assert np.array_equal(got, want) and mx == rmx
