@@ -167,6 +167,20 @@ def test_frames_per_wavefront_of_the_lane_kernels(ca, monkeypatch):
         ec.assert_packets_equal(*res[32][:3], *want, "lane frames 32 vs reference")
 
 
+def test_transient_kernels_agree(ca, monkeypatch):
+    """The transient metric runs tiled through LDS (default) or as the streaming lane kernel
+    (OPUSGPU_TRANSIENT_LANE=1): same arithmetic, same packets -- noise (every frame transient), music (few) and edge
+    frames, with a ragged last tile of rows (1 001 frames = 2 002 rows)."""
+    gm = ec.golden_module()
+    for kind, n, seed in (("noise", 1001, 31), ("music", 515, 32), ("edge", 64, 33)):
+        pcm = gm.synth_pcm(kind, n, seed)
+        a = _gpu_encode(ca, pcm, 1, (96000, 1, 0, 10))
+        monkeypatch.setenv("OPUSGPU_TRANSIENT_LANE", "1")
+        b = _gpu_encode(ca, pcm, 1, (96000, 1, 0, 10))
+        monkeypatch.delenv("OPUSGPU_TRANSIENT_LANE")
+        ec.assert_packets_equal(a[0], a[1], a[2], b[0], b[1], b[2], "transient kernels, %s" % kind)
+
+
 def test_small_workspace_chunks_the_batch(ca, monkeypatch):
     """A workspace smaller than the batch is legal (include/opusgpu.h): the library then runs the pipeline over
     chunks of workspace_bytes / opusgpu_encode_workspace_bytes(1) frames. Same packets, and the fused
