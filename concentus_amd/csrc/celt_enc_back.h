@@ -740,6 +740,60 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
     CA_COUNT("band.tf_change", tf_change);
     CA_COUNT(B > 1 ? "band.short" : "band.long", N);
     CA_STAMP_F(F, 26);
+#if defined(CA_LANE_FRAME)
+    // Lane build: the time-frequency re-arrangement of a band (haar1 levels, then the de-interleave) is pure data movement
+    // over N 16-bit bins. Done in place on X in HBM it costs every lane 2-byte loads and stores at a 4.7 KB stride from
+    // its neighbours' (each touching its own cache line) -- ~190 of them per band. Bands of up to 2*PVQ_LDS_N bins are
+    // instead pulled into the idle PVQ scratch in LDS with 16-byte loads, transformed there, and written back once, in
+    // output order, with 16-byte stores.
+    if (N <= 2 * PVQ_LDS_N && (N & 7) == 0 && (recombine > 0 || B > 1 || ((N_B & 1) == 0 && tf_change < 0))) {
+        LP<i16> T = lp_make(F.lds_pvq16, 64);
+        for (int k = 0; k < N; k += 8) {
+            const int4 v = *reinterpret_cast<const int4 *>(Xband + k);
+            T[k + 0] = (i16)v.x; T[k + 1] = (i16)(v.x >> 16); T[k + 2] = (i16)v.y; T[k + 3] = (i16)(v.y >> 16);
+            T[k + 4] = (i16)v.z; T[k + 5] = (i16)(v.z >> 16); T[k + 6] = (i16)v.w; T[k + 7] = (i16)(v.w >> 16);
+        }
+        wave_sync();
+        for (int k = 0; k < recombine; k++) haar1_wave(T, N >> k, 1 << k);
+        CA_STAMP_F(F, 27);
+        B >>= recombine;
+        N_B <<= recombine;
+        while ((N_B & 1) == 0 && tf_change < 0) {
+            haar1_wave(T, N_B, B);
+            B <<= 1;
+            N_B >>= 1;
+            tf_change++;
+        }
+        CA_STAMP_F(F, 28);
+        // write-back in output order; with B > 1 through the de-interleave (bands.c:524-549): output d*N0 + j takes
+        // input j*stride + s, d = ordery[s] for the Hadamard ordering of long blocks, d = s otherwise
+        const int stride = B > 1 ? B << recombine : 1, N0 = B > 1 ? N_B >> recombine : N;
+        const u8 *ordery = CLT_ordery_table + stride - 2;
+        int d = 0, j = 0, sidx = 0;
+        if (stride > 1 && longBlocks) { while (ordery[sidx] != 0) sidx++; }
+        for (int k = 0; k < N; k += 8) {
+            u32 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                w[u] = (u32)(u16)T[j * stride + sidx];
+                if (++j == N0) {
+                    j = 0;
+                    d++;
+                    sidx = d;
+                    if (stride > 1 && longBlocks && d < stride) { sidx = 0; while (ordery[sidx] != d) sidx++; }
+                }
+            }
+            int4 v;
+            v.x = (i32)(w[0] | (w[1] << 16)); v.y = (i32)(w[2] | (w[3] << 16));
+            v.z = (i32)(w[4] | (w[5] << 16)); v.w = (i32)(w[6] | (w[7] << 16));
+            *reinterpret_cast<int4 *>(Xband + k) = v;
+        }
+        wave_sync();
+        recombine = 0;
+        tf_change = 0;                 // nothing left for the in-place path below
+        if (B > 1) B = -B;             // (restored just below) marks the de-interleave as done
+    }
+#endif
     for (int k = 0; k < recombine; k++) { CA_COUNT("band.haar_recombine", N); haar1_wave(Xband, N >> k, 1 << k); }
     CA_STAMP_F(F, 27);
     B >>= recombine;
@@ -752,9 +806,11 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
         tf_change++;
     }
     CA_STAMP_F(F, 28);
+    bool deinterleaved = false;
+    if (B < 0) { B = -B; deinterleaved = true; }
     const int B0band = B;
     if (B0band > 1) CA_COUNT("band.deinterleave", N);
-    if (B0band > 1) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
+    if (B0band > 1 && !deinterleaved) deinterleave_hadamard_wave(F, Xband, N_B >> recombine, B0band << recombine, longBlocks);
     CA_STAMP_F(F, 21);
 
     int sp = 0;
