@@ -450,13 +450,25 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spre
     LP<i16> X = lp_make(Xg, 1);
     if (in_lds) {
         LP<i16> st = lp_make(F.lds_xs, 64);
-        for (int k = 0; k < N; k += 8) {
-            i32 v[8];
+        if (((uintptr_t)Xg & 15) == 0) {
+            // 16-byte aligned leaf: whole groups of eight bins per load (a group may reach past the leaf into the
+            // following bins of the same frame; they are loaded, not used)
+            for (int k = 0; k < N; k += 8) {
+                i32 v[8];
+                ld_bins8(Xg + k, v);
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = k + u < N ? (i32)Xg[k + u] : 0;
+                for (int u = 0; u < 8; u++)
+                    if (k + u < N) st[k + u] = (i16)v[u];
+            }
+        } else {
+            for (int k = 0; k < N; k += 8) {
+                i32 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (k + u < N) st[k + u] = (i16)v[u];
+                for (int u = 0; u < 8; u++) v[u] = k + u < N ? (i32)Xg[k + u] : 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (k + u < N) st[k + u] = (i16)v[u];
+            }
         }
         X = st;
     }
@@ -551,6 +563,26 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spre
 CA_DEV int stereo_itheta_wave(const i16 *X, const i16 *Y, int stereo, int N)               // vq.c:376-408
 {
     i32 pm = 0, ps = 0;
+#if defined(CA_LANE_FRAME)
+    if ((N & 7) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0) {
+        for (int i = 0; i < N; i += 8) {
+            i32 xv[8], yv[8];
+            ld_bins8(X + i, xv);
+            ld_bins8(Y + i, yv);
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (stereo) {
+                    i32 m = add16(xv[u] >> 1, yv[u] >> 1), sd = (i16)sub16(xv[u] >> 1, yv[u] >> 1);
+                    pm = mac16_16(pm, m, m);
+                    ps = mac16_16(ps, sd, sd);
+                } else {
+                    pm = mac16_16(pm, xv[u], xv[u]);
+                    ps = mac16_16(ps, yv[u], yv[u]);
+                }
+            }
+        }
+    } else
+#endif
     if (stereo) {
         CA_UNROLL_LANE
         for (int i = lane(); i < N; i += LANES) {

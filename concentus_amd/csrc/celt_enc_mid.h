@@ -17,6 +17,18 @@ namespace ca {
 
 CA_DEV int iabs(int a) { return a < 0 ? -a : a; }
 
+#if defined(CA_LANE_FRAME)
+// Lane build: eight consecutive bins of this lane's X (16-byte aligned: every band starts at a multiple of eight bins
+// and holds a multiple of eight) with ONE 16-byte load. A lane's row of X lies 4.7 KB from its neighbours', so every
+// load instruction costs the wavefront one cache line per lane whatever its width.
+CA_DEV void ld_bins8(const i16 *p, i32 v[8])
+{
+    const int4 w = *reinterpret_cast<const int4 *>(p);
+    v[0] = (i16)w.x; v[1] = w.x >> 16; v[2] = (i16)w.y; v[3] = w.y >> 16;
+    v[4] = (i16)w.z; v[5] = w.z >> 16; v[6] = (i16)w.w; v[7] = w.w >> 16;
+}
+#endif
+
 // haar1 on a vector in LDS (bands.c:581-594): N0 halved, `stride` interleaved sub-vectors; all pairs independent.
 template <class P>
 CA_DEV void haar1_wave(P X, int N0, int stride)
@@ -86,8 +98,17 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
 #else
         i16 *tmp = F.s.tf.tmp, *tmp_1 = F.s.tf.tmp1;
 #endif
+#if defined(CA_LANE_FRAME)
+        for (int j = 0; j < N; j += 8) {
+            i32 v[8];
+            ld_bins8(X + tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j, v);
+#pragma unroll
+            for (int u = 0; u < 8; u++) tmp[j + u] = (i16)v[u];
+        }
+#else
         CA_UNROLL_LANE
         for (int j = lane(); j < N; j += LANES) tmp[j] = X[tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j];
+#endif
         wave_sync();
         i32 L1 = l1_metric_wave(tmp, N, isTransient ? LM : 0, bias);
         i32 best_L1 = L1;
@@ -318,6 +339,19 @@ CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
             if (N <= 8) continue;
             const i16 *x = X + M * CLT_eband5ms[i] + c * FRAME;
             i32 t = 0;                                                            // three 10-bit counters
+#if defined(CA_LANE_FRAME)
+            for (int j = 0; j < N; j += 8) {
+                i32 v[8];
+                ld_bins8(x + j, v);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    i32 x2N = mul16_16(mul16_16_q15(v[u], v[u]), N);
+                    if (x2N < 2048) t += 1;
+                    if (x2N < 512) t += 1 << 10;
+                    if (x2N < 128) t += 1 << 20;
+                }
+            }
+#else
             CA_UNROLL_LANE
             for (int j = lane(); j < N; j += LANES) {
                 i32 x2N = mul16_16(mul16_16_q15(x[j], x[j]), N);
@@ -325,6 +359,7 @@ CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
                 if (x2N < 512) t += 1 << 10;
                 if (x2N < 128) t += 1 << 20;
             }
+#endif
             t = wave_add(t);
             int t0 = t & 1023, t1 = (t >> 10) & 1023, t2 = (t >> 20) & 1023;
             if (i > NB - 4) hf_sum += (32 * (t1 + t0)) / N;
@@ -466,6 +501,20 @@ CA_DEVFN int stereo_analysis_wave(L &F)
     const i16 *X = frame_X(F);
     i32 pLR = 0, pMS = 0;
     const int jend = CLT_eband5ms[13] << LM3;
+#if defined(CA_LANE_FRAME)
+    for (int j = 0; j < jend; j += 8) {
+        i32 lv[8], rv[8];
+        ld_bins8(X + j, lv);
+        ld_bins8(X + FRAME + j, rv);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i32 Lv = lv[u], R = rv[u];
+            const i32 Mi = add32(Lv, R), S = sub32(Lv, R);
+            pLR = add32(pLR, add32(Lv < 0 ? -Lv : Lv, R < 0 ? -R : R));
+            pMS = add32(pMS, add32(Mi < 0 ? -Mi : Mi, S < 0 ? -S : S));
+        }
+    }
+#else
     CA_UNROLL_LANE
     for (int j = lane(); j < jend; j += LANES) {
         i32 Lv = X[j], R = X[FRAME + j];
@@ -473,6 +522,7 @@ CA_DEVFN int stereo_analysis_wave(L &F)
         pLR = add32(pLR, add32(Lv < 0 ? -Lv : Lv, R < 0 ? -R : R));
         pMS = add32(pMS, add32(Mi < 0 ? -Mi : Mi, S < 0 ? -S : S));
     }
+#endif
     i32 sumLR = add32(1, wave_add(pLR)), sumMS = add32(1, wave_add(pMS));
     sumMS = mul16_32_q15(23170, sumMS);                                            // QCONST16(0.707107f,15)
     int thetas = 13;
@@ -503,8 +553,18 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
         for (int i = 0; i < 8; i++) {
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
+#if defined(CA_LANE_FRAME)
+            for (int j = 0; j < n; j += 8) {
+                i32 lv[8], rv[8];
+                ld_bins8(X + j0 + j, lv);
+                ld_bins8(X + FRAME + j0 + j, rv);
+#pragma unroll
+                for (int u = 0; u < 8; u++) p = mac16_16(p, lv[u], rv[u]);
+            }
+#else
             CA_UNROLL_LANE
             for (int j = lane(); j < n; j += LANES) p = mac16_16(p, X[j0 + j], X[FRAME + j0 + j]);
+#endif
             sum = add16(sum, (i16)(wave_add(p) >> 18));
         }
         sum = (i16)mul16_16_q15(4096, sum);                                         // QCONST16(1.f/8,15)
@@ -513,8 +573,18 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
         for (int i = 8; i < intensity; i++) {
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
+#if defined(CA_LANE_FRAME)
+            for (int j = 0; j < n; j += 8) {
+                i32 lv[8], rv[8];
+                ld_bins8(X + j0 + j, lv);
+                ld_bins8(X + FRAME + j0 + j, rv);
+#pragma unroll
+                for (int u = 0; u < 8; u++) p = mac16_16(p, lv[u], rv[u]);
+            }
+#else
             CA_UNROLL_LANE
             for (int j = lane(); j < n; j += LANES) p = mac16_16(p, X[j0 + j], X[FRAME + j0 + j]);
+#endif
             i32 v = (i16)(wave_add(p) >> 18);
             minXC = imin(minXC, v < 0 ? -v : v);
         }
