@@ -775,10 +775,10 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
 #if defined(CA_LANE_FRAME)
     // Lane build: the time-frequency re-arrangement of a band (haar1 levels, then the de-interleave) is pure data movement
     // over N 16-bit bins. Done in place on X in HBM it costs every lane 2-byte loads and stores at a 4.7 KB stride from
-    // its neighbours' (each touching its own cache line) -- ~190 of them per band. Bands of up to 2*PVQ_LDS_N bins are
-    // instead pulled into the idle PVQ scratch in LDS with 16-byte loads, transformed there, and written back once, in
-    // output order, with 16-byte stores.
-    if (N <= 2 * PVQ_LDS_N && (N & 7) == 0 && (recombine > 0 || B > 1 || ((N_B & 1) == 0 && tf_change < 0))) {
+    // its neighbours' (each touching its own cache line) -- ~190 of them per band. The band is instead pulled into the
+    // idle per-lane scratch in LDS (all bands but the last fit: N <= LANE_SCRATCH_N = 144) with 16-byte loads, transformed
+    // there, and written back once, in output order, with 16-byte stores.
+    if (N <= LANE_SCRATCH_N && (N & 7) == 0 && (recombine > 0 || B > 1 || ((N_B & 1) == 0 && tf_change < 0))) {
         LP<i16> T = lp_make(F.lds_pvq16, 64);
         for (int k = 0; k < N; k += 8) {
             const int4 v = *reinterpret_cast<const int4 *>(Xband + k);

@@ -91,10 +91,11 @@ CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate
         const int width = CLT_eband5ms[i + 1] - CLT_eband5ms[i];
         const int N = width << LM, narrow = width == 1;
 #if defined(CA_LANE_FRAME)
-        // bands of up to 48 bins are analysed in the workgroup's LDS scratch ([element][lane])
-        const bool in_lds = N <= 48;
-        LP<i16> tmp = in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.tf.tmp, 1);
-        LP<i16> tmp_1 = in_lds ? lp_make(F.lds_pvq16 + 48 * 64, 64) : lp_make((i16 *)F.s.tf.tmp1, 1);
+        // the band is analysed in the workgroup's LDS scratch ([element][lane], LANE_SCRATCH_N slots per lane); its second
+        // copy (transient frames) too when both fit
+        const bool one_in_lds = N <= LANE_SCRATCH_N, two_in_lds = 2 * N <= LANE_SCRATCH_N;
+        LP<i16> tmp = one_in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.tf.tmp, 1);
+        LP<i16> tmp_1 = two_in_lds ? lp_make(F.lds_pvq16 + (LANE_SCRATCH_N / 2) * 64, 64) : lp_make((i16 *)F.s.tf.tmp1, 1);
 #else
         i16 *tmp = F.s.tf.tmp, *tmp_1 = F.s.tf.tmp1;
 #endif

@@ -36,10 +36,20 @@ struct LdsTables {
 #undef X
 };
 __shared__ LdsTables g_lds_tables;
-// PVQ search state of the 64 frames of the workgroup, [element][lane]: y and |x| (int16, 48 each), iy (int32, 48)
-__shared__ int16_t g_lds_pvq16[2 * 48 * 64];
-__shared__ int32_t g_lds_pvq32[48 * 64];
-__shared__ int16_t g_lds_xs[48 * 64];
+// Per-lane scratch of the 64 frames of the workgroup, [element][lane] (30 KB in one block). Every lane owns ONE column,
+// and the two wavefronts of a workgroup (OPUSGPU_LANE_FRAMES=32) run independently, so an array may only ever be
+// addressed with the element size its region is laid out for -- a 16-bit view of the 32-bit region would land in other
+// lanes' columns:
+//   16-bit slots   0.. 95  PVQ search state y and |x| (48 each)          g_lds_pvq16
+//   16-bit slots  96..143  the leaf's copy of X (48)                     g_lds_xs
+//   then 48 32-bit slots   PVQ search state iy                           g_lds_pvq32
+// Stages that run while the PVQ search is idle (band re-arrangement, TF analysis) use the 16-bit part as one array of up
+// to LANE_SCRATCH_N bins through g_lds_pvq16.
+enum { LANE_SCRATCH_N = 144 };
+__shared__ __attribute__((aligned(16))) int16_t g_lds_scratch[(LANE_SCRATCH_N + 2 * 48) * 64];
+#define g_lds_pvq16 (ca::g_lds_scratch)
+#define g_lds_xs (ca::g_lds_scratch + 96 * 64)
+#define g_lds_pvq32 (reinterpret_cast<int32_t *>(ca::g_lds_scratch + LANE_SCRATCH_N * 64))
 __device__ __forceinline__ void fill_lds_tables()
 {
 #define X(T, NAME, N) for (int k = threadIdx.x; k < N; k += blockDim.x) g_lds_tables.NAME##_[k] = NAME[k];
