@@ -516,7 +516,9 @@ def main():
         elapsed = time.perf_counter() - t0
         barrier()
         KNAMES = ["celt_front_kernel", "celt_back_kernel", "celt_back_lane_kernel", "celt_dc_reject_kernel",
-                  "celt_front1_kernel", "celt_transient_kernel", "celt_front2_kernel"]
+                  "celt_front1_kernel",
+                  "celt_transient_kernel" if os.environ.get("OPUSGPU_TRANSIENT_LANE") else "celt_transient_tile_kernel",
+                  "celt_front2_kernel"]
         NK = len(KNAMES)
         ksum = (ctypes.c_double * NK)()
         kcnt = (ctypes.c_int * NK)()
@@ -533,6 +535,7 @@ def main():
             "celt_dc_reject_kernel": PCM_BYTES + PCM_BYTES,
             "celt_front1_kernel": PCM_BYTES + IN_BYTES + (MID_BYTES - PCM_BYTES),
             "celt_transient_kernel": IN_BYTES + 8,
+            "celt_transient_tile_kernel": 2 * IN_BYTES + 8,       # two passes over the time signal by construction
             "celt_front2_kernel": IN_BYTES + MID_BYTES,
             "celt_back_kernel": MID_BYTES + mean_len + 8,
             "celt_back_lane_kernel": MID_BYTES + mean_len + 8,

@@ -629,6 +629,9 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
     int qn = compute_qn(N, *b, offset, pulse_cap, stereo);
     if (stereo && i >= ctx.intensity) qn = 1;
     int itheta = stereo_itheta_wave(X, Y, stereo, N);
+#if defined(CA_LANE_FRAME)
+    const bool vec8 = (N & 7) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0;      // whole 16-byte groups of bins
+#endif
     i32 tell = (i32)ec_tell_frac(ec);
     if (qn != 1) {
         itheta = (itheta * qn + 8192) >> 14;
@@ -653,10 +656,39 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
                 i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
                 i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
                 i32 a1 = (i16)(shl32(left, 14) / norm), a2 = (i16)(shl32(right, 14) / norm);
+#if defined(CA_LANE_FRAME)
+                if (vec8)
+                    for (int j = 0; j < N; j += 8) {
+                        i32 xv[8], yv[8];
+                        ld_bins8(X + j, xv);
+                        ld_bins8(Y + j, yv);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) xv[u] = (i16)(mac16_16(mul16_16(a1, xv[u]), a2, yv[u]) >> 14);
+                        st_bins8(X + j, xv);
+                    }
+                else
+#endif
                 CA_UNROLL_LANE
                 for (int j = lane(); j < N; j += LANES)
                     X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
             } else {
+#if defined(CA_LANE_FRAME)
+                if (vec8)
+                    for (int j = 0; j < N; j += 8) {                                       // stereo_split (bands.c:362-373)
+                        i32 xv[8], yv[8];
+                        ld_bins8(X + j, xv);
+                        ld_bins8(Y + j, yv);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const i32 l = mul16_16(23170, xv[u]), r = mul16_16(23170, yv[u]);
+                            xv[u] = (i16)(add32(l, r) >> 15);
+                            yv[u] = (i16)(sub32(r, l) >> 15);
+                        }
+                        st_bins8(X + j, xv);
+                        st_bins8(Y + j, yv);
+                    }
+                else
+#endif
                 CA_UNROLL_LANE
                 for (int j = lane(); j < N; j += LANES) {                                  // stereo_split (bands.c:362-373)
                     i32 l = mul16_16(23170, X[j]), r = mul16_16(23170, Y[j]);

@@ -27,6 +27,14 @@ CA_DEV void ld_bins8(const i16 *p, i32 v[8])
     v[0] = (i16)w.x; v[1] = w.x >> 16; v[2] = (i16)w.y; v[3] = w.y >> 16;
     v[4] = (i16)w.z; v[5] = w.z >> 16; v[6] = (i16)w.w; v[7] = w.w >> 16;
 }
+// ... and the store of eight bins (values taken modulo 2^16)
+CA_DEV void st_bins8(i16 *p, const i32 v[8])
+{
+    int4 w;
+    w.x = (i32)(((u32)v[0] & 0xffffu) | ((u32)v[1] << 16)); w.y = (i32)(((u32)v[2] & 0xffffu) | ((u32)v[3] << 16));
+    w.z = (i32)(((u32)v[4] & 0xffffu) | ((u32)v[5] << 16)); w.w = (i32)(((u32)v[6] & 0xffffu) | ((u32)v[7] << 16));
+    *reinterpret_cast<int4 *>(p) = w;
+}
 #endif
 
 // haar1 on a vector in LDS (bands.c:581-594): N0 halved, `stride` interleaved sub-vectors; all pairs independent.
