@@ -23,7 +23,7 @@ struct __attribute__((aligned(16))) DecWork {
     i16 *X;                        // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
 #if defined(CA_LANE_FRAME)
     i32 *lds_pvq32;                // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
-    i16 *lds_pvq16;                // -> ... of the (de)interleave scratch (96 bins)
+    i16 *lds_pvq16;                // -> ... of the 16-bit scratch (LANE_SCRATCH_N bins: (de)interleave, band staging)
 #endif
     i16 norm[2 * 624];             // folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel
     i32 iy[176];
@@ -458,7 +458,8 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
     return cm_total;
 }
 
-CA_DEV void haar1_ref(i16 *X, int N0, int stride)                                               // bands.c:580-594
+template <class P>
+CA_DEV void haar1_ref(P X, int N0, int stride)                                                  // bands.c:580-594
 {
     N0 >>= 1;
     for (int i = 0; i < stride; i++) {
@@ -612,6 +613,65 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     unsigned cm = quant_partition_dec(F, dec, ctx, X, N, b, B, lp, LM, gain, fill);
     CA_STAMP_F(F, 8);
     // resynthesis
+#if defined(CA_LANE_FRAME)
+    // Lane build: undoing the band's time-frequency re-arrangement (interleave, haar1 levels) is data movement over N0
+    // 16-bit bins. In place on X in HBM every step costs 2-byte loads and stores, one cache line per lane each; the band is
+    // instead pulled into the idle per-lane LDS scratch with 16-byte loads (through the interleave), transformed there,
+    // and written back once with 16-byte stores (same scheme as the encoder's band set-up, celt_enc_back.h).
+    if (N0 <= LANE_SCRATCH_N && (N0 & 7) == 0 && ((uintptr_t)X & 15) == 0 && (B0 > 1 || time_divide > 0 || recombine > 0)) {
+        LP<i16> T = lp_make(F.lds_pvq16, 64);
+        {   // interleave_hadamard (bands.c:551-578) on the way in: X[d*Ni + j] -> T[j*stride + i], d = ordery[i] or i
+            const int stride = B0 > 1 ? B0 << recombine : 1, Ni = B0 > 1 ? N_B >> recombine : N0;
+            const u8 *ordery = CLT_ordery_table + stride - 2;
+            int d = 0, j = 0, i = 0;
+            if (stride > 1 && longBlocks) { while (ordery[i] != 0) i++; }
+            for (int k = 0; k < N0; k += 8) {
+                const int4 w = *reinterpret_cast<const int4 *>(X + k);
+                const i32 v[8] = {(i16)w.x, w.x >> 16, (i16)w.y, w.y >> 16, (i16)w.z, w.z >> 16, (i16)w.w, w.w >> 16};
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    T[j * stride + i] = (i16)v[u];
+                    if (++j == Ni) {
+                        j = 0;
+                        d++;
+                        i = d;
+                        if (stride > 1 && longBlocks && d < stride) { i = 0; while (ordery[i] != d) i++; }
+                    }
+                }
+            }
+        }
+        N_B = N_B0;
+        B = B0;
+        for (int k = 0; k < time_divide; k++) {
+            B >>= 1;
+            N_B <<= 1;
+            cm |= cm >> B;
+            haar1_ref(T, N_B, B);
+        }
+        for (int k = 0; k < recombine; k++) {
+            cm = CLT_bit_deinterleave_table[cm];
+            haar1_ref(T, N0 >> k, 1 << k);
+        }
+        B <<= recombine;
+        const i32 n = (i16)celt_sqrt(shl32(N0, 22));
+        for (int k = 0; k < N0; k += 8) {
+            u32 h[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i32 v = T[k + u];
+                h[u] = (u32)v & 0xffffu;
+                if (lowband_out) lowband_out[k + u] = (i16)mul16_16_q15(n, v);
+            }
+            int4 w;
+            w.x = (i32)(h[0] | (h[1] << 16)); w.y = (i32)(h[2] | (h[3] << 16));
+            w.z = (i32)(h[4] | (h[5] << 16)); w.w = (i32)(h[6] | (h[7] << 16));
+            *reinterpret_cast<int4 *>(X + k) = w;
+        }
+        cm &= (1u << B) - 1;
+        CA_STAMP_F(F, 9);
+        return cm;
+    }
+#endif
     if (B0 > 1) interleave_hadamard_ref(F, X, N_B >> recombine, B0 << recombine, longBlocks);
     N_B = N_B0;
     B = B0;
