@@ -147,7 +147,8 @@ CA_DEV void exp_rotation1_ref(i16 *X, int len, int stride, i32 c, i32 s)        
     }
 }
 
-CA_DEV void exp_rotation_inv(i16 *X, int len, int stride, int K, int spread)                    // vq.c:70-117, dir = -1
+template <class P>
+CA_DEV void exp_rotation_inv(P X, int len, int stride, int K, int spread)                       // vq.c:70-117, dir = -1
 {
     if (2 * K >= len || spread == SPREAD_NONE) return;
     const int factor = spread == SPREAD_LIGHT ? 15 : spread == SPREAD_NORMAL ? 10 : 5;
@@ -270,13 +271,38 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
         int k = celt_ilog2(Ryy) >> 1;
         i32 t = vshr32(Ryy, 2 * (k - 7));
         i32 g = (i16)mul16_16_p15(celt_rsqrt_norm(t), gain);
+#if defined(CA_LANE_FRAME)
+        if (N <= LANE_SCRATCH_N) {
+            // the leaf is scaled and un-rotated in the per-lane LDS scratch (16-bit part; iy sits in the 32-bit part) and
+            // reaches X in HBM once, sixteen bytes at a time where the leaf is aligned
+            LP<i16> T = lp_make(F.lds_pvq16, 64);
+#pragma unroll 8
+            for (int i = 0; i < N; i++) T[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
+            CA_STAMP_F(F, 5);
+            exp_rotation_inv(T, N, B, K, spread);
+            if ((N & 7) == 0 && ((uintptr_t)X & 15) == 0) {
+                for (int i = 0; i < N; i += 8) {
+                    u32 h[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) h[u] = (u32)(i32)T[i + u] & 0xffffu;
+                    int4 w;
+                    w.x = (i32)(h[0] | (h[1] << 16)); w.y = (i32)(h[2] | (h[3] << 16));
+                    w.z = (i32)(h[4] | (h[5] << 16)); w.w = (i32)(h[6] | (h[7] << 16));
+                    *reinterpret_cast<int4 *>(X + i) = w;
+                }
+            } else {
+#pragma unroll 8
+                for (int i = 0; i < N; i++) X[i] = T[i];
+            }
+        } else
+#endif
         {
 #pragma unroll 8
             for (int i = 0; i < N; i++) X[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
+            CA_STAMP_F(F, 5);
+            exp_rotation_inv(X, N, B, K, spread);
         }
     }
-    CA_STAMP_F(F, 5);
-    exp_rotation_inv(X, N, B, K, spread);
     CA_STAMP_F(F, 6);
     if (B <= 1) return 1;                                                                     // extract_collapse_mask
     const int N0 = (int)((u32)N / (u32)B);
