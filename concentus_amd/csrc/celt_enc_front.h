@@ -283,9 +283,13 @@ CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pi
 {
     const int C = fc.C, len = MAXP + FRAME;
     i16 *x_lp = F.s.pitch.buf;
+    // The first frame of a stream (every frame of the independent-frames workload) has an all-zero history: pre[c][k] = 0
+    // for k < 1024. Zeros change neither the extrema nor any of the wrapping sums below, and they decimate / filter to
+    // zeros, so those ranges are skipped (x_lp[0..512) is simply cleared).
+    const int k0 = fc.hist ? 0 : MAXP, h0 = k0 >> 1;
     i32 mx = 0, mn = 0;                                                            // celt_maxabs32 per channel
     for (int c = 0; c < C; c++)
-        for (int k = lane(); k < len; k += LANES) {
+        for (int k = k0 + lane(); k < len; k += LANES) {
             i32 v = pre_at(F, fc, c, k);
             mx = imax(mx, v);
             mn = imin(mn, v);
@@ -295,7 +299,8 @@ CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pi
     int shift = celt_ilog2(maxabs) - 10;
     if (shift < 0) shift = 0;
     if (C == 2) shift++;
-    for (int i = lane(); i < (len >> 1); i += LANES) {
+    for (int i = lane(); i < h0; i += LANES) x_lp[i] = 0;
+    for (int i = h0 + lane(); i < (len >> 1); i += LANES) {
         i32 acc = 0;
         for (int c = 0; c < C; c++) {
             i32 v;
@@ -313,7 +318,7 @@ CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pi
     // _celt_autocorr(x_lp, ac, NULL, 0, 4, n = 992)  (celt_lpc.c:232-330), overlap == 0
     const int n = len >> 1, lag = 4, fastN = n - lag;
     i32 part = 0;
-    for (int i = lane(); i < n; i += LANES) part = add32(part, mul16_16(x_lp[i], x_lp[i]) >> 9);
+    for (int i = h0 + lane(); i < n; i += LANES) part = add32(part, mul16_16(x_lp[i], x_lp[i]) >> 9);
     i32 ac0 = add32(1 + (n << 7), wave_add(part));
     int sh = (celt_ilog2(ac0) - 30 + 10) / 2;
     i32 ac[5];
@@ -323,7 +328,7 @@ CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pi
     (void)fastN;
     for (int k = 0; k <= lag; k++) {
         i32 p = 0;
-        for (int i = lane(); i + k < n; i += LANES) {
+        for (int i = (h0 ? h0 - LANES : 0) + lane(); i + k < n; i += LANES) {       // products with x_lp[i < h0] are zero
             i32 a = sh ? (i16)pshr32(x_lp[i], sh) : x_lp[i];
             i32 b = sh ? (i16)pshr32(x_lp[i + k], sh) : x_lp[i + k];
             p = mac16_16(p, a, b);
@@ -377,7 +382,7 @@ CA_DEVFN void pitch_downsample_wave(L &F, const FrameCtx &fc)              // pi
     num[4] = (i16)mul16_16_q15(c1, lpc[3]);
     // celt_fir5 in place, zero initial memory (pitch.c:105-145). Chunks go from the end so that the taps
     // x[i-1..i-5] are still unfiltered when read.
-    for (int base = ((n - 1) / LANES) * LANES; base >= 0; base -= LANES) {
+    for (int base = ((n - 1) / LANES) * LANES; base >= h0; base -= LANES) {       // below h0: zeros in, zeros out
         int i = base + lane();
         i32 y = 0;
         if (i < n) {
@@ -529,6 +534,9 @@ CA_DEVFN int pitch_search_wave(L &F)
         const int2 *xv = reinterpret_cast<const int2 *>(x4), *yv = reinterpret_cast<const int2 *>(y4 + i0);
         i32 s0 = 0, s1 = 0, s2 = 0, s3 = 0;
         int2 w0 = yv[0];
+#if !defined(CA_HOST_EMU)
+#pragma unroll 4
+#endif
         for (int c = 0; c < (len >> 4); c++) {
             const int2 w1 = yv[c + 1], xx = xv[c];
             const i32 x0 = (i16)xx.x, x1 = xx.x >> 16, x2 = (i16)xx.y, x3 = xx.y >> 16;
