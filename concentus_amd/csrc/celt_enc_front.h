@@ -502,7 +502,7 @@ CA_DEV void find_best_pitch_wave(const i32 *xcorr, const i16 *y, int len, int ma
 
 // pitch_search(x_lp = buf+512, y = buf, len = 960, max_pitch = 979)  (pitch.c:260-369)
 template <class L>
-CA_DEVFN int pitch_search_wave(L &F)
+CA_DEVFN int pitch_search_wave(L &F, bool zero_hist)
 {
     const int len = FRAME, max_pitch = MAXP - 3 * MINP, lag = len + max_pitch;
     const i16 *y = F.s.pitch.buf, *x_lp = F.s.pitch.buf + (MAXP >> 1);
@@ -510,14 +510,17 @@ CA_DEVFN int pitch_search_wave(L &F)
     i32 *xcorr = F.s.pitch.xcorr;
     i32 mx = 0, mn = 0, my = 0, ny = 0;
     for (int j = lane(); j < (len >> 2); j += LANES) { i32 v = x_lp[2 * j]; x4[j] = (i16)v; mx = imax(mx, v); mn = imin(mn, v); }
-    for (int j = lane(); j < (lag >> 2); j += LANES) { i32 v = y[2 * j]; y4[j] = (i16)v; my = imax(my, v); ny = imin(ny, v); }
+    // first frame of a stream: y[0..512) is the all-zero history (pitch_downsample_wave), so y4[0..256) is zero as well
+    const int z4 = zero_hist ? (MAXP >> 3) * 2 : 0;
+    for (int j = lane(); j < z4; j += LANES) y4[j] = 0;
+    for (int j = z4 + lane(); j < (lag >> 2); j += LANES) { i32 v = y[2 * j]; y4[j] = (i16)v; my = imax(my, v); ny = imin(ny, v); }
     i32 xmax = imax(wave_max(mx), -wave_min(mn));
     i32 ymax = imax(wave_max(my), -wave_min(ny));
     int shift = celt_ilog2(imax(1, imax(xmax, ymax))) - 11;
     wave_sync();
     if (shift > 0) {
         for (int j = lane(); j < (len >> 2); j += LANES) x4[j] = (i16)(x4[j] >> shift);
-        for (int j = lane(); j < (lag >> 2); j += LANES) y4[j] = (i16)(y4[j] >> shift);
+        for (int j = z4 + lane(); j < (lag >> 2); j += LANES) y4[j] = (i16)(y4[j] >> shift);
         shift *= 2;
     } else {
         shift = 0;
@@ -742,7 +745,7 @@ CA_DEVFN PrefilterOut run_prefilter_wave(L &F, FrameCtx &fc, const i32 *in_mem, 
         CA_STAMP_F(F, 3);
         pitch_downsample_wave(F, fc);
         CA_STAMP_F(F, 23);
-        pitch_index = pitch_search_wave(F);
+        pitch_index = pitch_search_wave(F, fc.hist == nullptr);
         CA_STAMP_F(F, 24);
         pitch_index = MAXP - pitch_index;
         gain1 = remove_doubling_wave(F, &pitch_index, fc.prefilter_period, fc.prefilter_gain);
