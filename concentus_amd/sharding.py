@@ -34,7 +34,8 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
     Shards may differ in size by one frame, so every rank pads to the largest shard first. `sizes` = the shard sizes of
     all ranks when the caller knows them (they follow from shard_range); otherwise they are exchanged first.
     `trim`: send only the first max(lens) bytes of every packet row (rounded up to 16) instead of the whole stride -- a
-    VBR slab is mostly padding (mean packet ~320 B in a 1500-byte row); costs one device->host read of the maximum.
+    VBR slab is mostly padding (mean packet ~320 B in a 1500-byte row); costs one device->host read of the maximum. The
+    gathered slab then has that trimmed row width.
     Returns (out, lens, rng) concatenated in rank order on `dst`, None elsewhere; with async_op=True a PendingGather."""
     import torch
     import torch.distributed as dist
@@ -75,12 +76,9 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
     def finish():
         if rank != dst:
             return None
-        res = [torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0) for _t, bufs in bufs_all]
-        if trim and width is not None and res[0].shape[1] != width:      # back to the caller's row stride
-            full = torch.zeros((res[0].shape[0], width), dtype=res[0].dtype, device=res[0].device)
-            full[:, :res[0].shape[1]] = res[0]
-            res[0] = full
-        return tuple(res)
+        # with trim the gathered slab keeps the trimmed row width (>= every packet length): re-expanding 8 x 65 536 rows
+        # to the 1500-byte stride on the destination would cost more than the exchange itself
+        return tuple(torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0) for _t, bufs in bufs_all)
 
     if async_op:
         return PendingGather(works, finish)

@@ -67,7 +67,7 @@ def _worker(rank, world, port, q):
         try:
             for what, rr in (("sharded", res), ("sharded, trimmed + async", res2)):
                 o, l, r = (t.numpy() for t in rr)
-                assert o.shape == (n, 1280)
+                assert o.shape[0] == n and (o.shape[1] == 1280 if what == "sharded" else o.shape[1] >= int(ln[:n].max()))
                 ec.assert_packets_equal(o, l, r.view(np.uint32), pk[:n], ln[:n], rg[:n], what)
             q.put("ok")
         except AssertionError as e:
