@@ -52,8 +52,8 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
     n_max = max(sizes)
     width = out.shape[1] if out.dim() == 2 else None
     if trim and width is not None:
-        w = torch.tensor([int(lens.max().item()) if lens.numel() else 0], dtype=torch.int64, device=out.device)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)              # one width for the job
+        w = (lens.max() if lens.numel() else torch.zeros((), dtype=lens.dtype, device=lens.device)).to(torch.int64).reshape(1)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)              # one width for the job; the only host read of the exchange
         w = min(width, max(16, (int(w.item()) + 15) & ~15))
         out = out[:, :w]
 
