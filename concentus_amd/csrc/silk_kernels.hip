@@ -302,7 +302,28 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
         const i32 b0 = B_Q14[0], b1 = B_Q14[1], b2 = B_Q14[2], b3 = B_Q14[3], b4 = B_Q14[4];
         const i32 *x_Q3 = in.x_Q3 + k * subfr_length;
         i16 *pxq = &NSQ.xq[ltp_mem_length + k * subfr_length];
+        // The pitch-lag taps slide by one sample per step: they are kept in registers (pt[j] = sLTP_Q15[pred_lag - j],
+        // st[j] = sLTP_shp_Q14[shp_lag - j]) and only the newest one is loaded. A step writes position idx and the newest
+        // taps of the NEXT step sit at idx + 3 - lag / idx + 2 - lag, i.e. were written at least a step ago when lag >= 4
+        // (pitch lags are >= 2 ms): they are fetched a whole step ahead, like the next input sample.
+        i32 pt[5] = {0, 0, 0, 0, 0}, st[3] = {0, 0, 0}, pn = 0, sn = 0;
+        if (voiced) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) pt[j] = sLTP_Q15[pred_lag - j];
+        }
+        if (lag > 0) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) st[j] = NSQ.sLTP_shp_Q14[shp_lag - j];
+        }
+        const bool ahead = lag >= 8;
+        i32 xn = x_Q3[0];
         for (int i = 0; i < subfr_length; i++) {
+            const i32 xcur = xn;
+            xn = x_Q3[i + 1 < subfr_length ? i + 1 : i];
+            if (ahead) {
+                if (voiced) pn = sLTP_Q15[pred_lag + 1];
+                sn = NSQ.sLTP_shp_Q14[shp_lag + 1];
+            }
             rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
             i32 LPC_pred_Q10 = predictLPCOrder >> 1;
 #pragma unroll
@@ -314,12 +335,11 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             i32 LTP_pred_Q13 = 0;
             if (voiced) {
                 LTP_pred_Q13 = 2;
-                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag], b0);
-                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 1], b1);
-                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 2], b2);
-                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 3], b3);
-                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, sLTP_Q15[pred_lag - 4], b4);
-                pred_lag++;
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[0], b0);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[1], b1);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[2], b2);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[3], b3);
+                LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[4], b4);
             }
             // noise shape feedback: the sAR2 delay line shifts by one (NSQ.c:262-279)
             i32 tmp2 = lp[0], tmp1 = ar[0];
@@ -352,17 +372,16 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             tmp1 = s_subw(shl32(LPC_pred_Q10, 2), n_AR_Q12);
             tmp1 = s_subw(tmp1, n_LF_Q12);
             if (lag > 0) {
-                i32 n_LTP_Q13 = s_smulwb(s_addw(NSQ.sLTP_shp_Q14[shp_lag], NSQ.sLTP_shp_Q14[shp_lag - 2]), HarmShapeFIRPacked_Q14);
-                n_LTP_Q13 = s_smlawt(n_LTP_Q13, NSQ.sLTP_shp_Q14[shp_lag - 1], HarmShapeFIRPacked_Q14);
+                i32 n_LTP_Q13 = s_smulwb(s_addw(st[0], st[2]), HarmShapeFIRPacked_Q14);
+                n_LTP_Q13 = s_smlawt(n_LTP_Q13, st[1], HarmShapeFIRPacked_Q14);
                 n_LTP_Q13 = shl32(n_LTP_Q13, 1);
-                shp_lag++;
                 tmp2 = s_subw(LTP_pred_Q13, n_LTP_Q13);
                 tmp1 = s_addw(tmp2, shl32(tmp1, 1));
                 tmp1 = s_rshift_round(tmp1, 3);
             } else {
                 tmp1 = s_rshift_round(tmp1, 2);
             }
-            i32 r_Q10 = s_subw(s_smulww(x_Q3[i], inv_gain_Q23), tmp1);
+            i32 r_Q10 = s_subw(s_smulww(xcur, inv_gain_Q23), tmp1);
             if (rand_seed < 0) r_Q10 = (i32)(0u - (u32)r_Q10);
             r_Q10 = s_limit(r_Q10, -(31 << 10), 30 << 10);
             i32 q1_Q10 = r_Q10 - offset_Q10, q2_Q10, rd1_Q20, rd2_Q20;
@@ -423,6 +442,17 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             sLTP_shp_buf_idx++;
             sLTP_buf_idx++;
             rand_seed = (i32)((u32)rand_seed + (u32)pulse);
+            // slide the taps
+            if (!ahead) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (voiced) pn = sLTP_Q15[pred_lag + 1];
+                if (lag > 0) sn = NSQ.sLTP_shp_Q14[shp_lag + 1];
+            }
+            pred_lag++;
+            shp_lag++;
+            pt[4] = pt[3]; pt[3] = pt[2]; pt[2] = pt[1]; pt[1] = pt[0]; pt[0] = pn;
+            st[2] = st[1]; st[1] = st[0]; st[0] = sn;
         }
     }
     // ---- state write-back ----
@@ -439,9 +469,20 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
     NSQ.rand_seed = rand_seed;
     NSQ.prev_gain_Q16 = prev_gain_Q16;
     NSQ.rewhite_flag = rewhite_flag;
-    // silk_memmove of the histories (NSQ.c:176-177): ascending copy is safe (dst < src)
-    for (int i = 0; i < ltp_mem_length; i++) NSQ.xq[i] = NSQ.xq[i + frame_length];
-    for (int i = 0; i < ltp_mem_length; i++) NSQ.sLTP_shp_Q14[i] = NSQ.sLTP_shp_Q14[i + frame_length];
+    // silk_memmove of the histories (NSQ.c:176-177): ascending copy is safe (dst < src). The record is only 4-byte
+    // aligned (4 380 bytes), so the copy moves 16 bytes at a time through a 4-byte-aligned vector type.
+    if ((ltp_mem_length & 7) == 0 && (frame_length & 1) == 0) {
+        struct __attribute__((packed, aligned(4))) V16 { i32 x, y, z, w; };
+        V16 *dq = reinterpret_cast<V16 *>(NSQ.xq);
+        const V16 *sq = reinterpret_cast<const V16 *>(NSQ.xq + frame_length);
+        for (int i = 0; i < ltp_mem_length / 8; i++) { const V16 v = sq[i]; dq[i] = v; }
+        V16 *ds = reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14);
+        const V16 *ss = reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length);
+        for (int i = 0; i < ltp_mem_length / 4; i++) { const V16 v = ss[i]; ds[i] = v; }
+    } else {
+        for (int i = 0; i < ltp_mem_length; i++) NSQ.xq[i] = NSQ.xq[i + frame_length];
+        for (int i = 0; i < ltp_mem_length; i++) NSQ.sLTP_shp_Q14[i] = NSQ.sLTP_shp_Q14[i + frame_length];
+    }
 }
 
 }  // namespace ca
