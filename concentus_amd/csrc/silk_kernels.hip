@@ -317,7 +317,22 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
         }
         const bool ahead = lag >= 8;
         i32 xn = x_Q3[0];
-        for (int i = 0; i < subfr_length; i++) {
+        // The five per-sample outputs (pulse, xq, sLPC_Q14, sLTP_shp_Q14, sLTP_Q15) are collected for four samples and
+        // written with one store each (a store instruction costs the wavefront one cache line per lane whatever its width).
+        // Nothing reads them back within the group when lag >= 8; otherwise the group is one sample.
+        struct __attribute__((packed, aligned(4))) V16 { i32 x, y, z, w; };
+        struct __attribute__((packed, aligned(4))) V8 { i32 x, y; };
+        const int G = (ahead || lag <= 0) ? 4 : 1;            // no pitch lag: nothing is read back at all
+        for (int i0 = 0; i0 < subfr_length; i0 += G) {
+          i32 o_lpc[4] = {0, 0, 0, 0}, o_shp[4] = {0, 0, 0, 0}, o_ltp[4] = {0, 0, 0, 0};
+          u32 o_xq[4] = {0, 0, 0, 0}, o_pl[4] = {0, 0, 0, 0};
+          const int shp_idx0 = sLTP_shp_buf_idx, ltp_idx0 = sLTP_buf_idx;
+          int cnt = 0;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int i = i0 + u;
+            if (u >= G || i >= subfr_length) break;
+            cnt = u + 1;
             const i32 xcur = xn;
             xn = x_Q3[i + 1 < subfr_length ? i + 1 : i];
             if (ahead) {
@@ -413,7 +428,7 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             rd2_Q20 = s_addw(rd2_Q20, s_smulbb(rr_Q10, rr_Q10));
             if (rd2_Q20 < rd1_Q20) q1_Q10 = q2_Q10;
             const i32 pulse = (i8)s_rshift_round(q1_Q10, 10);
-            pulses[k * subfr_length + i] = (i8)pulse;
+            o_pl[u] = (u32)pulse & 0xffu;
             i32 exc_Q14 = shl32(q1_Q10, 4);
             if (rand_seed < 0) exc_Q14 = (i32)(0u - (u32)exc_Q14);
             const i32 LPC_exc_Q14 = s_addw(exc_Q14, shl32(LTP_pred_Q13, 1));
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             {   // silk_SAT16(silk_RSHIFT_ROUND(silk_SMULWW(xq_Q14, Gain_Q10), 8)) in 64 bits
                 i64 t = ((i64)xq_Q14 * Gain_Q10) >> 16;
                 t = ((t >> 7) + 1) >> 1;
-                pxq[i] = (i16)(t > 32767 ? 32767 : (t < -32768 ? -32768 : t));
+                o_xq[u] = (u32)(i32)(t > 32767 ? 32767 : (t < -32768 ? -32768 : t)) & 0xffffu;
             }
             // slide the LPC history (register shift) and record the sample in the state buffer
             {
@@ -434,25 +449,55 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
                 for (int j = 15; j > 0; j--) lp[j] = lp[j - 1];
                 lp[0] = xq_Q14;
             }
-            NSQ.sLPC_Q14[32 + i] = xq_Q14;
+            o_lpc[u] = xq_Q14;
             sLF_AR_shp_Q14 = s_subw(xq_Q14, shl32(n_AR_Q12, 2));
             shp_prev = s_subw(sLF_AR_shp_Q14, shl32(n_LF_Q12, 2));
-            NSQ.sLTP_shp_Q14[sLTP_shp_buf_idx] = shp_prev;
-            sLTP_Q15[sLTP_buf_idx] = shl32(LPC_exc_Q14, 1);
+            o_shp[u] = shp_prev;
+            o_ltp[u] = shl32(LPC_exc_Q14, 1);
             sLTP_shp_buf_idx++;
             sLTP_buf_idx++;
             rand_seed = (i32)((u32)rand_seed + (u32)pulse);
             // slide the taps
-            if (!ahead) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (voiced) pn = sLTP_Q15[pred_lag + 1];
-                if (lag > 0) sn = NSQ.sLTP_shp_Q14[shp_lag + 1];
-            }
             pred_lag++;
             shp_lag++;
             pt[4] = pt[3]; pt[3] = pt[2]; pt[2] = pt[1]; pt[1] = pt[0]; pt[0] = pn;
             st[2] = st[1]; st[1] = st[0]; st[0] = sn;
+          }
+          if (cnt == 4) {
+              *reinterpret_cast<u32 *>(&pulses[k * subfr_length + i0]) = o_pl[0] | (o_pl[1] << 8) | (o_pl[2] << 16) | (o_pl[3] << 24);
+              V8 xv; xv.x = (i32)(o_xq[0] | (o_xq[1] << 16)); xv.y = (i32)(o_xq[2] | (o_xq[3] << 16));
+              *reinterpret_cast<V8 *>(&pxq[i0]) = xv;
+              V16 v; v.x = o_lpc[0]; v.y = o_lpc[1]; v.z = o_lpc[2]; v.w = o_lpc[3];
+              *reinterpret_cast<V16 *>(&NSQ.sLPC_Q14[32 + i0]) = v;
+              v.x = o_shp[0]; v.y = o_shp[1]; v.z = o_shp[2]; v.w = o_shp[3];
+              *reinterpret_cast<V16 *>(&NSQ.sLTP_shp_Q14[shp_idx0]) = v;
+              v.x = o_ltp[0]; v.y = o_ltp[1]; v.z = o_ltp[2]; v.w = o_ltp[3];
+              *reinterpret_cast<V16 *>(&sLTP_Q15[ltp_idx0]) = v;
+          } else {
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                  if (u >= cnt) break;
+                  pulses[k * subfr_length + i0 + u] = (i8)o_pl[u];
+                  pxq[i0 + u] = (i16)o_xq[u];
+                  NSQ.sLPC_Q14[32 + i0 + u] = o_lpc[u];
+                  NSQ.sLTP_shp_Q14[shp_idx0 + u] = o_shp[u];
+                  sLTP_Q15[ltp_idx0 + u] = o_ltp[u];
+              }
+          }
+          if (G == 1) {
+              // tiny lags (never produced by the SILK pitch analysis, whose lags are >= 2 ms): a step may read what the step
+              // before it stored, so the taps are re-read from memory after every (single-sample) group
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              if (voiced) {
+#pragma unroll
+                  for (int j = 0; j < 5; j++) pt[j] = sLTP_Q15[pred_lag - j];
+              }
+              if (lag > 0) {
+#pragma unroll
+                  for (int j = 0; j < 3; j++) st[j] = NSQ.sLTP_shp_Q14[shp_lag - j];
+              }
+          }
         }
     }
     // ---- state write-back ----
