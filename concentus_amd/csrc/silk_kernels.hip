@@ -28,12 +28,35 @@ namespace ca {
 enum { QA = 25, COND_FAC_Q32 = 42950 };                              // SILK_FIX_CONST(FIND_LPC_COND_FAC = 1e-5f, 32)
 
 // ---- silk_burg_modified: one lane per record --------------------------------------------------------
+// A record's samples x[384] are read ~25 times each (16 autocorrelation lags, then both ends of every subframe in
+// every order of the recursion). From HBM that is a 2-byte load per use at a 784-byte stride between lanes -- one cache
+// line per lane per instruction. The wavefront instead copies its 64 records' samples into LDS once (16-byte loads),
+// laid out [sample][lane], and every later use is a conflict-free LDS read.
+struct BurgX {
+    const i16 *p;                                              // this lane's column of the [sample][lane] block
+    __device__ __forceinline__ i32 operator[](int k) const { return p[k * 64]; }
+    __device__ __forceinline__ BurgX operator+(int o) const { BurgX r; r.p = p + o * 64; return r; }
+};
+
 __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__restrict__ recs, opusgpu_burg_out *__restrict__ outs, int n_rec)
 {
+    __shared__ i16 xs[OPUSGPU_SILK_BURG_MAX_X * 64];
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_burg_in &in = recs[r];
-    const i16 *x = in.x;
+    {
+        static_assert(sizeof(opusgpu_burg_in) % 16 == 0 && OPUSGPU_SILK_BURG_MAX_X % 8 == 0, "16-byte loads of x");
+        const int nx = in.subfr_length * in.nb_subfr;
+        const int4 *src = reinterpret_cast<const int4 *>(in.x);
+        i16 *col = xs + threadIdx.x;
+        for (int k = 0; k < nx; k += 8) {
+            const int4 w = src[k >> 3];
+            col[(k + 0) * 64] = (i16)w.x; col[(k + 1) * 64] = (i16)(w.x >> 16); col[(k + 2) * 64] = (i16)w.y; col[(k + 3) * 64] = (i16)(w.y >> 16);
+            col[(k + 4) * 64] = (i16)w.z; col[(k + 5) * 64] = (i16)(w.z >> 16); col[(k + 6) * 64] = (i16)w.w; col[(k + 7) * 64] = (i16)(w.w >> 16);
+        }
+    }
+    BurgX x;
+    x.p = xs + threadIdx.x;
     const int subfr_length = in.subfr_length, nb_subfr = in.nb_subfr, D = in.D;
     const i32 minInvGain_Q30 = in.minInvGain_Q30;
     i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
@@ -53,7 +76,7 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
     for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
     if (rshifts > 0) {
         for (s = 0; s < nb_subfr; s++) {
-            const i16 *xp = x + s * subfr_length;
+            const BurgX xp = x + s * subfr_length;
             for (n = 1; n < D + 1; n++) {
                 i64 acc = 0;
                 for (k = 0; k < subfr_length - n; k++) acc += __mul24(xp[k], xp[k + n]);
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
         }
     } else {
         for (s = 0; s < nb_subfr; s++) {
-            const i16 *xp = x + s * subfr_length;
+            const BurgX xp = x + s * subfr_length;
             for (n = 1; n < D + 1; n++) {
                 i32 d = 0;           // celt_pitch_xcorr + tail loop = the full lag-n product, 32-bit wrap-around
                 for (k = n; k < subfr_length; k++) d = s_addw(d, __mul24(xp[k], xp[k - n]));
@@ -76,7 +99,7 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
     for (n = 0; n < D; n++) {
         if (rshifts > -2) {
             for (s = 0; s < nb_subfr; s++) {
-                const i16 *xp = x + s * subfr_length;
+                const BurgX xp = x + s * subfr_length;
                 x1 = (i32)(0u - (u32)shl32(xp[n], 16 - rshifts));
                 x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], 16 - rshifts));
                 tmp1 = shl32(xp[n], QA - 16);
@@ -97,7 +120,7 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
             }
         } else {
             for (s = 0; s < nb_subfr; s++) {
-                const i16 *xp = x + s * subfr_length;
+                const BurgX xp = x + s * subfr_length;
                 x1 = (i32)(0u - (u32)shl32(xp[n], -rshifts));
                 x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], -rshifts));
                 tmp1 = shl32(xp[n], 17);
@@ -173,14 +196,14 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
         for (k = 0; k < D; k++) out.A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
         if (rshifts > 0) {
             for (s = 0; s < nb_subfr; s++) {
-                const i16 *xp = x + s * subfr_length;
+                const BurgX xp = x + s * subfr_length;
                 i64 acc = 0;
                 for (k = 0; k < D; k++) acc += __mul24(xp[k], xp[k]);
                 C0 = s_subw(C0, (i32)(acc >> rshifts));
             }
         } else {
             for (s = 0; s < nb_subfr; s++) {
-                const i16 *xp = x + s * subfr_length;
+                const BurgX xp = x + s * subfr_length;
                 i32 acc = 0;
                 for (k = 0; k < D; k++) acc = s_addw(acc, __mul24(xp[k], xp[k]));
                 C0 = s_subw(C0, shl32(acc, -rshifts));
