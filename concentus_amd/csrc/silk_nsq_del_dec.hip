@@ -404,13 +404,24 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
             NSQ.rewhite_flag = rewhite;
         }
         quad_fence();
-        // silk_memmove of the two histories by frame_length (:315-316), shared out over the quad: element m takes
-        // m + frame_length; a forward copy only overwrites what earlier iterations have already read
-        for (int m = k; m < ltp_mem; m += 4) {
-            const i16 a = NSQ.xq[m + frame_length];
-            const i32 b = NSQ.sLTP_shp_Q14[m + frame_length];
-            NSQ.xq[m] = a;
-            NSQ.sLTP_shp_Q14[m] = b;
+        // silk_memmove of the two histories by frame_length (:315-316), shared out over the quad in 16-byte pieces (the
+        // record is only 4-byte aligned, hence the 4-byte-aligned vector type); a forward copy only overwrites what
+        // earlier iterations have already read (the source runs frame_length >= 32 elements ahead)
+        if ((ltp_mem & 7) == 0 && (frame_length & 7) == 0) {
+            struct __attribute__((packed, aligned(4))) V16 { i32 x, y, z, w; };
+            V16 *dq = reinterpret_cast<V16 *>(NSQ.xq);
+            const V16 *sq = reinterpret_cast<const V16 *>(NSQ.xq + frame_length);
+            for (int c = k; c < ltp_mem / 8; c += 4) { const V16 v = sq[c]; dq[c] = v; }
+            V16 *ds = reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14);
+            const V16 *ss = reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length);
+            for (int c = k; c < ltp_mem / 4; c += 4) { const V16 v = ss[c]; ds[c] = v; }
+        } else {
+            for (int m = k; m < ltp_mem; m += 4) {
+                const i16 a = NSQ.xq[m + frame_length];
+                const i32 b = NSQ.sLTP_shp_Q14[m + frame_length];
+                NSQ.xq[m] = a;
+                NSQ.sLTP_shp_Q14[m] = b;
+            }
         }
     }
 }
