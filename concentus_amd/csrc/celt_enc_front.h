@@ -244,8 +244,10 @@ CA_DEV void preemphasis_wave(L &F, FrameCtx &fc)
         // pcmf aliases the first half of xf: channel 1 goes first (its xf half is clear of pcmf), channel 0
         // walks down in blocks whose reads complete before their writes (xf[0][i] lands on pcmf[2i], pcmf[2i+1]).
         for (int c = fc.C - 1; c >= 0; c--) {
-            const i32 mem0 = fc.preemph_memE[c];
-            fc.preemph_memE[c] = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+            // (no fc.preemph_memE[c]: a run-time index into FrameCtx would send the whole struct to scratch memory)
+            const i32 mem0 = c ? fc.preemph_memE[1] : fc.preemph_memE[0];
+            const i32 memn = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+            if (c) fc.preemph_memE[1] = memn; else fc.preemph_memE[0] = memn;
             wave_sync();
             for (int base = FRAME - LANES; base >= 0; base -= LANES) {
                 const int i = base + lane();
@@ -261,10 +263,11 @@ CA_DEV void preemphasis_wave(L &F, FrameCtx &fc)
     for (int c = 0; c < fc.C; c++) {
         for (int i = lane(); i < FRAME; i += LANES) {
             i32 x = pcmf[c * FRAME + i];
-            i32 m = i == 0 ? fc.preemph_memE[c] : (mul16_16(27853, pcmf[c * FRAME + i - 1]) >> 3);
+            i32 m = i == 0 ? (c ? fc.preemph_memE[1] : fc.preemph_memE[0]) : (mul16_16(27853, pcmf[c * FRAME + i - 1]) >> 3);
             tsig(F, c)[OVL + i] = sub32(shl32(x, 12), m);
         }
-        fc.preemph_memE[c] = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+        const i32 memn = mul16_16(27853, pcmf[c * FRAME + FRAME - 1]) >> 3;
+        if (c) fc.preemph_memE[1] = memn; else fc.preemph_memE[0] = memn;
     }
     wave_sync();
 }
@@ -566,7 +569,8 @@ CA_DEVFN int pitch_search_wave(L &F, bool zero_hist)
     wave_sync();
     maxcorr = 1;
     for (int cand = 0; cand < 2; cand++) {
-        for (int i = imax(0, 2 * best_pitch[cand] - 2); i <= imin((max_pitch >> 1) - 1, 2 * best_pitch[cand] + 2); i++) {
+        const int bpc = cand ? best_pitch[1] : best_pitch[0];        // (a run-time index would put best_pitch[] in scratch memory)
+        for (int i = imax(0, 2 * bpc - 2); i <= imin((max_pitch >> 1) - 1, 2 * bpc + 2); i++) {
             if (cand == 1) { int d0 = i - 2 * best_pitch[0]; if ((d0 < 0 ? -d0 : d0) <= 2) continue; }   // done already
             i32 p = 0;
             for (int j = lane(); j < (len >> 1); j += LANES) p = add32(p, mul16_16(x_lp[j], y[i + j]) >> shift);
