@@ -1,36 +1,48 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the batched Opus frame path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload celt|mdct|silk|decode|mixed] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--workload celt|celt_streams|mdct|silk|silk_deldec|decode|mixed] [--frames F]
 
 One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM.
 
-  celt (default)  BASELINE.json configs[2]: 65 536 independent 48 kHz stereo 20 ms frames per GPU,
-                  full CELT encode (opus_encode(): dc_reject, pre-emphasis, pitch pre-filter, MDCT,
-                  PVQ quant_all_bands, range coder) at 96 kb/s VBR complexity 10 -- the configuration the
-                  metric "frames encoded/sec" is quoted on. Algorithmic bytes: 3 840 B PCM in + packet
-                  (~255 B) + 8 B (len, rng) per frame (~4 090 B/frame).
-  silk            BASELINE.json configs[3]: 65 536 function-boundary records, silk_burg_modified + silk_NSQ
+  celt (default)  BASELINE.json configs[2]: 65 536 independent 48 kHz stereo 20 ms frames per GPU (each the first frame
+                  of its own stream), full CELT encode (opus_encode(): dc_reject, pre-emphasis, pitch pre-filter, MDCT,
+                  PVQ quant_all_bands, range coder) at 96 kb/s VBR complexity 10 -- the configuration the metric
+                  "frames encoded/sec" is quoted on. Algorithmic bytes: 3 840 B PCM in + packet + 8 B.
+  celt_streams    the same encoder in streams mode: 65 536 streams per GPU, every step encodes the NEXT 20 ms frame of
+                  every stream (encoder state, 9 KB per stream, carried in HBM) -- no first-frame short-cuts.
+  silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
-  mixed           BASELINE.json configs[4]: per GPU 131 072 units = 7/8 CELT frames (as celt) + 1/8 SILK records (as silk);
-                  with --gpus 8 that is the 1 M-unit corpus sharded over the node.
+  silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  mixed           BASELINE.json configs[4]: per GPU 131 072 units = 7/8 CELT frames (as celt) + 1/8 SILK records (as
+                  silk); with --gpus 8 that is the 1 M-unit corpus sharded over the node.
   decode          the packets of configs[2] through opusgpu_decode_batch (fresh decoder each).
   mdct            BASELINE.json configs[1]: 4 096 frames, clt_mdct_forward + clt_mdct_backward only
                   (33 600 algorithmic bytes per stereo frame) -- the HBM-bound slice.
 
-With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank encodes its own shard of F
-frames -- the frame corpus partitions with no data-path collective -- then the packets are gathered to
-rank 0 over RCCL (inside the timed region, once per step; rows trimmed to the longest packet, the exchange of step k
-overlapping the encode of step k+1), so scaling is "weak" and `value` is the whole-job frames/s.
+N > 1: one rank per GPU. Either the driver launches the ranks (python -m torch.distributed.run ... bench.py --gpus N:
+RANK / LOCAL_RANK / WORLD_SIZE in the environment), or `python bench.py --gpus N` alone starts them itself: the parent
+process touches no GPU, spawns torch.distributed.run as a CHILD (never exec) and exits with its status. Every rank
+encodes its own shard of F frames -- the corpus partitions with no data-path collective -- then the packets are gathered
+to rank 0 over RCCL (inside the timed region, once per step; rows trimmed to the longest packet, the exchange of step k
+overlapping the encode of step k+1), so scaling is "weak" and `value` is the whole-job frames/s. A world size that
+differs from --gpus is an error.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel,
-timed with events on the launch stream) and `cpu_baseline` (the reference's own C code timed on this
-box's host cores over a bounded sample).
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant kernel, timed with HIP events
+on the launch stream), `cpu_baseline` (the reference's own C code timed on this box's host cores over a bounded
+sample) and `parity_checked` (units of the LAST timed step compared bit-exactly with the reference after the clock
+stopped; a mismatch is a failure, not a number).
+
+--rehearse: no GPU and no codec work -- the ranks only rendezvous on gloo and run the packet gather on synthetic
+slabs; `value` is null. It exists so the multi-rank launch path can be tested on a CPU-only machine.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,23 +52,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS = 256 * 4                    # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine clock
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "decode", "mixed"]
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="celt", choices=["celt", "mdct", "silk", "silk_deldec", "decode", "mixed"])
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step")
+    ap.add_argument("--workload", default="celt", choices=WORKLOADS)
+    ap.add_argument("--frames", type=int, default=None, help="frames (units) per GPU per step")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("CONCENTUS_BENCH_STREAMS", "1")),
                     help="celt: HIP streams the consecutive batches (steps) alternate over (each with its own workspace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-clock comparison with the reference")
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL packet gather (N > 1)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse", action="store_true", help="CPU only: rendezvous on gloo + packet gather, no codec work")
+    return ap.parse_args(argv)
+
+
+# ---- multi-rank launch ---------------------------------------------------------------------------------------
+def launch_ranks(a, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children of this (GPU-free) process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def host_threads():
@@ -64,42 +95,54 @@ def host_threads():
     return min(cores, 16)          # one GPU's share of the host (the box allots 16 per GPU)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def cpu_baseline_mdct(seed_sig):
-    """Reference clt_mdct_forward_c + clt_mdct_backward_c (oracle/_ref, kind "reference"), or our C
-    restatement (kind "port") if that library did not travel, on a bounded sample."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    cores = host_threads()
-    n = 2048
-    sig = np.ascontiguousarray(np.tile(seed_sig, (n // seed_sig.shape[0] + 1, 1, 1))[:n])
-    freq = np.zeros((n, 2, 960), np.int32)
-    rec = sig.copy()
-    refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
-    if os.path.exists(refdrv):
-        drv = C.CDLL(refdrv)
-        drv.refdrv_mdct_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
-
-        def run(threads):
-            drv.refdrv_mdct_batch(_p(sig), _p(freq), _p(rec), n * 2, 0, 3, threads)
-        kind = "reference"
-    else:
-        import oraclelib
-        orc = oraclelib.lib()
-
-        def run(threads):
-            orc.orc_mdct_forward_batch(_p(sig), _p(freq), n, 2, 0)
-            orc.orc_mdct_backward_batch(_p(freq), _p(rec), n, 2, 0)
-        kind = "port"
-        cores = 1
-    one, multi = _time_cpu(run, n, cores)
-    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": "%d stereo frames x clt_mdct_forward_c+clt_mdct_backward_c (shift 0) per pass, "
-                      "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+def _refdrv():
+    path = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
+    return C.CDLL(path) if os.path.exists(path) else None
 
 
+class RefCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in "channels bitrate vbr constrained_vbr complexity lsb_depth loss_rate max_data_bytes".split()]
+
+
+def ref_encode(pcm, cfgvals, fps, threads):
+    """The compiled reference's opus_encode() over frames [n][960][2] (stream-major, fps frames per stream)."""
+    drv = _refdrv()
+    cfg = RefCfg(*cfgvals)
+    n = pcm.shape[0]
+    pcm = np.ascontiguousarray(pcm)
+    out = np.zeros((n, 1280), np.uint8)
+    lens = np.zeros(n, np.int32)
+    rng = np.zeros(n, np.uint32)
+    drv.refdrv_encode_frames(C.byref(cfg), _p(pcm), C.c_long(n), fps, _p(out), 1280, _p(lens), _p(rng), threads)
+    return out, lens, rng
+
+
+def check_packets(what, got_pk, got_len, got_rng, exp_pk, exp_len, exp_rng):
+    if not np.array_equal(got_len, exp_len):
+        raise SystemExit("PARITY FAILURE (%s): packet lengths differ at %s" % (what, np.nonzero(got_len != exp_len)[0][:8]))
+    if not np.array_equal(got_rng.astype(np.uint32), exp_rng):
+        raise SystemExit("PARITY FAILURE (%s): final ranges differ" % what)
+    w = int(exp_len.max())
+    mask = np.arange(w)[None, :] < exp_len[:, None]
+    if not np.array_equal(np.where(mask, got_pk[:, :w], 0), np.where(mask, exp_pk[:, :w], 0)):
+        raise SystemExit("PARITY FAILURE (%s): packet bytes differ" % what)
+
+
+# ---- CPU baselines (the checker's code timed on the host; never on the product path) ----------------------------
 def _time_cpu(run, n, cores):
     run(1)
     t0 = time.perf_counter()
@@ -120,41 +163,79 @@ def _time_cpu(run, n, cores):
     return one, multi
 
 
-def cpu_baseline_celt(pcm_sample, cfgvals):
-    """The reference's own opus_encode() (unmodified opus-fix, FIXED_POINT, -O2; oracle/_ref) over a
-    bounded sample of the same workload: independent frames = fresh opus_encoder_create + opus_demo
-    ctl sequence + one opus_encode per frame."""
-    refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
-    if not os.path.exists(refdrv):
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
-                "sample": "oracle/_ref/librefdrv.so did not travel; no CPU baseline"}
-    drv = C.CDLL(refdrv)
+def _no_ref(unit="frames/s"):
+    return {"value": None, "unit": unit, "cores": 0, "kind": "reference", "cpu": cpu_model(),
+            "sample": "oracle/_ref/librefdrv.so did not travel; no CPU baseline"}
 
-    class Cfg(C.Structure):
-        _fields_ = [(k, C.c_int32) for k in "channels bitrate vbr constrained_vbr complexity lsb_depth loss_rate max_data_bytes".split()]
-    cfg = Cfg(*cfgvals)
+
+def cpu_baseline_mdct(seed_sig):
+    """Reference clt_mdct_forward_c + clt_mdct_backward_c (oracle/_ref, kind "reference"), or our C
+    restatement (kind "port") if that library did not travel, on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    cores = host_threads()
+    n = 2048
+    sig = np.ascontiguousarray(np.tile(seed_sig, (n // seed_sig.shape[0] + 1, 1, 1))[:n])
+    freq = np.zeros((n, 2, 960), np.int32)
+    rec = sig.copy()
+    drv = _refdrv()
+    if drv is not None:
+        drv.refdrv_mdct_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+
+        def run(threads):
+            drv.refdrv_mdct_batch(_p(sig), _p(freq), _p(rec), n * 2, 0, 3, threads)
+        kind = "reference"
+    else:
+        import oraclelib
+        orc = oraclelib.lib()
+
+        def run(threads):
+            orc.orc_mdct_forward_batch(_p(sig), _p(freq), n, 2, 0)
+            orc.orc_mdct_backward_batch(_p(freq), _p(rec), n, 2, 0)
+        kind = "port"
+        cores = 1
+    one, multi = _time_cpu(run, n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": kind, "cpu": cpu_model(),
+            "sample": "%d stereo frames x clt_mdct_forward_c+clt_mdct_backward_c (shift 0) per pass, "
+                      "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+
+
+def cpu_baseline_celt(pcm_sample, cfgvals, fps=1):
+    """The reference's own opus_encode() (unmodified opus-fix, FIXED_POINT, -O2; oracle/_ref) over a bounded sample of
+    the same workload. fps == 1: independent frames = fresh opus_encoder_create + opus_demo ctl sequence + one
+    opus_encode per frame (SURVEY 8d), with the steady-state (streams) rate of the same library next to it;
+    fps > 1: streams of fps frames, one encoder per stream."""
+    if _refdrv() is None:
+        return _no_ref()
     cores = host_threads()
     n = pcm_sample.shape[0]
-    pcm = np.ascontiguousarray(pcm_sample)
-    out = np.zeros((n, 1280), np.uint8)
-    lens = np.zeros(n, np.int32)
-    rng = np.zeros(n, np.uint32)
 
     def run(threads):
-        drv.refdrv_encode_frames(C.byref(cfg), _p(pcm), C.c_long(n), 1, _p(out), 1280, _p(lens), _p(rng), threads)
+        ref_encode(pcm_sample, cfgvals, fps, threads)
     one, multi = _time_cpu(run, n, cores)
-    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
-            "sample": "%d independent frames per pass through opus-fix opus_encode() (create+ctl+encode per frame), "
-                      "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+    if fps == 1:
+        sfps = 32
+        ns = (n // sfps) * sfps
+
+        def run_s(threads):
+            ref_encode(pcm_sample[:ns], cfgvals, sfps, threads)
+        _one_s, multi_s = _time_cpu(run_s, ns, cores)
+        sample = ("%d independent frames per pass through opus-fix opus_encode() (create+ctl+encode per frame), repeated "
+                  "~8 s on %d thread(s); 1 thread: %.0f frames/s; steady state (one encoder per %d-frame stream, same "
+                  "frames): %.0f frames/s on %d threads" % (n, cores, one, sfps, multi_s, cores))
+        extra = {"steady_state_value": round(multi_s, 1)}
+    else:
+        sample = ("%d streams x %d consecutive frames per pass through opus-fix opus_encode() (one encoder per stream), "
+                  "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n // fps, fps, cores, one))
+        extra = {}
+    return dict({"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
+                 "sample": sample}, **extra)
 
 
 def cpu_baseline_decode(pk, ln):
     """The reference's own opus_decode() over a bounded sample: fresh opus_decoder_create + one opus_decode per packet."""
-    refdrv = os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")
-    if not os.path.exists(refdrv):
-        return {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
-                "sample": "oracle/_ref/librefdrv.so did not travel; no CPU baseline"}
-    drv = C.CDLL(refdrv)
+    drv = _refdrv()
+    if drv is None:
+        return _no_ref()
     cores = host_threads()
     n = pk.shape[0]
     pk = np.ascontiguousarray(pk)
@@ -166,22 +247,32 @@ def cpu_baseline_decode(pk, ln):
     def run(threads):
         drv.refdrv_decode_frames(_p(pk), pk.shape[1], _p(ln), C.c_long(n), 1, _p(pcm), _p(rng), _p(ret), threads)
     one, multi = _time_cpu(run, n, cores)
-    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference",
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
             "sample": "%d independent packets per pass through opus-fix opus_decode() (create+decode per packet), "
                       "repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
 
 
-def cpu_baseline_silk(rec, n):
+def _pool_run(work, n):
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(threads):
+        if threads == 1:
+            work(0, n)
+            return
+        per = (n + threads - 1) // threads
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
+    return run
+
+
+def cpu_baseline_silk(bi, ni, st0):
     """CPU baseline for the SILK records: our C restatement (oracle/oracle_silk.c, kind "port"; the reference's
     silk_NSQ_c needs its whole encoder state struct, so it is not driven directly), chunks on a thread pool."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
-    from concurrent.futures import ThreadPoolExecutor
     orc = oraclelib.lib()
     cores = host_threads()
-    bi = np.ascontiguousarray(np.tile(rec["burg_in"], (n // 80 + 1, 1))[:n])
-    ni = np.ascontiguousarray(np.tile(rec["nsq_in"], (n // 80 + 1, 1))[:n])
-    st0 = np.ascontiguousarray(np.tile(rec["nsq_state_in"], (n // 80 + 1, 1))[:n])
+    n = bi.shape[0]
     bo = np.zeros((n, 72), np.uint8)
     no = np.zeros((n, 320), np.uint8)
 
@@ -189,94 +280,132 @@ def cpu_baseline_silk(rec, n):
         st = st0[lo:hi].copy()
         orc.orc_silk_burg_batch(C.c_void_p(bi.ctypes.data + lo * 784), C.c_void_p(bo.ctypes.data + lo * 72), hi - lo)
         orc.orc_silk_nsq_batch(C.c_void_p(ni.ctypes.data + lo * 1640), _p(st), C.c_void_p(no.ctypes.data + lo * 320), hi - lo)
-
-    def run(threads):
-        if threads == 1:
-            work(0, n)
-            return
-        per = (n + threads - 1) // threads
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
-    one, multi = _time_cpu(run, n, cores)
-    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port",
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "%d records (silk_burg_modified + silk_NSQ each) per pass through oracle/oracle_silk.c, repeated ~8 s on "
                       "%d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
-def cpu_baseline_silk_dd(rec, n):
-    """CPU baseline for the silk_NSQ_del_dec records: the C restatement (oracle/oracle_silk.c, kind "port"), chunks on a
-    thread pool."""
+def cpu_baseline_silk_dd(di, st0):
+    """CPU baseline for the silk_NSQ_del_dec records: the C restatement (oracle/oracle_silk.c, kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
-    from concurrent.futures import ThreadPoolExecutor
     orc = oraclelib.lib()
     cores = host_threads()
-    m = rec["dd_in"].shape[0]
-    di = np.ascontiguousarray(np.tile(rec["dd_in"], (n // m + 1, 1))[:n])
-    st0 = np.ascontiguousarray(np.tile(rec["dd_state_in"], (n // m + 1, 1))[:n])
+    n = di.shape[0]
     do = np.zeros((n, 324), np.uint8)
 
     def work(lo, hi):
         st = st0[lo:hi].copy()
         orc.orc_silk_nsq_del_dec_batch(C.c_void_p(di.ctypes.data + lo * 1648), _p(st), C.c_void_p(do.ctypes.data + lo * 324), hi - lo)
-
-    def run(threads):
-        if threads == 1:
-            work(0, n)
-            return
-        per = (n + threads - 1) // threads
-        with ThreadPoolExecutor(threads) as ex:
-            list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
-    one, multi = _time_cpu(run, n, cores)
-    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port",
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "%d silk_NSQ_del_dec records per pass through oracle/oracle_silk.c, repeated ~8 s on %d thread(s); "
                       "1 thread: %.0f records/s" % (n, cores, one)}
 
 
-def silk_records(F, rank, dev):
-    """F function-boundary records on the device: the 80 captured from the reference encoder (tests/golden), tiled, the
-    Burg inputs dithered per record."""
-    import torch
-    g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz"))
+# ---- SILK input records ------------------------------------------------------------------------------------------
+def silk_records(F, kind, rank):
+    """F function-boundary records (host arrays) + a description. Preferred: F DISTINCT records captured on this box
+    from the unmodified reference encoder running on synthetic speech (tests/silk_corpus.py; needs the capture build
+    of the reference, oracle/_ref/libopus_ref_silkcap.so, which travels with the snapshot) -- input generation, before
+    any clock starts; the corpus also carries the reference's outputs, which the post-clock parity check uses.
+    Fallback when the capture library is absent: the committed golden records tiled (and said so)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import silk_corpus
+    if silk_corpus.available():
+        c = silk_corpus.corpus(F, kind, seed=20260401 + 1000003 * rank)
+        return {k: np.ascontiguousarray(v) for k, v in c.items()}, \
+            "%d distinct records captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s VOIP, %s)" % (
+                F, "complexity 3" if kind == "nsq" else "complexity 5/7/10 = 2/3/4 delayed-decision states")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz" if kind == "nsq" else "silk_dd_golden.npz"))
     rec = {k[5:]: g[k] for k in g.files}
-    reps = F // 80 + 1
+    m = next(iter(rec.values())).shape[0]
+    out = {k: np.ascontiguousarray(np.tile(v, (F // m + 1, 1))[:F]) for k, v in rec.items()}
+    for k in ("burg_out", "nsq_out", "nsq_state_out", "dd_out", "dd_state_out"):
+        out.pop(k, None)              # tiled inputs are perturbed below, the captured outputs no longer apply
     rng = np.random.default_rng(4 + rank)
-    bi_h = np.tile(rec["burg_in"], (reps, 1))[:F].copy()
-    bi_h[:, :768].view(np.int16)[...] += rng.integers(-3, 4, size=(F, 384), dtype=np.int16)
-    ni_h = np.tile(rec["nsq_in"], (reps, 1))[:F].copy()
-    st_h = np.tile(rec["nsq_state_in"], (reps, 1))[:F].copy()
-    bi, ni, st0 = (torch.from_numpy(x).to(dev) for x in (bi_h, ni_h, st_h))
-    return rec, bi, ni, st0
+    if kind == "nsq":
+        out["burg_in"][:, :768].view(np.int16)[...] += rng.integers(-3, 4, size=(F, 384), dtype=np.int16)
+    else:
+        out["dd_in"][:, 36:40].view(np.int32)[:, 0] = rng.integers(0, 4, size=F)
+    return out, "%d records = the %d committed golden records tiled (capture library absent)" % (F, m)
 
 
-def main():
-    a = parse()
+def rehearse(a, world, rank):
+    """CPU-only rehearsal of the N-rank path: gloo rendezvous, world-size check, the packet gather on synthetic slabs."""
     import torch
     import torch.distributed as dist
+    from concentus_amd.sharding import gather_packets
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == a.gpus
+    F = a.frames or 256
+    g = torch.Generator().manual_seed(100 + rank)
+    lens = torch.randint(100, 400, (F,), generator=g, dtype=torch.int32)
+    out = torch.randint(0, 256, (F, 1500), generator=g, dtype=torch.uint8)
+    rng = torch.randint(0, 1 << 30, (F,), generator=g, dtype=torch.int32)
+    ok = True
+    if world > 1:
+        res = gather_packets(out, lens, rng, world, sizes=[F] * world, trim=True, async_op=True).wait()
+        if rank == 0:
+            ok = res[0].shape[0] == F * world and bool((res[1][:F] == lens).all()) and bool((res[2][:F] == rng).all())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (no codec work)", "value": None, "unit": "frames/s", "n_gpus": world,
+                          "rehearsal": True, "gather_ok": ok, "frames_per_rank": F}))
+    return 0 if ok else 1
 
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # no launcher around us: start the ranks ourselves, BEFORE anything in this process touches a GPU
+        return launch_ranks(a, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU "
+                         "(python -m torch.distributed.run --nproc-per-node %d ... bench.py --gpus %d)\n"
+                         % (a.gpus, world, a.gpus, a.gpus))
+        return 2
+    if a.rehearse:
+        return rehearse(a, world, rank)
+
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import concentus_amd as ca
-    ca.lib.load()
+    L = ca.lib.load()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    traffic_db = {}
-    tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp):
+    def load_db(name):
+        p = os.path.join(ROOT, "profiles", name)
         try:
-            traffic_db = json.load(open(tp))
+            return json.load(open(p)) if os.path.exists(p) else {}
         except Exception:
-            traffic_db = {}
+            return {}
+    traffic_db = load_db("traffic.json")
+    pmc_db = load_db("pmc.json")           # per kernel: wave-instructions per launch at the default batch (tools/pmc_db.py)
+    sample_threads = host_threads()
+    parity = {"checked": 0, "note": "skipped (--no-parity)" if a.no_parity else ""}
+    limiter = "hbm"
+    unit_bytes = None                      # SURVEY 8d algorithmic bytes per unit of the workload
 
     if a.workload == "mdct":
         F = a.frames or 4096
@@ -314,6 +443,26 @@ def main():
         dtype = "int32"
         extra = {"other_kernel_ms": round(bwd_ms if kname.startswith("mdct_forward") else fwd_ms, 5)}
         cpu = (lambda: cpu_baseline_mdct(host[:256]))
+        if not a.no_parity and rank == 0:
+            drv = _refdrv()
+            if drv is not None:
+                m = min(F, 512)
+                drv.refdrv_mdct_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int]
+                ssig = np.ascontiguousarray(host[:m])
+                sfreq = np.zeros((m, 2, 960), np.int32)
+                # the timed loop left rec = backward(freq) accumulated `steps + warm` times onto sig: check freq, and
+                # one fresh backward on top of sig
+                drv.refdrv_mdct_batch(_p(ssig), _p(sfreq), None, m * 2, 0, 1, sample_threads)
+                srec = ssig.copy()
+                drv.refdrv_mdct_batch(None, _p(sfreq), _p(srec), m * 2, 0, 2, sample_threads)
+                rec2 = sig[:m].clone()
+                ca.mdct_backward_batch(freq[:m].contiguous(), rec2, shift=0)
+                torch.cuda.synchronize()
+                if not (np.array_equal(freq[:m].cpu().numpy(), sfreq) and np.array_equal(rec2.cpu().numpy(), srec)):
+                    raise SystemExit("PARITY FAILURE (mdct)")
+                parity = {"checked": m, "note": "first %d frames of the last step: forward output + one backward vs clt_mdct_*_c of oracle/_ref" % m}
+            else:
+                parity["note"] = "oracle/_ref did not travel"
     elif a.workload == "decode":
         # packets of config #3 (GPU-encoded, bit-exact with the reference) decoded by fresh decoders
         F = a.frames or 65536
@@ -327,8 +476,6 @@ def main():
         for _ in range(warm):
             dec.reset()
             pcm, ret = dec.decode(pk, ln)
-        import ctypes
-        L = ca.lib.load()
         L.opusgpu_kernel_timing_enable(1)
         barrier()
         t0 = time.perf_counter()
@@ -340,8 +487,8 @@ def main():
         barrier()
         assert (ret.cpu().numpy() == 960).all(), "decoder reported an error"
         NK = 10
-        ksum = (ctypes.c_double * NK)()
-        kcnt = (ctypes.c_int * NK)()
+        ksum = (C.c_double * NK)()
+        kcnt = (C.c_int * NK)()
         ca.lib.check(L.opusgpu_kernel_timing_read(ksum, kcnt, NK), "opusgpu_kernel_timing_read")
         L.opusgpu_kernel_timing_enable(0)
         mean_len = float(ln.float().mean().item())
@@ -356,27 +503,43 @@ def main():
                 kern.append({"kernel": nm, "avg_launch_ms": round(avg, 5), "algorithmic_bytes_per_launch": int(F * b),
                              "achieved": round(F * b / (avg * 1e-3) / 1e9, 2), "traffic": traffic_db.get(nm)})
         kern.sort(key=lambda k: -k["avg_launch_ms"])
-        kname, kbytes, kms = kern[0]["kernel"], kern[0]["algorithmic_bytes_per_launch"], kern[0]["avg_launch_ms"]
+        kname, kms = kern[0]["kernel"], kern[0]["avg_launch_ms"]
+        unit_bytes = mean_len + 8 + PCM_BYTES                    # packet + (len, rng) in, PCM out
+        kbytes = int(F * unit_bytes)
+        limiter = "latency / VALU issue (lane per stream)"
         metric = "48kHz stereo 20ms CELT frames decoded/sec"
         workload = ("%d independent CELT-only 20 ms stereo packets per GPU (config #3's packets, mean %.1f B), each through a "
                     "fresh decoder (state reset included in the step), PCM bit-exact vs FIXED_POINT opus_decode()" % (F, mean_len))
         dtype = "int16/int32 fixed-point"
-        extra = {"mean_packet_bytes": round(mean_len, 2), "other_kernels": kern[1:], "state_bytes_per_stream": STATE}
+        extra = {"mean_packet_bytes": round(mean_len, 2), "kernels": kern, "state_bytes_per_stream": STATE}
         pk_h, ln_h = pk[:4096].cpu().numpy(), ln[:4096].cpu().numpy()
         cpu = (lambda: cpu_baseline_decode(pk_h, ln_h))
+        if not a.no_parity and rank == 0:
+            drv = _refdrv()
+            if drv is not None:
+                idx = np.arange(0, F, max(1, F // 1024))[:1024]
+                t_idx = torch.from_numpy(idx).to(dev)
+                spk = np.ascontiguousarray(pk[t_idx].cpu().numpy())
+                sln = np.ascontiguousarray(ln[t_idx].cpu().numpy().astype(np.int32))
+                m = len(idx)
+                epcm = np.zeros((m, 960, 2), np.int16)
+                erng = np.zeros(m, np.uint32)
+                eret = np.zeros(m, np.int32)
+                drv.refdrv_decode_frames(_p(spk), spk.shape[1], _p(sln), C.c_long(m), 1, _p(epcm), _p(erng), _p(eret), sample_threads)
+                if not (np.array_equal(pcm[t_idx].cpu().numpy(), epcm)
+                        and np.array_equal(dec.final_range[t_idx].cpu().numpy().view(np.uint32), erng)):
+                    raise SystemExit("PARITY FAILURE (decode)")
+                parity = {"checked": m, "note": "strided sample of the last step: PCM + final range vs opus_decode() of oracle/_ref"}
+            else:
+                parity["note"] = "oracle/_ref did not travel"
     elif a.workload == "silk_deldec":
-        # silk_NSQ_del_dec (the quantizer of complexity >= 4) over records captured at complexity 5/7/10
+        # silk_NSQ_del_dec (the quantizer of complexity >= 4)
         F = a.frames or 65536
         steps = a.steps or 10
         warm = a.warmup if a.warmup is not None else 2
-        g = np.load(os.path.join(ROOT, "tests", "golden", "silk_dd_golden.npz"))
-        rec = {k[5:]: g[k] for k in g.files}
-        m = rec["dd_in"].shape[0]
-        rng = np.random.default_rng(6 + rank)
-        di_h = np.tile(rec["dd_in"], (F // m + 1, 1))[:F].copy()
-        di_h[:, 36:40].view(np.int32)[:, 0] = rng.integers(0, 4, size=F)              # dither seed per record
-        di = torch.from_numpy(di_h).to(dev)
-        st0 = torch.from_numpy(np.tile(rec["dd_state_in"], (F // m + 1, 1))[:F].copy()).to(dev)
+        rec, rec_desc = silk_records(F, "dd", rank)
+        di = torch.from_numpy(rec["dd_in"]).to(dev)
+        st0 = torch.from_numpy(rec["dd_state_in"]).to(dev)
         st = st0.clone()
         do = torch.empty((F, 324), dtype=torch.uint8, device=dev)
         for _ in range(warm):
@@ -395,17 +558,29 @@ def main():
         kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         kname = "silk_nsq_del_dec_kernel"
         kbytes = F * (1648 + 2 * 4380 + 324)
+        limiter = "latency / VALU issue (per-sample recurrence)"
         metric = "SILK 16kHz mono 20ms frames/sec (silk_NSQ_del_dec records)"
-        workload = ("%d function-boundary records per GPU (84 captured from the reference encoder on 16 kHz mono voice at "
-                    "32 kb/s, complexity 5/7/10 = 2/3/4 delayed-decision states, tiled), silk_NSQ_del_dec, bit-exact vs FIXED_POINT" % F)
+        workload = "%s per GPU, silk_NSQ_del_dec, bit-exact vs FIXED_POINT" % rec_desc
         dtype = "int16/int32/int64 fixed-point"
         extra = {}
-        cpu = (lambda: cpu_baseline_silk_dd(rec, 4096))
+        m_cpu = min(F, 4096)
+        cpu = (lambda: cpu_baseline_silk_dd(rec["dd_in"][:m_cpu], rec["dd_state_in"][:m_cpu]))
+        if not a.no_parity and rank == 0:
+            st.copy_(st0)                          # one more pass from the captured states, outside the clock
+            ca.silk_NSQ_del_dec(di, st, do)
+            torch.cuda.synchronize()
+            if "dd_out" in rec:
+                if not (np.array_equal(do.cpu().numpy(), rec["dd_out"]) and np.array_equal(st.cpu().numpy(), rec["dd_state_out"])):
+                    raise SystemExit("PARITY FAILURE (silk_NSQ_del_dec)")
+                parity = {"checked": F, "note": "every record (pulses, Seed, all of silk_nsq_state) vs the reference's own captured outputs"}
+            else:
+                parity["note"] = "capture library absent: tiled golden inputs, outputs not compared here"
     elif a.workload == "silk":
         F = a.frames or 65536
         steps = a.steps or 20
         warm = a.warmup if a.warmup is not None else 3
-        rec, bi, ni, st0 = silk_records(F, rank, dev)
+        rec, rec_desc = silk_records(F, "nsq", rank)
+        bi, ni, st0 = (torch.from_numpy(rec[k]).to(dev) for k in ("burg_in", "nsq_in", "nsq_state_in"))
         st = st0.clone()
         bo = torch.empty((F, 72), dtype=torch.uint8, device=dev)
         pulses = torch.empty((F, 320), dtype=torch.int8, device=dev)
@@ -429,12 +604,74 @@ def main():
         kms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
         kname = "silk_nsq_kernel"
         kbytes = F * (1640 + 2 * 4380 + 320)
+        limiter = "latency / VALU issue (per-sample recurrence)"
         metric = "SILK 16kHz mono 20ms frames/sec (silk_burg_modified + silk_NSQ records, config #4)"
-        workload = ("configs[3]: %d function-boundary records per GPU (80 captured from the reference encoder on "
-                    "16 kHz mono voice at 32 kb/s complexity 3, tiled), silk_burg_modified + silk_NSQ, bit-exact vs FIXED_POINT" % F)
+        workload = "configs[3]: %s per GPU, silk_burg_modified + silk_NSQ, bit-exact vs FIXED_POINT" % rec_desc
         dtype = "int16/int32/int64 fixed-point"
         extra = {"burg_kernel_ms": round(burg_ms, 5), "burg_GBps": round(F * 856 / (burg_ms * 1e-3) / 1e9, 2)}
-        cpu = (lambda: cpu_baseline_silk(rec, 8192))
+        m_cpu = min(F, 8192)
+        cpu = (lambda: cpu_baseline_silk(rec["burg_in"][:m_cpu], rec["nsq_in"][:m_cpu], rec["nsq_state_in"][:m_cpu]))
+        if not a.no_parity and rank == 0:
+            st.copy_(st0)
+            ca.silk_NSQ(ni, st, pulses)
+            torch.cuda.synchronize()
+            if "nsq_out" in rec:
+                ok = (np.array_equal(bo.cpu().numpy(), rec["burg_out"])
+                      and np.array_equal(pulses.cpu().numpy().view(np.uint8), rec["nsq_out"])
+                      and np.array_equal(st.cpu().numpy(), rec["nsq_state_out"]))
+                if not ok:
+                    raise SystemExit("PARITY FAILURE (silk)")
+                parity = {"checked": F, "note": "every record (A_Q16 / res_nrg, pulses, all of silk_nsq_state) vs the reference's own captured outputs"}
+            else:
+                parity["note"] = "capture library absent: tiled golden inputs, outputs not compared here"
+    elif a.workload == "celt_streams":
+        # streams mode (SURVEY 8d "Definition of independent frame", 8f row 1): S streams, one frame per stream per step
+        F = a.frames or 65536
+        steps = a.steps or 8
+        warm = a.warmup if a.warmup is not None else 2
+        T = steps + warm
+        cfgvals = (2, 96000, 1, 0, 10, 16, 0, 1500)
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        pcm_all = torch.randint(-8192, 8192, (T, F, 960, 2), generator=g, dtype=torch.int16, device=dev)
+        enc = ca.OpusEncoderBatch(F, device=dev).apply_opus_demo_ctls(96000, 1, 0, 10)
+        for t in range(warm):
+            out, lens = enc.encode(pcm_all[t])
+        torch.cuda.synchronize()
+        L.opusgpu_kernel_timing_enable(1)
+        barrier()
+        t0 = time.perf_counter()
+        for t in range(warm, T):
+            out, lens = enc.encode(pcm_all[t])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        _r = enc.final_range
+        kern, mean_len = celt_kernel_table(ca, L, F, steps, lens, traffic_db)
+        dom = kern[0]
+        kname, kms = dom["kernel"], dom["avg_launch_ms"]
+        unit_bytes = PCM_BYTES + mean_len + 8
+        kbytes = int(dom["frames_per_launch"] * unit_bytes)
+        limiter = "latency / VALU issue (lane per frame)"
+        metric = "48kHz stereo 20ms CELT frames encoded/sec (streams mode)"
+        workload = ("streams mode of configs[2]: %d streams per GPU x %d consecutive 48 kHz stereo 20 ms frames (%d warm-up + %d "
+                    "timed; one frame of every stream per step, encoder state 9 024 B/stream in HBM), full CELT encode 96 kb/s "
+                    "VBR complexity 10, packets bit-exact vs FIXED_POINT opus_encode(); mean packet %.1f B" % (F, T, warm, steps, mean_len))
+        dtype = "int16/int32 fixed-point"
+        extra = {"mean_packet_bytes": round(mean_len, 2), "kernels": kern, "realtime_factor": None}
+        sidx = np.arange(0, F, max(1, F // 256))[:256]
+        t_sidx = torch.from_numpy(sidx).to(dev)
+        spcm = np.ascontiguousarray(pcm_all[:, t_sidx].permute(1, 0, 2, 3).cpu().numpy().reshape(len(sidx) * T, 960, 2))
+        cpu = (lambda: cpu_baseline_celt(spcm, cfgvals, fps=T))
+        if not a.no_parity and rank == 0:
+            if _refdrv() is not None:
+                epk, eln, erg = ref_encode(spcm, cfgvals, T, sample_threads)
+                last = np.arange(len(sidx)) * T + (T - 1)
+                check_packets("celt_streams", out[t_sidx].cpu().numpy(), lens[t_sidx].cpu().numpy(),
+                              _r[t_sidx].cpu().numpy().view(np.uint32), epk[last], eln[last], erg[last])
+                parity = {"checked": len(sidx), "note": "frame %d (the last timed one) of a strided sample of streams: packet bytes + "
+                          "final range vs opus_encode() of oracle/_ref run over the same %d-frame streams" % (T - 1, T)}
+            else:
+                parity["note"] = "oracle/_ref did not travel"
     else:
         mixed = a.workload == "mixed"
         # mixed = BASELINE configs[4]: per GPU a shard of 131 072 units, 7/8 CELT frames (config #3's kind) and 1/8 SILK
@@ -445,12 +682,15 @@ def main():
         steps = a.steps or (5 if mixed else 10)
         warm = a.warmup if a.warmup is not None else 2
         cfg = ca.default_config(2, 96000)          # opus_demo restricted-lowdelay 48000 2 96000, complexity 10, VBR
+        cfgvals = (2, 96000, 1, 0, 10, 16, 0, 1500)
         rng = np.random.default_rng((5 if mixed else 3) + rank)      # seed 3 (config #3) / 5 (config #5), uniform int16 in [-8192, 8191]
         host = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
         pcm = torch.from_numpy(host).to(dev)
         out = lens = None
         if mixed:
-            _rec, s_bi, s_ni, s_st = silk_records(NS, rank, dev)
+            srec, srec_desc = silk_records(NS, "nsq", rank)
+            s_bi, s_ni, s_st0 = (torch.from_numpy(srec[k]).to(dev) for k in ("burg_in", "nsq_in", "nsq_state_in"))
+            s_st = s_st0.clone()
             s_bo = torch.empty((NS, 72), dtype=torch.uint8, device=dev)
             s_pulses = torch.empty((NS, 320), dtype=torch.int8, device=dev)
             silk_stream = torch.cuda.Stream(device=dev)
@@ -472,8 +712,6 @@ def main():
                 silk_join()
         torch.cuda.synchronize()
         from concentus_amd.sharding import gather_packets
-        import ctypes
-        L = ca.lib.load()
         L.opusgpu_kernel_timing_enable(1)          # HIP events around each kernel, on the launch stream
         barrier()
         t0 = time.perf_counter()
@@ -484,7 +722,7 @@ def main():
                 with torch.cuda.stream(s_):
                     ca.encode_independent(pcm, cfg)
             torch.cuda.synchronize()
-            L.opusgpu_kernel_timing_read((ctypes.c_double * 8)(), (ctypes.c_int * 8)(), 8)
+            L.opusgpu_kernel_timing_read((C.c_double * 8)(), (C.c_int * 8)(), 8)
             barrier()
             t0 = time.perf_counter()
         pending = []
@@ -506,64 +744,56 @@ def main():
                 if side:
                     torch.cuda.current_stream().wait_stream(side[k % len(side)])
                 for pg in pending:
-                    gathered = pg.wait()
+                    pg.wait()
                 pending = [gather_packets(out, lens, _r, world, sizes=[F] * world, trim=True, async_op=True)]
                 if mixed:
                     pending.append(gather_packets(s_pulses, s_bo, s_bo[:, :4], world, sizes=[NS] * world, async_op=True))
         for pg in pending:
-            gathered = pg.wait()
+            pg.wait()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
-        KNAMES = ["celt_front_kernel", "celt_back_kernel", "celt_back_lane_kernel", "celt_dc_reject_kernel",
-                  "celt_front1_kernel",
-                  "celt_transient_kernel" if os.environ.get("OPUSGPU_TRANSIENT_LANE") else "celt_transient_tile_kernel",
-                  "celt_front2_kernel"]
-        NK = len(KNAMES)
-        ksum = (ctypes.c_double * NK)()
-        kcnt = (ctypes.c_int * NK)()
-        ca.lib.check(L.opusgpu_kernel_timing_read(ksum, kcnt, NK), "opusgpu_kernel_timing_read")
-        L.opusgpu_kernel_timing_enable(0)
-        lens_h = lens.cpu().numpy()
-        assert (lens_h > 0).all(), "encoder reported an error"
-        mean_len = float(lens_h.mean())
-        # algorithmic bytes per frame and kernel: what each kernel must read and write once
-        MID_BYTES = int(ca.encoder.MID_RECORD_BYTES)
-        IN_BYTES = 2 * 1080 * 4
-        per_frame = {
-            "celt_front_kernel": PCM_BYTES + MID_BYTES,
-            "celt_dc_reject_kernel": PCM_BYTES + PCM_BYTES,
-            "celt_front1_kernel": PCM_BYTES + IN_BYTES + (MID_BYTES - PCM_BYTES),
-            "celt_transient_kernel": IN_BYTES + 8,
-            "celt_transient_tile_kernel": 2 * IN_BYTES + 8,       # two passes over the time signal by construction
-            "celt_front2_kernel": IN_BYTES + MID_BYTES,
-            "celt_back_kernel": MID_BYTES + mean_len + 8,
-            "celt_back_lane_kernel": MID_BYTES + mean_len + 8,
-        }
-        kern = []
-        for i, nm in enumerate(KNAMES):
-            if kcnt[i]:
-                avg = ksum[i] / kcnt[i]
-                fpl = F * steps / kcnt[i]
-                kern.append({"kernel": nm, "avg_launch_ms": round(avg, 5), "frames_per_launch": int(fpl),
-                             "algorithmic_bytes_per_launch": int(fpl * per_frame[nm]),
-                             "achieved": round(fpl * per_frame[nm] / (avg * 1e-3) / 1e9, 2), "traffic": traffic_db.get(nm)})
-        kern.sort(key=lambda k: -k["avg_launch_ms"])
+        kern, mean_len = celt_kernel_table(ca, L, F, steps, lens, traffic_db)
         dom = kern[0]
-        kname, kbytes, kms = dom["kernel"], dom["algorithmic_bytes_per_launch"], dom["avg_launch_ms"]
+        kname, kms = dom["kernel"], dom["avg_launch_ms"]
+        unit_bytes = PCM_BYTES + mean_len + 8      # PCM in + packet + (len, rng) out
+        kbytes = int(dom["frames_per_launch"] * unit_bytes)
+        limiter = "latency / VALU issue (lane per frame)"
         metric = "48kHz stereo 20ms CELT frames encoded/sec"
-        workload = ("configs[2]: %d independent 48 kHz stereo 20 ms frames per GPU, full CELT encode "
-                    "(MDCT + PVQ + range enc) 96 kb/s VBR complexity 10, packets bit-exact vs FIXED_POINT "
+        workload = ("configs[2]: %d independent 48 kHz stereo 20 ms frames per GPU (each the first frame of its own stream), full "
+                    "CELT encode (MDCT + PVQ + range enc) 96 kb/s VBR complexity 10, packets bit-exact vs FIXED_POINT "
                     "opus_encode(); mean packet %.1f B" % (F, mean_len))
         dtype = "int16/int32 fixed-point"
         extra = {"mean_packet_bytes": round(mean_len, 2), "frames_per_launch": dom["frames_per_launch"],
-                 "other_kernels": kern[1:], "realtime_factor": None}
-        cpu = (lambda: cpu_baseline_celt(host[:4096], (2, 96000, 1, 0, 10, 16, 0, 1500)))
+                 "kernels": kern, "realtime_factor": None}
+        cpu = (lambda: cpu_baseline_celt(host[:4096], cfgvals))
+        if not a.no_parity and rank == 0:
+            if _refdrv() is not None:
+                idx = np.arange(0, F, max(1, F // 2048))[:2048]
+                t_idx = torch.from_numpy(idx).to(dev)
+                epk, eln, erg = ref_encode(host[idx], cfgvals, 1, sample_threads)
+                check_packets(a.workload, out[t_idx].cpu().numpy(), lens[t_idx].cpu().numpy(),
+                              _r[t_idx].cpu().numpy().view(np.uint32), epk, eln, erg)
+                parity = {"checked": len(idx), "note": "strided sample of the last timed step: packet bytes + final range vs "
+                          "opus_encode() of oracle/_ref"}
+            else:
+                parity["note"] = "oracle/_ref did not travel"
         if mixed:
+            if not a.no_parity and rank == 0 and "nsq_out" in srec:
+                s_st.copy_(s_st0)
+                ca.silk_NSQ(s_ni, s_st, s_pulses)
+                torch.cuda.synchronize()
+                ok = (np.array_equal(s_bo.cpu().numpy(), srec["burg_out"])
+                      and np.array_equal(s_pulses.cpu().numpy().view(np.uint8), srec["nsq_out"])
+                      and np.array_equal(s_st.cpu().numpy(), srec["nsq_state_out"]))
+                if not ok:
+                    raise SystemExit("PARITY FAILURE (mixed: SILK records)")
+                parity["checked"] += NS
+                parity["note"] += "; all %d SILK records vs the reference's captured outputs" % NS
             metric = "mixed CELT/SILK 20ms frames processed/sec (configs[4]: 7/8 CELT encode, 1/8 SILK burg+NSQ records)"
             workload = ("configs[4]: %d units per GPU = %d independent 48 kHz stereo CELT frames (full encode, 96 kb/s VBR "
-                        "complexity 10, mean packet %.1f B) + %d SILK function-boundary records (silk_burg_modified + silk_NSQ), "
-                        "bit-exact vs FIXED_POINT; the SILK kernels run on a side stream" % (FT, F, mean_len, NS))
+                        "complexity 10, mean packet %.1f B) + %s (silk_burg_modified + silk_NSQ), "
+                        "bit-exact vs FIXED_POINT; the SILK kernels run on a side stream" % (FT, F, mean_len, srec_desc))
             extra["celt_frames_per_gpu"], extra["silk_records_per_gpu"] = F, NS
             extra.pop("realtime_factor", None)
             F = FT
@@ -578,6 +808,20 @@ def main():
         value = F * world * steps / elapsed
         if "realtime_factor" in extra:
             extra["realtime_factor"] = round(value * 0.02, 1)        # 20 ms of audio per frame
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic_db.get(kname),
+                "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 5), "limiter": limiter}
+        if unit_bytes is not None:
+            roof["algorithmic_bytes_per_unit"] = round(unit_bytes, 1)
+            roof["pipeline_achieved"] = round(value / world * unit_bytes / 1e9, 2)     # whole step, per GPU
+            roof["pipeline_frac"] = round(value / world * unit_bytes / 1e9 / HBM_PEAK_GBS, 6)
+        pm = pmc_db.get(kname)
+        if pm and pm.get("SQ_INSTS_VALU"):
+            # VALU-issue roofline of the dominant kernel: wave-instructions x 4 cycles each / (SIMDs x cycles of the launch);
+            # instruction count from the committed PMC pass (profiles/pmc.json, same batch size), duration measured live
+            scale = (extra.get("frames_per_launch") or pm.get("units_per_launch") or 1) / float(pm.get("units_per_launch") or 1)
+            roof["valu_issue_frac"] = round(pm["SQ_INSTS_VALU"] * scale * 4.0 / (SIMDS * CLOCK_HZ * kms * 1e-3), 4)
+            roof["valu_wave_insts_per_launch"] = int(pm["SQ_INSTS_VALU"] * scale)
         out_line = {
             "metric": metric,
             "value": round(value, 1),
@@ -593,13 +837,15 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": F, "channels": 2,
                        "sharding": "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0"},
-            "roofline": dict({"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                              "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic_db.get(kname),
-                              "algorithmic_bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 5)}, **extra),
+            "parity_checked": parity["checked"],
+            "parity_note": parity["note"],
+            "roofline": dict(roof, **extra),
         }
         if not a.no_cpu_baseline:
             try:
                 out_line["cpu_baseline"] = cpu()
+                if out_line["cpu_baseline"].get("value"):
+                    out_line["vs_cpu_baseline"] = round(value / out_line["cpu_baseline"]["value"], 2)
             except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
                 out_line["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference",
                                             "sample": "failed: %r" % (e,)}
@@ -607,7 +853,48 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def celt_kernel_table(ca, L, F, steps, lens, traffic_db):
+    """Per-kernel averages of the CELT encode pipeline over the timed region (HIP events on the launch stream,
+    opusgpu_kernel_timing_*), sorted by time; and the mean packet length of the last step."""
+    KNAMES = ["celt_front_kernel", "celt_back_kernel", "celt_back_lane_kernel", "celt_dc_reject_kernel",
+              "celt_front1_kernel",
+              "celt_transient_kernel" if os.environ.get("OPUSGPU_TRANSIENT_LANE") else "celt_transient_tile_kernel",
+              "celt_front2_kernel"]
+    NK = len(KNAMES)
+    ksum = (C.c_double * NK)()
+    kcnt = (C.c_int * NK)()
+    ca.lib.check(L.opusgpu_kernel_timing_read(ksum, kcnt, NK), "opusgpu_kernel_timing_read")
+    L.opusgpu_kernel_timing_enable(0)
+    lens_h = lens.cpu().numpy()
+    assert (lens_h > 0).all(), "encoder reported an error"
+    mean_len = float(lens_h.mean())
+    # hand-off bytes per frame and kernel (DESIGN.md section 4): what each kernel must read and write once
+    MID_BYTES = int(ca.encoder.MID_RECORD_BYTES)
+    IN_BYTES = 2 * 1080 * 4
+    per_frame = {
+        "celt_front_kernel": PCM_BYTES + MID_BYTES,
+        "celt_dc_reject_kernel": PCM_BYTES + PCM_BYTES,
+        "celt_front1_kernel": PCM_BYTES + IN_BYTES + (MID_BYTES - PCM_BYTES),
+        "celt_transient_kernel": IN_BYTES + 8,
+        "celt_transient_tile_kernel": 2 * IN_BYTES + 8,       # two passes over the time signal by construction
+        "celt_front2_kernel": IN_BYTES + MID_BYTES,
+        "celt_back_kernel": MID_BYTES + mean_len + 8,
+        "celt_back_lane_kernel": MID_BYTES + mean_len + 8,
+    }
+    kern = []
+    for i, nm in enumerate(KNAMES):
+        if kcnt[i]:
+            avg = ksum[i] / kcnt[i]
+            fpl = F * steps / kcnt[i]
+            kern.append({"kernel": nm, "avg_launch_ms": round(avg, 5), "frames_per_launch": int(fpl),
+                         "handoff_bytes_per_launch": int(fpl * per_frame[nm]),
+                         "handoff_GBps": round(fpl * per_frame[nm] / (avg * 1e-3) / 1e9, 2), "traffic": traffic_db.get(nm)})
+    kern.sort(key=lambda k: -k["avg_launch_ms"])
+    return kern, mean_len
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -31,7 +31,15 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_decode_lane_kernel(opusgpu
     DecWork F;
     F.lds_pvq32 = g_lds_pvq32 + slot;
     F.lds_pvq16 = g_lds_pvq16 + slot;
-    DecResult r = celt_decode_front(F, states + k, packets + (size_t)k * packet_stride, len[k]);
+    const int ln = len[k];
+    if (ln > packet_stride) {
+        // a length past this stream's row would read the next stream's packet (or, for the last stream, past the slab)
+        states[k].mid_valid = 0;
+        ret[k] = OPUSGPU_BAD_ARG;
+        rng[k] = 0;
+        return;
+    }
+    DecResult r = celt_decode_front(F, states + k, packets + (size_t)k * packet_stride, ln);
     ret[k] = r.samples;
     rng[k] = r.final_range;
 }

@@ -119,7 +119,7 @@ static int config_ok(const opusgpu_celt_config *c)
         if ((cbr < maxb ? cbr : maxb) * 400 < 32000) return OPUSGPU_UNIMPLEMENTED;
     }
     // PLC-frame corner (opus_encoder.c:1056-1084) and too-small buffers
-    if (c->max_data_bytes < 3 || c->bitrate > 510000) return OPUSGPU_UNIMPLEMENTED;
+    if (c->max_data_bytes < 3 || c->bitrate > 1276 * 400) return OPUSGPU_UNIMPLEMENTED;     // 510 400 = OPUS_BITRATE_MAX into a 1276-byte buffer
     return OPUSGPU_OK;
 }
 
@@ -162,15 +162,15 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
     FrameMid *mid = (FrameMid *)d_workspace;
     i32 *in_ws = (i32 *)((char *)d_workspace + chunk * sizeof(FrameMid));
     hipStream_t s = (hipStream_t)stream;
+    // default: one lane per frame for the serial back phase; OPUSGPU_BACK_WAVE=1 selects the one-wave-per-frame kernel
+    // (kept for the stage-stamp diagnostics and as a cross-check); OPUSGPU_FRONT_FUSED=1: the whole front phase in one
+    // wave-per-frame kernel (cross-check / diagnostics). Read once per call, not per chunk.
+    const bool lane_back = getenv("OPUSGPU_BACK_WAVE") == nullptr;
+    const bool fused_front = getenv("OPUSGPU_FRONT_FUSED") != nullptr;
     for (size_t first = 0; first < (size_t)n_frames; first += chunk) {
         int n = (int)(((size_t)n_frames - first) < chunk ? ((size_t)n_frames - first) : chunk);
         int g1 = n < cus * 7 ? n : cus * 7;          // 22.8 KB LDS per workgroup -> 7 resident per CU (measured best)
         int g2 = n < cus * 16 ? n : cus * 16;        // ~9.6 KB LDS per workgroup -> 16 resident per CU
-        // default: one lane per frame for the serial back phase; OPUSGPU_BACK_WAVE=1 selects the
-        // one-wave-per-frame kernel (kept for the stage-stamp diagnostics and as a cross-check)
-        const bool lane_back = getenv("OPUSGPU_BACK_WAVE") == nullptr;
-        // OPUSGPU_FRONT_FUSED=1: the whole front phase in one wave-per-frame kernel (cross-check / diagnostics)
-        const bool fused_front = getenv("OPUSGPU_FRONT_FUSED") != nullptr;
         int slot;
         if (fused_front) {
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT, s);

@@ -18,6 +18,7 @@ struct OpusGpuEncoder {
     uint32_t *d_rng;
     size_t ws_bytes;
     uint32_t final_range;
+    int bitrate_is_max;            // OPUS_SET_BITRATE(OPUS_BITRATE_MAX): resolved per opus_encode() call (src/opus_encoder.c:512-521)
     hipStream_t stream;
 };
 
@@ -85,8 +86,9 @@ extern "C" int opusgpu_encoder_ctl(OpusGpuEncoder *st, int request, ...)
     switch (request) {
     case 4002: {                                                                  // OPUS_SET_BITRATE (:2066-2083)
         int32_t v = va_arg(ap, int32_t);
+        st->bitrate_is_max = v == -1;                                             // OPUS_BITRATE_MAX
         if (v == -1000) v = 3000 + 48000 * st->cfg.channels;                      // OPUS_AUTO
-        else if (v == -1) v = 510000;                                             // OPUS_BITRATE_MAX
+        else if (v == -1) v = 1276 * 400;                                         // placeholder; see opusgpu_encode
         else if (v <= 0) { ret = OPUSGPU_BAD_ARG; break; }
         else if (v <= 500) v = 500;
         else if (v > 300000 * st->cfg.channels) v = 300000 * st->cfg.channels;
@@ -140,6 +142,9 @@ extern "C" int32_t opusgpu_encode(OpusGpuEncoder *st, const int16_t *pcm, int fr
     if (frame_size != 960) return frame_size == 120 || frame_size == 240 || frame_size == 480 || frame_size == 1920 || frame_size == 2880
                                       ? OPUSGPU_UNIMPLEMENTED : OPUSGPU_BAD_ARG;   // 20 ms @ 48 kHz only
     st->cfg.max_data_bytes = max_data_bytes;
+    // user_bitrate_to_bitrate (src/opus_encoder.c:512-521, called at :1050 with max_data_bytes = IMIN(1276, out_data_bytes)):
+    // OPUS_BITRATE_MAX means "whatever fills this call's buffer" = max_data_bytes * 8 * Fs / frame_size
+    if (st->bitrate_is_max) st->cfg.bitrate = (max_data_bytes < 1276 ? max_data_bytes : 1276) * 8 * (48000 / 960);
     if (hipMemcpyAsync(st->d_pcm, pcm, 960 * 2 * sizeof(int16_t), hipMemcpyHostToDevice, st->stream) != hipSuccess) return OPUSGPU_INTERNAL_ERROR;
     int rc = opusgpu_encode_batch(&st->cfg, st->d_state, st->d_pcm, st->d_out, OUT_STRIDE, st->d_len, st->d_rng, 1, st->d_ws,
                                   st->ws_bytes, st->stream);

@@ -11,3 +11,5 @@ extern "C" int opusgpu_timing_begin(int kernel, hipStream_t s);
 extern "C" void opusgpu_timing_end(int slot, hipStream_t s);
 // frames (streams) per wavefront of the lane-per-frame kernels: 64, 32 or 16 (OPUSGPU_LANE_FRAMES)
 extern "C" int opusgpu_lane_frames(void);
+// device counter of SILK records whose header failed the bounds checks (silk_validate.h); nullptr = allocation failed
+extern "C" int *opusgpu_bad_record_counter(void);

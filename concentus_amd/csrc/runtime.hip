@@ -92,3 +92,37 @@ extern "C" int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_k
     g_launches.clear();
     return rc;
 }
+
+// ---- bad-record counter of the SILK record kernels (silk_validate.h) ----
+// One counter per device, allocated on first use and never freed (4 bytes for the life of the process).
+namespace {
+std::mutex g_bad_m;
+int *g_bad[64] = {};
+}
+
+extern "C" int *opusgpu_bad_record_counter(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_bad_m);
+    if (!g_bad[dev]) {
+        int *p = nullptr;
+        if (hipMalloc((void **)&p, sizeof(int)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, sizeof(int)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        g_bad[dev] = p;
+    }
+    return g_bad[dev];
+}
+
+// Records rejected by the SILK batch kernels of the current device since the last call (waits for `stream`).
+extern "C" int opusgpu_silk_bad_records(void *stream)
+{
+    int *p = opusgpu_bad_record_counter();
+    if (!p) return OPUSGPU_ALLOC_FAIL;
+    int n = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(&n, p, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemsetAsync(p, 0, sizeof(int), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return OPUSGPU_INTERNAL_ERROR;
+    return n;
+}

@@ -22,6 +22,7 @@
 #include "silk_math.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
+#include "silk_validate.h"
 
 namespace ca {
 
@@ -38,12 +39,21 @@ struct BurgX {
     __device__ __forceinline__ BurgX operator+(int o) const { BurgX r; r.p = p + o * 64; return r; }
 };
 
-__global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__restrict__ recs, opusgpu_burg_out *__restrict__ outs, int n_rec)
+__global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__restrict__ recs, opusgpu_burg_out *__restrict__ outs, int n_rec,
+                                                       int *__restrict__ bad_records)
 {
     __shared__ i16 xs[OPUSGPU_SILK_BURG_MAX_X * 64];
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_burg_in &in = recs[r];
+    if (!burg_record_ok(in)) {                                 // would index xs[] / the order-16 arrays out of bounds
+        opusgpu_burg_out &o = outs[r];
+        o.res_nrg = 0;
+        o.res_nrg_Q = (i32)0x80000000;
+        for (int k = 0; k < 16; k++) o.A_Q16[k] = 0;
+        atomicAdd(bad_records, 1);
+        return;
+    }
     {
         static_assert(sizeof(opusgpu_burg_in) % 16 == 0 && OPUSGPU_SILK_BURG_MAX_X % 8 == 0, "16-byte loads of x");
         const int nx = in.subfr_length * in.nb_subfr;
@@ -231,12 +241,18 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
 struct NsqScratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
 
 __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__restrict__ recs, opusgpu_nsq_state *__restrict__ states,
-                                                      opusgpu_nsq_out *__restrict__ outs, NsqScratch *__restrict__ ws, int n_rec)
+                                                      opusgpu_nsq_out *__restrict__ outs, NsqScratch *__restrict__ ws, int n_rec,
+                                                      int *__restrict__ bad_records)
 {
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_nsq_in &in = recs[r];
     opusgpu_nsq_state &NSQ = states[r];
+    if (!nsq_record_ok(in, NSQ.lagPrev)) {                     // state untouched, no pulses
+        for (int k = 0; k < OPUSGPU_SILK_MAX_FRAME; k++) outs[r].pulses[k] = 0;
+        atomicAdd(bad_records, 1);
+        return;
+    }
     i32 *sLTP_Q15 = ws[r].sLTP_Q15;
     i16 *sLTP = ws[r].sLTP;
     const int nb_subfr = in.nb_subfr, subfr_length = in.subfr_length, frame_length = in.frame_length;
@@ -562,7 +578,9 @@ extern "C" int opusgpu_silk_burg_modified_batch(const opusgpu_burg_in *d_in, opu
     if (n < 0) return OPUSGPU_BAD_ARG;
     if (n == 0) return OPUSGPU_OK;
     if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
-    hipLaunchKernelGGL(silk_burg_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n);
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_burg_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
     return opusgpu_check_launch();
 }
 
@@ -575,8 +593,10 @@ extern "C" int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_st
     if (n == 0) return OPUSGPU_OK;
     if (!d_in || !d_state || !d_out || !d_workspace) return OPUSGPU_BAD_ARG;
     if (workspace_bytes < (size_t)n * sizeof(NsqScratch)) return OPUSGPU_BUFFER_TOO_SMALL;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
     hipLaunchKernelGGL(silk_nsq_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
-                       (NsqScratch *)d_workspace, n);
+                       (NsqScratch *)d_workspace, n, bad);
     return opusgpu_check_launch();
 }
 

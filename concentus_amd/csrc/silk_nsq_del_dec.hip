@@ -22,6 +22,7 @@
 #include "silk_math.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
+#include "silk_validate.h"
 
 namespace ca {
 
@@ -50,7 +51,8 @@ CA_DEV i16 sat16(i32 v) { return (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 
 }  // namespace dd
 
 __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_dd_in *__restrict__ recs, opusgpu_nsq_state *states,
-                                                              opusgpu_nsq_dd_out *__restrict__ outs, dd::Scratch *ws, int n_rec)
+                                                              opusgpu_nsq_dd_out *__restrict__ outs, dd::Scratch *ws, int n_rec,
+                                                              int *__restrict__ bad_records)
 {
     using namespace dd;
     __shared__ i32 ring[ROWS * 64];
@@ -60,6 +62,14 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
     const opusgpu_nsq_in &in = recs[r].base;
     const int nst = recs[r].nStatesDelayedDecision, warping_Q16 = recs[r].warping_Q16;
     opusgpu_nsq_state &NSQ = states[r];
+    if (!nsq_dd_record_ok(recs[r], NSQ.lagPrev)) {            // the same verdict in all four lanes of the quad: they leave together
+        if (k == 0) {
+            for (int e = 0; e < OPUSGPU_SILK_MAX_FRAME; e++) outs[r].pulses[e] = 0;
+            outs[r].Seed = in.Seed;
+            atomicAdd(bad_records, 1);
+        }
+        return;
+    }
     i32 *sLTP_Q15 = ws[r].sLTP_Q15;
     i16 *sLTP = ws[r].sLTP;
     const int nb_subfr = in.nb_subfr, L = in.subfr_length, frame_length = in.frame_length;
@@ -439,7 +449,9 @@ extern "C" int opusgpu_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *d_in, opu
     if (n == 0) return OPUSGPU_OK;
     if (!d_in || !d_state || !d_out || !d_workspace) return OPUSGPU_BAD_ARG;
     if (workspace_bytes < (size_t)n * sizeof(dd::Scratch)) return OPUSGPU_BUFFER_TOO_SMALL;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
     hipLaunchKernelGGL(silk_nsq_del_dec_kernel, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
-                       (dd::Scratch *)d_workspace, n);
+                       (dd::Scratch *)d_workspace, n, bad);
     return opusgpu_check_launch();
 }

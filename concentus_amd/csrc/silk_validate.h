@@ -1,0 +1,54 @@
+// silk_validate.h -- bounds checks of the device-resident SILK function-boundary records (include/opusgpu_silk.h).
+//
+// The batched SILK kernels index LDS, private arrays and the record's own arrays with header fields that arrive in
+// device memory (nb_subfr, subfr_length, D, pitchL, ltp_mem_length ...): the host cannot look at them without a
+// round trip, so every lane checks ITS record before touching anything, skips a record that would index out of bounds
+// (outputs zeroed, NSQ state untouched, Burg res_nrg_Q = INT32_MIN) and counts it in the library's bad-record counter,
+// which opusgpu_silk_bad_records() returns and clears. The limits are the reference's own (silk/define.h:
+// MAX_NB_SUBFR 4, MAX_SUB_FRAME_LENGTH 80, MAX_FRAME_LENGTH 320, LTP_MEM_LENGTH_MS 20 -> 320, MAX_LPC_ORDER 16,
+// MAX_SHAPE_LPC_ORDER 16, LTP_ORDER 5, MAX_DEL_DEC_STATES 4; burg_modified_FIX.c:36 MAX_FRAME_SIZE 384; the
+// silk_assert( start_idx > 0 ) of NSQ.c:141 / NSQ_del_dec.c:236).
+#pragma once
+#include "../../include/opusgpu_silk.h"
+
+namespace ca {
+
+__device__ __forceinline__ bool burg_record_ok(const opusgpu_burg_in &in)
+{
+    const int L = in.subfr_length, n = in.nb_subfr, D = in.D;
+    return n >= 1 && n <= 4 && D >= 1 && D <= OPUSGPU_SILK_MAX_ORDER && L > D && L <= OPUSGPU_SILK_BURG_MAX_X &&
+           L * n <= OPUSGPU_SILK_BURG_MAX_X;
+}
+
+__device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
+{
+    const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;
+    if (!(n >= 1 && n <= 4 && L >= 1 && L <= 80 && in.frame_length == n * L && in.frame_length <= OPUSGPU_SILK_MAX_FRAME)) return false;
+    if (!(ltp >= 1 && ltp <= OPUSGPU_SILK_MAX_FRAME && po >= 2 && po <= 16 && so >= 2 && so <= 16 && !(so & 1))) return false;
+    if (in.signalType < 0 || in.signalType > 2 || (unsigned)in.quantOffsetType > 1u) return false;
+    if (lagPrev < 0 || lagPrev > ltp) return false;
+    if (in.signalType == 2)
+        for (int k = 0; k < n; k++) {
+            const int lag = in.pitchL[k];
+            // re-whitening starts at ltp_mem_length - lag - predictLPCOrder - LTP_ORDER/2 (> 0 in the reference); the LTP taps
+            // reach lag + LTP_ORDER/2 samples back
+            if (lag < 3 || ltp - lag - po - 2 <= 0) return false;
+        }
+    return true;
+}
+
+__device__ __forceinline__ bool nsq_dd_record_ok(const opusgpu_nsq_dd_in &in, int lagPrev)
+{
+    if (!nsq_record_ok(in.base, lagPrev)) return false;
+    if (in.nStatesDelayedDecision < 1 || in.nStatesDelayedDecision > OPUSGPU_SILK_MAX_DEL_DEC_STATES) return false;
+    // decisionDelay = min(DECISION_DELAY, subfr_length, lag - LTP_ORDER/2 - 1) must stay positive (NSQ_del_dec.c:157-170)
+    if (in.base.signalType == 2) {
+        for (int k = 0; k < in.base.nb_subfr; k++)
+            if (in.base.pitchL[k] - 3 < 1) return false;
+    } else if (lagPrev > 0 && lagPrev - 3 < 1) {
+        return false;
+    }
+    return true;
+}
+
+}  // namespace ca

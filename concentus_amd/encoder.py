@@ -114,6 +114,7 @@ class OpusEncoderBatch:
         _lib.check(L.opusgpu_celt_state_init(self._states.data_ptr(), n_streams, _lib.current_stream_handle()),
                    "opusgpu_celt_state_init")
         self.final_range = None
+        self._bitrate_is_max = False
 
     def ctl(self, request, value=None):
         """opus_encoder_ctl(enc, request, value) for the requests opus_demo issues."""
@@ -123,7 +124,10 @@ class OpusEncoderBatch:
                 value = 60 * 50 + 48000 * c.channels
             if value != OPUS_BITRATE_MAX and value <= 0:
                 raise _lib.OpusGpuError(-1, "OPUS_SET_BITRATE")
-            c.bitrate = min(value, 300000 * c.channels) if value != OPUS_BITRATE_MAX else 510000
+            # OPUS_BITRATE_MAX is resolved per encode() call from that call's buffer size (user_bitrate_to_bitrate,
+            # src/opus_encoder.c:512-521)
+            self._bitrate_is_max = value == OPUS_BITRATE_MAX
+            c.bitrate = max(500, min(value, 300000 * c.channels)) if value != OPUS_BITRATE_MAX else 1276 * 400
         elif request == OPUS_SET_VBR_REQUEST:
             c.vbr = int(bool(value))
         elif request == OPUS_SET_VBR_CONSTRAINT_REQUEST:
@@ -171,6 +175,8 @@ class OpusEncoderBatch:
         if pcm.shape[0] != self.n:
             raise ValueError("one frame per stream expected")
         self.cfg.max_data_bytes = max_data_bytes
+        if self._bitrate_is_max:
+            self.cfg.bitrate = min(1276, max_data_bytes) * 8 * (48000 // FRAME_SIZE)
         out, lens, rng = _encode(self.cfg, self._states.data_ptr(), pcm)
         self.final_range = rng
         return out, lens

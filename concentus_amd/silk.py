@@ -58,6 +58,24 @@ def silk_burg_modified(burg_in, burg_out=None):
 _WS = {}
 
 
+def _scratch(device, need, op):
+    """Re-whitening scratch of the NSQ kernels, per (device, stream, operator): calls issued on different HIP streams
+    (bench.py's mixed workload runs SILK on a side stream) must not share it, and neither may the two quantisers."""
+    import torch
+    key = (device, _lib.current_stream_handle().value, op)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def bad_records():
+    """Records the SILK batch kernels skipped on the current device since the last call because their header failed
+    the device-side bounds checks (include/opusgpu_silk.h); waits for the current stream."""
+    return _lib.check(_lib.load().opusgpu_silk_bad_records(_lib.current_stream_handle()), "opusgpu_silk_bad_records")
+
+
 def silk_NSQ(nsq_in, nsq_state, pulses=None):
     """nsq_in uint8 [N][1640], nsq_state uint8 [N][4380] (updated in place) -> pulses int8 [N][320]."""
     import torch
@@ -66,12 +84,11 @@ def silk_NSQ(nsq_in, nsq_state, pulses=None):
     n = nsq_in.shape[0]
     if pulses is None:
         pulses = torch.zeros((n, 320), dtype=torch.int8, device=nsq_in.device)
+    if not (pulses.is_cuda and pulses.dtype in (torch.int8, torch.uint8) and pulses.is_contiguous() and tuple(pulses.shape) == (n, 320)):
+        raise ValueError("pulses must be a contiguous int8 CUDA tensor [records][320]")
     L = _lib.load()
     need = L.opusgpu_silk_nsq_workspace_bytes(n)
-    ws = _WS.get(nsq_in.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=nsq_in.device)
-        _WS[nsq_in.device] = ws
+    ws = _scratch(nsq_in.device, need, "nsq")
     rc = L.opusgpu_silk_nsq_batch(nsq_in.data_ptr(), nsq_state.data_ptr(), pulses.data_ptr(), n, ws.data_ptr(), ws.numel(),
                                   _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_nsq_batch")
@@ -99,10 +116,7 @@ def silk_NSQ_del_dec(dd_in, nsq_state, dd_out=None):
     _check(dd_out, SIZES["nsq_dd_out"], "dd_out")
     L = _lib.load()
     need = L.opusgpu_silk_nsq_del_dec_workspace_bytes(n)
-    ws = _WS.get(dd_in.device)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty((max(need, 1),), dtype=torch.uint8, device=dd_in.device)
-        _WS[dd_in.device] = ws
+    ws = _scratch(dd_in.device, need, "nsq_del_dec")
     rc = L.opusgpu_silk_nsq_del_dec_batch(dd_in.data_ptr(), nsq_state.data_ptr(), dd_out.data_ptr(), n, ws.data_ptr(), ws.numel(),
                                           _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_nsq_del_dec_batch")

@@ -74,6 +74,14 @@ size_t opusgpu_silk_nsq_workspace_bytes(int n);
 int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, int n,
                            void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* The header fields of the records arrive in device memory, so they are bounds-checked on the device, per record
+ * (concentus_amd/csrc/silk_validate.h: nb_subfr <= 4, subfr_length <= 80, orders <= 16, pitch lags inside the LTP
+ * memory, 1..4 delayed-decision states ...). A record that fails is SKIPPED -- Burg: A_Q16 = 0, res_nrg = 0,
+ * res_nrg_Q = INT32_MIN; NSQ / NSQ_del_dec: pulses zeroed, state left untouched -- and counted.
+ * opusgpu_silk_bad_records() waits for hip_stream and returns the number of records skipped on the current device
+ * since the previous call (>= 0), or a negative OPUSGPU_* code; it resets the counter. */
+int opusgpu_silk_bad_records(void *hip_stream);
+
 /* Per-call hook with the reference's own signature (host pointers, one call = one record, synchronous): what the macro
  * silk_burg_modified (opus-fix/silk/SigProc_FIX.h:601-602) would be pointed at. Plumbing / parity only. Errors are
  * reported through opusgpu_get_last_error(). */

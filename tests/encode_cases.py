@@ -36,3 +36,15 @@ def assert_packets_equal(got_pk, got_len, got_rng, exp_pk, exp_len, exp_rng, wha
         if not np.array_equal(got_pk[n, :L], exp_pk[n, :L]):
             d = np.nonzero(got_pk[n, :L] != exp_pk[n, :L])[0]
             raise AssertionError("%s: frame %d differs first at byte %d of %d" % (what, n, d[0], L))
+
+
+def assert_packets_equal_fast(got_pk, got_len, got_rng, exp_pk, exp_len, exp_rng, what=""):
+    """The same criterion for large batches: vectorised, the per-frame loop only runs to report a mismatch."""
+    got_len = np.asarray(got_len)
+    assert np.array_equal(got_len, exp_len), "%s: packet lengths differ at %s" % (what, np.nonzero(got_len != exp_len)[0][:8])
+    assert np.array_equal(np.asarray(got_rng).astype(np.uint32), exp_rng), "%s: final range differs at %s" % (
+        what, np.nonzero(np.asarray(got_rng).astype(np.uint32) != exp_rng)[0][:8])
+    w = int(exp_len.max())
+    mask = np.arange(w)[None, :] < np.asarray(exp_len)[:, None]
+    bad = np.nonzero(((got_pk[:, :w] != exp_pk[:, :w]) & mask).any(1))[0]
+    assert bad.size == 0, "%s: %d of %d packets differ, first %s" % (what, bad.size, len(exp_len), bad[:8])

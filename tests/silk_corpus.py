@@ -1,0 +1,201 @@
+"""Distinct SILK function-boundary records at BASELINE config #4's size -- TEST / BENCH INPUT GENERATION.
+
+SURVEY.md 8d defines config #4's input as "65 536 function-boundary records captured from the oracle encoding 16 kHz
+mono voice at 32 kb/s, VOIP". The 80 committed golden records cover parity on real captures; this module produces the
+full-size corpus the same way -- the UNMODIFIED reference encoder (oracle/_ref/libopus_ref_silkcap.so, built by
+oracle/Makefile with --wrap capture shims, oracle/ref_silk_capture.c) encodes synthetic speech-like audio and every call
+of silk_burg_modified_c / silk_NSQ_c / silk_NSQ_del_dec_c is recorded with its arguments AND its results, so the
+corpus carries the reference's own outputs for every record. Nothing is tiled: every record comes from a different
+frame of a different piece of audio (voiced / unvoiced / pauses, pitch 70-320 Hz, changing formants and levels).
+
+The capture library keeps its buffers in globals, so segments are captured in worker PROCESSES; the records land in
+memory-mapped .npy files under a cache directory (default $CONCENTUS_SILK_CACHE or /tmp/concentus_silk_corpus), which a
+later call re-opens instead of re-encoding. Nothing here is imported by the product package.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CAPLIB = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_silkcap.so")
+FS = 16000
+FRAME = 320
+SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder each)
+WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
+
+SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324}
+
+
+def available():
+    return os.path.exists(CAPLIB)
+
+
+def synth_voice(nsamples, seed):
+    """Speech-like mono int16 at 16 kHz: glottal pulse train with a wandering pitch (70-320 Hz) or noise excitation
+    through three formant resonators whose centre frequencies change every 120-400 ms; utterances of 0.4-2.5 s at
+    random levels separated by pauses."""
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(seed)
+    n = nsamples
+    # pitch contour: random knots every 100 ms, linearly interpolated
+    knots = np.clip(np.cumsum(rng.normal(0, 12, n // 1600 + 2)) + rng.uniform(90, 240), 70, 320)
+    f0 = np.interp(np.arange(n), np.arange(len(knots)) * 1600, knots)
+    phase = np.cumsum(f0 / FS)
+    pulses = (np.diff(np.floor(phase), prepend=0) > 0).astype(np.float64)
+    # segmentation into voiced / unvoiced / pause with a level per utterance
+    voiced = np.zeros(n)
+    gain = np.zeros(n)
+    pos = 0
+    while pos < n:
+        utt = int(rng.uniform(0.4, 2.5) * FS)
+        level = 10 ** (rng.uniform(-26, 0) / 20)
+        end = min(n, pos + utt)
+        q = pos
+        while q < end:
+            v = rng.random() < 0.65
+            d = int(rng.uniform(0.08, 0.5) * FS) if v else int(rng.uniform(0.03, 0.18) * FS)
+            voiced[q:min(end, q + d)] = 1.0 if v else 0.0
+            gain[q:min(end, q + d)] = level * (1.0 if v else rng.uniform(0.15, 0.6))
+            q += d
+        pos = end + int(max(0.0, rng.normal(0.15, 0.2)) * FS)
+    exc = pulses * voiced * 1.0 + rng.normal(0, 0.05, n) * (1 - voiced) + rng.normal(0, 0.002, n)
+    exc *= gain
+    # time-varying formants: constant within a chunk, filter memories carried across chunks
+    y = np.empty(n)
+    zi = [np.zeros(2), np.zeros(2), np.zeros(2)]
+    vowels = np.array([[730, 1090, 2440], [270, 2290, 3010], [300, 870, 2240], [530, 1840, 2480], [660, 1720, 2410],
+                       [440, 1020, 2240], [490, 1350, 1690], [400, 2000, 2550]], dtype=np.float64)
+    pos = 0
+    while pos < n:
+        d = int(rng.uniform(0.12, 0.4) * FS)
+        seg = exc[pos:pos + d]
+        fm = vowels[rng.integers(len(vowels))] * rng.uniform(0.9, 1.12)
+        bw = np.array([rng.uniform(60, 140), rng.uniform(60, 120), rng.uniform(110, 200)])
+        for k in range(3):
+            r = np.exp(-np.pi * bw[k] / FS)
+            a = [1.0, -2 * r * np.cos(2 * np.pi * min(fm[k], 7000) / FS), r * r]
+            seg, zi[k] = lfilter([1 - r], a, seg, zi=zi[k])
+        y[pos:pos + len(seg)] = seg
+        pos += d
+    peak = np.abs(y).max() + 1e-12
+    return np.clip(y / peak * 24000, -32768, 32767).astype(np.int16)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _capture_segment(args):
+    """Worker: encode SEG_FRAMES + WARMUP frames of synth_voice(seed) with a fresh reference encoder and write the
+    records of frames [WARMUP, WARMUP + take) into rows [row0, row0 + take) of the corpus files."""
+    cache, kind, seed, complexity, row0, take, total = args
+    lib = C.CDLL(CAPLIB)
+    lib.opus_encoder_create.restype = C.c_void_p
+    lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    nfr = take + WARMUP
+    pcm = synth_voice(nfr * FRAME, seed)
+    cap = 3 * nfr + 16
+    if kind == "dd":
+        lib.refcap_start_dd(cap)
+    else:
+        lib.refcap_start(cap)
+    err = C.c_int()
+    enc = C.c_void_p(lib.opus_encoder_create(FS, 1, 2048, C.byref(err)))          # OPUS_APPLICATION_VOIP
+    assert enc and err.value == 0
+    for req, v in ((4002, 32000), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
+        lib.opus_encoder_ctl(enc, req, v)
+    out = (C.c_ubyte * 1500)()
+    for f in range(nfr):
+        fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
+        assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
+    files = _files(cache, kind, total, mode="r+")
+    if kind == "dd":
+        nd = lib.refcap_count_dd()
+        assert nd >= nfr, (nd, nfr)
+        bufs = [np.zeros((nd, SIZES["dd_in"]), np.uint8), np.zeros((nd, SIZES["nsq_state"]), np.uint8),
+                np.zeros((nd, SIZES["nsq_state"]), np.uint8), np.zeros((nd, SIZES["dd_out"]), np.uint8)]
+        lib.refcap_get_dd(*[_p(b) for b in bufs])
+        for name, b in zip(("dd_in", "dd_state_in", "dd_state_out", "dd_out"), bufs):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    else:
+        nb, nn = lib.refcap_count_burg(), lib.refcap_count_nsq()
+        assert nn >= nfr and nb >= nfr, (nb, nn, nfr)
+        bufs = [np.zeros((nb, SIZES["burg_in"]), np.uint8), np.zeros((nb, SIZES["burg_out"]), np.uint8),
+                np.zeros((nn, SIZES["nsq_in"]), np.uint8), np.zeros((nn, SIZES["nsq_state"]), np.uint8),
+                np.zeros((nn, SIZES["nsq_state"]), np.uint8), np.zeros((nn, SIZES["nsq_out"]), np.uint8)]
+        lib.refcap_get(*[_p(b) for b in bufs])
+        skip_b = nb - (nn - WARMUP) if nb > nn else WARMUP       # burg may run twice per frame: keep the trailing ones
+        skip_b = max(WARMUP, min(skip_b, nb - take))
+        for name, b in zip(("burg_in", "burg_out"), bufs[:2]):
+            files[name][row0:row0 + take] = b[skip_b:skip_b + take]
+        for name, b in zip(("nsq_in", "nsq_state_in", "nsq_state_out", "nsq_out"), bufs[2:]):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    for f in files.values():
+        f.flush()
+    return take
+
+
+_LAYOUT = {
+    "nsq": (("burg_in", "burg_in"), ("burg_out", "burg_out"), ("nsq_in", "nsq_in"), ("nsq_state_in", "nsq_state"),
+            ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
+    "dd": (("dd_in", "dd_in"), ("dd_state_in", "nsq_state"), ("dd_state_out", "nsq_state"), ("dd_out", "dd_out")),
+}
+
+
+def _files(cache, kind, n, mode):
+    out = {}
+    for name, sz in _LAYOUT[kind]:
+        path = os.path.join(cache, "%s_%s_%d.npy" % (kind, name, n))
+        if mode == "w+":
+            out[name] = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(n, SIZES[sz]))
+        else:
+            out[name] = np.load(path, mmap_mode=mode)
+    return out
+
+
+def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=20260401):
+    """n distinct records: kind "nsq" -> burg_in/burg_out/nsq_in/nsq_state_in/nsq_state_out/nsq_out captured at
+    complexity 3 (silk_NSQ_c, control_codec.c:333-343); kind "dd" -> dd_in/dd_state_in/dd_state_out/dd_out captured at
+    complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
+    if not available():
+        raise FileNotFoundError(CAPLIB)
+    complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10))
+    cache = cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus")
+    os.makedirs(cache, exist_ok=True)
+    done = os.path.join(cache, "%s_%d_%s.done" % (kind, n, "-".join(map(str, complexities))))
+    if not os.path.exists(done):
+        for f in _files(cache, kind, n, "w+").values():
+            f.flush()
+        jobs, row = [], 0
+        while row < n:
+            take = min(SEG_FRAMES, n - row)
+            k = len(jobs)
+            jobs.append((cache, kind, seed + 7919 * k + (0 if kind == "nsq" else 104729), complexities[k % len(complexities)],
+                         row, take, n))
+            row += take
+        workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
+        if workers == 1:
+            for j in jobs:
+                _capture_segment(j)
+        else:
+            import multiprocessing as mp
+            with mp.get_context("spawn").Pool(workers) as pool:
+                for _ in pool.imap_unordered(_capture_segment, jobs):
+                    pass
+        open(done, "w").write("ok\n")
+    return _files(cache, kind, n, "r")
+
+
+if __name__ == "__main__":
+    import time
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    kind = sys.argv[2] if len(sys.argv) > 2 else "nsq"
+    t0 = time.time()
+    c = corpus(n, kind)
+    print("%d %s records in %.1f s:" % (n, kind, time.time() - t0), {k: v.shape for k, v in c.items()})
+    if kind == "nsq":
+        st = np.asarray(c["nsq_in"][:, 24:28]).view(np.int32)[:, 0]
+        print("signalType histogram (0 inactive, 1 unvoiced, 2 voiced):", np.bincount(st, minlength=3))

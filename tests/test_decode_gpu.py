@@ -158,3 +158,22 @@ def test_gpu_decodes_bit_file_written_by_reference_cli(ca, tmp_path):
         assert int(r.item()) == 960
         assert np.uint32(dec.ctl(4031).cpu().numpy().view(np.uint32)[0]) == rg[k]
         assert np.array_equal(o.cpu().numpy()[0], want[k]), k
+
+
+def test_packet_length_past_the_row_is_rejected_per_stream(ca):
+    """lens[k] > packet_stride would make stream k read the next stream's packet (the last stream: past the slab). The
+    stream gets OPUS_BAD_ARG and is left alone; the others decode as usual."""
+    import torch
+    pcm, pk, ln, rg = ec.load_case("noise_vbr_indep")
+    want = np.load(os.path.join(ROOT, "tests", "golden", "decode_golden.npz"))["noise_vbr_indep_dpcm"]
+    w = int(ln.max())
+    d_pk = torch.from_numpy(np.ascontiguousarray(pk[:, :w])).cuda()
+    bad_ln = ln.astype(np.int32).copy()
+    bad_ln[5] = w + 1
+    bad_ln[len(ln) - 1] = 1276
+    dpcm, ret, drng = ca.decode_independent(d_pk, torch.from_numpy(bad_ln).cuda())
+    torch.cuda.synchronize()
+    ret = ret.cpu().numpy()
+    good = np.setdiff1d(np.arange(len(ln)), [5, len(ln) - 1])
+    assert (ret[[5, len(ln) - 1]] == -1).all() and (ret[good] == 960).all()
+    assert np.array_equal(dpcm.cpu().numpy()[good], want[good])

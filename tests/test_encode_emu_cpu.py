@@ -55,3 +55,24 @@ def test_emulated_kernel_matches_live_reference_on_fresh_noise():
     pk, ln, rg = gm.ref_encode(gm._Cfg(2, 96000, 1, 0, 10, 16, 0, 1500), pcm, 1)
     out, lens, rng = _run_emu(pcm, 1, cfgvals)
     ec.assert_packets_equal(out, lens, rng, pk, ln, rg, "fresh noise")
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("mdb,vbr,cvbr", [(1500, 1, 0), (400, 1, 0), (400, 1, 1), (400, 0, 0), (1276, 0, 0)])
+def test_bitrate_max_resolves_per_call_like_the_reference(mdb, vbr, cvbr):
+    """OPUS_SET_BITRATE(OPUS_BITRATE_MAX): the reference resolves it at every opus_encode() call as
+    IMIN(1276, max_data_bytes) * 8 * Fs / frame_size (user_bitrate_to_bitrate, src/opus_encoder.c:512-521, :1040-1050) --
+    510 400 b/s for a 1276-byte buffer, 160 000 for 400 bytes. The host side (OpusEncoderBatch / opusgpu_encode) hands the
+    kernels that number; here the kernel sources run with it against the reference run with -1."""
+    gm = ec.golden_module()
+    pcm = gm.synth_pcm("music", 32, 77)
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, -1, vbr, cvbr, 10, 16, 0, mdb), pcm, 16)
+    emu = emulib.lib()
+    cfg = emulib.Config(2, min(1276, mdb) * 400, vbr, cvbr, 10, 16, 0, mdb)
+    out = np.zeros((32, 1280), np.uint8)
+    lens = np.zeros(32, np.int32)
+    rng = np.zeros(32, np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    st = emulib.fresh_states(2)
+    emu.emu_celt_encode_frames(C.byref(cfg), p(st), p(np.ascontiguousarray(pcm)), 32, 16, p(out), 1280, p(lens), p(rng))
+    ec.assert_packets_equal(out, lens, rng, pk, ln, rg, "OPUS_BITRATE_MAX, max_data_bytes %d" % mdb)

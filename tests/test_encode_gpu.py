@@ -13,6 +13,7 @@ import encode_cases as ec
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+THREADS = min(16, len(os.sched_getaffinity(0)))
 
 
 @pytest.fixture(scope="module")
@@ -82,9 +83,9 @@ def test_gpu_matches_live_reference(ca, kind, n, fps, cfgvals):
 
 
 def test_config3_full_size_65536_frames(ca):
-    """65 536 independent frames, 96 kb/s, complexity 10 (BASELINE config #3). Exact check on a strided
-    sample of 512 frames (live reference if present, else batch-size independence only), and the result of
-    every frame must not depend on the batch it was encoded in."""
+    """65 536 independent frames, 96 kb/s, complexity 10 (BASELINE config #3): EVERY packet and final range against
+    the compiled reference (oracle/_ref, ~1 s on the box's host threads) -- small fixtures do not see inter-wave bugs --
+    and the result of a frame must not depend on the batch it was encoded in."""
     import torch
     gm = ec.golden_module()
     n = 65536
@@ -100,13 +101,87 @@ def test_config3_full_size_65536_frames(ca):
     sub = torch.from_numpy(np.ascontiguousarray(pcm[idx])).cuda()
     o2, l2, r2 = ca.encode_independent(sub, cfg)
     torch.cuda.synchronize()
-    out_h = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+    out_h = out.cpu().numpy()
+    fr_h = fr.cpu().numpy().view(np.uint32)
     assert np.array_equal(l2.cpu().numpy(), lens_h[idx])
-    assert np.array_equal(r2.cpu().numpy(), fr.cpu().numpy()[idx])
-    assert np.array_equal(o2.cpu().numpy(), out_h)
-    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
-        pk, ln, rg = gm.ref_encode(gm._Cfg(2, 96000, 1, 0, 10, 16, 0, 1500), pcm[idx], 1, threads=8)
-        ec.assert_packets_equal(out_h, lens_h[idx], fr.cpu().numpy()[idx].view(np.uint32), pk, ln, rg, "config3 sample")
+    assert np.array_equal(r2.cpu().numpy().view(np.uint32), fr_h[idx])
+    assert np.array_equal(o2.cpu().numpy(), out_h[idx])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("oracle/_ref did not travel: batch-size independence only")
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, 96000, 1, 0, 10, 16, 0, 1500), pcm, 1, threads=THREADS)
+    ec.assert_packets_equal_fast(out_h, lens_h, fr_h, pk, ln, rg, "config3, all 65 536 frames")
+
+
+def test_config5_mixed_shard_on_one_gpu(ca):
+    """One rank's shard of BASELINE configs[4] (1 M mixed units over 8 GPUs -> 131 072 per GPU = 114 688 CELT frames +
+    16 384 SILK records, sharding.mixed_counts), run the way bench.py --workload mixed runs it: the CELT pipeline on the
+    current stream, silk_burg_modified + silk_NSQ on a side stream. CELT: every 8th frame against the compiled reference;
+    SILK: every record against the outputs the reference produced when the records were captured."""
+    import torch
+    from concentus_amd.sharding import mixed_counts
+    import silk_corpus
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")) or not silk_corpus.available():
+        pytest.skip("oracle/_ref did not travel")
+    gm = ec.golden_module()
+    F, NS = mixed_counts(131072)
+    assert (F, NS) == (114688, 16384)
+    rec = silk_corpus.corpus(NS, "nsq")
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
+    d = torch.from_numpy(pcm).cuda()
+    bi, ni, st = (torch.from_numpy(np.ascontiguousarray(rec[k])).cuda() for k in ("burg_in", "nsq_in", "nsq_state_in"))
+    side = torch.cuda.Stream()
+    for _ in range(2):                      # twice: the second pass runs with both workspaces already allocated
+        st.copy_(torch.from_numpy(np.ascontiguousarray(rec["nsq_state_in"])).cuda())
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            bo = ca.silk_burg_modified(bi)
+            pulses = ca.silk_NSQ(ni, st)
+        out, lens, fr = ca.encode_independent(d, ca.default_config())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+    assert np.array_equal(bo.cpu().numpy(), rec["burg_out"])
+    assert np.array_equal(pulses.cpu().numpy().view(np.uint8), rec["nsq_out"])
+    assert np.array_equal(st.cpu().numpy(), rec["nsq_state_out"])
+    idx = np.arange(0, F, 8)
+    t_idx = torch.from_numpy(idx).cuda()
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, 96000, 1, 0, 10, 16, 0, 1500), pcm[idx], 1, threads=THREADS)
+    ec.assert_packets_equal_fast(out[t_idx].cpu().numpy(), lens[t_idx].cpu().numpy(), fr[t_idx].cpu().numpy().view(np.uint32),
+                                 pk, ln, rg, "config5 shard, CELT sample")
+
+
+@pytest.mark.parametrize("mdb", [1500, 400])
+def test_bitrate_max_follows_the_buffer_of_each_call(ca, mdb):
+    """OPUS_SET_BITRATE(OPUS_BITRATE_MAX) through both host mirrors (OpusEncoderBatch.ctl and the C verbs
+    opusgpu_encoder_ctl / opusgpu_encode) against the live reference driven with -1: user_bitrate_to_bitrate
+    (src/opus_encoder.c:512-521) resolves it per call from max_data_bytes."""
+    import torch
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("oracle/_ref did not travel")
+    gm = ec.golden_module()
+    ns, fps = 4, 6
+    pcm = gm.synth_pcm("music", ns * fps, 91)
+    pk, ln, rg = gm.ref_encode(gm._Cfg(2, -1, 1, 0, 10, 16, 0, mdb), pcm, fps, threads=2)
+    enc = ca.OpusEncoderBatch(ns).apply_opus_demo_ctls(-1, 1, 0, 10)
+    p4 = pcm.reshape(ns, fps, 960, 2)
+    for f in range(fps):
+        o, l = enc.encode(torch.from_numpy(np.ascontiguousarray(p4[:, f])).cuda(), max_data_bytes=mdb)
+        torch.cuda.synchronize()
+        idx = np.arange(ns) * fps + f
+        ec.assert_packets_equal(o.cpu().numpy(), l.cpu().numpy(), enc.ctl(4031).cpu().numpy().view(np.uint32),
+                                pk[idx], ln[idx], rg[idx], "OpusEncoderBatch, BITRATE_MAX, frame %d" % f)
+    L = ca.lib.load()
+    err = C.c_int(0)
+    st = L.opusgpu_encoder_create(48000, 2, 2051, C.byref(err))
+    for req, v in ((4002, -1), (4006, 1), (4020, 0), (4010, 10), (4036, 16)):
+        assert L.opusgpu_encoder_ctl(C.c_void_p(st), req, C.c_int32(v)) == 0
+    data = (C.c_ubyte * 1500)()
+    for f in range(fps):
+        frame = np.ascontiguousarray(pcm[f])
+        got = L.opusgpu_encode(C.c_void_p(st), frame.ctypes.data_as(C.c_void_p), 960, data, mdb)
+        assert got == ln[f] and bytes(data[:got]) == pk[f, :got].tobytes(), f
+    L.opusgpu_encoder_destroy(C.c_void_p(st))
 
 
 def test_bad_configs_rejected(ca):

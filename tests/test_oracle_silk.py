@@ -82,3 +82,32 @@ def test_oracle_del_dec_matches_fresh_capture(complexity):
     rec = gm.silk_dd_capture(gm.synth_voice(16000 * 3, 77 + complexity), complexity)
     assert rec["dd_in"].shape[0] >= 100
     _check_dd(rec)
+
+
+def test_oracle_pinned_on_a_fresh_corpus_of_distinct_records():
+    """oracle/oracle_silk.c against 4 096 + 3 072 records freshly captured from the unmodified reference encoder
+    (tests/silk_corpus.py): Burg, NSQ and NSQ_del_dec outputs and every byte of silk_nsq_state."""
+    import ctypes as C
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    import tempfile
+    orc = oraclelib.lib()
+    p = oraclelib.ptr
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4096, "nsq", cache=tmp, workers=2)
+        n = 4096
+        bo = np.zeros((n, 72), np.uint8)
+        orc.orc_silk_burg_batch(p(np.ascontiguousarray(c["burg_in"])), p(bo), n)
+        assert np.array_equal(bo, c["burg_out"])
+        st = np.array(c["nsq_state_in"])
+        no = np.zeros((n, 320), np.uint8)
+        orc.orc_silk_nsq_batch(p(np.ascontiguousarray(c["nsq_in"])), p(st), p(no), n)
+        assert np.array_equal(no, c["nsq_out"]) and np.array_equal(st, c["nsq_state_out"])
+        d = silk_corpus.corpus(3072, "dd", cache=tmp, workers=2)
+        n = 3072
+        st = np.array(d["dd_state_in"])
+        do = np.zeros((n, 324), np.uint8)
+        orc.orc_silk_nsq_del_dec_batch(p(np.ascontiguousarray(d["dd_in"])), p(st), p(do), n)
+        assert np.array_equal(do, d["dd_out"]) and np.array_equal(st, d["dd_state_out"])
+        del c, d

@@ -91,3 +91,30 @@ def test_two_rank_sharded_encode_matches_golden(world):
         p.join(timeout=180)
         assert p.exitcode == 0
     assert q.get(timeout=10) == "ok"
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start the ranks itself (child processes, before any GPU
+    call) and report n_gpus 2. --rehearse keeps it CPU-only: gloo rendezvous + the packet gather, no codec work."""
+    rc, line, err = _run_bench(["--gpus", "2", "--rehearse"])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["rehearsal"] is True and line["gather_ok"] is True and line["value"] is None
+
+
+def test_bench_rejects_a_world_size_that_differs_from_gpus():
+    rc, line, err = _run_bench(["--gpus", "2", "--rehearse"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and line is None and "WORLD_SIZE=1" in err

@@ -174,3 +174,87 @@ def test_burg_per_call_hook_with_reference_signature(ca):
         assert (nrg.value, nrg_q.value, list(A)[:rec.D]) == (want.res_nrg, want.res_nrg_Q, list(want.A_Q16)[:rec.D]), r
     L.opusgpu_silk_burg_modified_c(C.byref(nrg), C.byref(nrg_q), A, x, 0, 10, 4, 17, 0)      # order > 16
     assert L.opusgpu_get_last_error() == -1
+
+
+# ---- config #4 at full size on DISTINCT records (tests/silk_corpus.py: every record captured from the unmodified
+# reference encoder on its own frame of synthetic speech, with the reference's outputs) ----
+def test_silk_kernels_65536_distinct_records_vs_reference_outputs(ca):
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(65536, "nsq")
+    bo, pulses, st = _run_gpu(ca, rec)
+    assert np.array_equal(bo, rec["burg_out"]), np.nonzero((bo != rec["burg_out"]).any(1))[0][:8]
+    assert np.array_equal(pulses, rec["nsq_out"]), np.nonzero((pulses != rec["nsq_out"]).any(1))[0][:8]
+    bad = np.nonzero((st != rec["nsq_state_out"]).any(1))[0]
+    assert bad.size == 0, ("NSQ state differs", bad[:8])
+    sig = np.asarray(rec["nsq_in"][:, 24:28]).view(np.int32)[:, 0]
+    assert (np.bincount(sig, minlength=3) > 2000).all()          # inactive, unvoiced and voiced frames all well represented
+
+
+def test_del_dec_65536_distinct_records_vs_reference_outputs(ca):
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(65536, "dd")
+    st = _dev(rec["dd_state_in"])
+    out = ca.silk_NSQ_del_dec(_dev(rec["dd_in"]), st)
+    torch.cuda.synchronize()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    assert np.array_equal(out, rec["dd_out"]), np.nonzero((out != rec["dd_out"]).any(1))[0][:8]
+    bad = np.nonzero((st != rec["dd_state_out"]).any(1))[0]
+    assert bad.size == 0, ("NSQ state differs", bad[:8])
+    nst = np.asarray(rec["dd_in"][:, 1640:1644]).view(np.int32)[:, 0]
+    assert set(np.unique(nst)) == {2, 3, 4}
+
+
+def test_corrupted_record_headers_are_skipped_not_executed(ca):
+    """The header fields of the records live in device memory; a corrupted one (D > 16, nx > 384, a pitch lag outside
+    the LTP memory, 7 delayed-decision states ...) must not index LDS / private arrays out of bounds: the record is
+    skipped (outputs zeroed, state untouched) and counted (opusgpu_silk_bad_records), its neighbours are unaffected."""
+    import torch
+    g = np.load(GOLD)
+    rec = {k[5:]: g[k].copy() for k in g.files}
+    ca.silk.bad_records()                                        # clear
+    bi = rec["burg_in"].copy()
+    hdr = bi[:, 768:784].view(np.int32)                         # minInvGain_Q30, subfr_length, nb_subfr, D
+    hdr[3, 3] = 17            # D
+    hdr[5, 1] = 200           # subfr_length * nb_subfr = 800 > 384
+    hdr[7, 2] = 0             # nb_subfr
+    hdr[9, 1] = -5
+    bo = ca.silk_burg_modified(_dev(bi)).cpu().numpy()
+    assert ca.silk.bad_records() == 4
+    good = np.setdiff1d(np.arange(80), [3, 5, 7, 9])
+    assert np.array_equal(bo[good], rec["burg_out"][good])
+    assert (bo[[3, 5, 7, 9], 4:8].view(np.int32) == -2 ** 31).all() and (bo[[3, 5, 7, 9], 8:] == 0).all()
+    ni = rec["nsq_in"].copy()
+    h = ni[:, :128].view(np.int32)     # nb_subfr, subfr_length, frame_length, ltp_mem_length, predictLPCOrder, shapingLPCOrder, signalType ...
+    voiced = np.nonzero(h[:, 6] == 2)[0]
+    v = int(voiced[0])
+    h[v, 28 + 1] = 100000     # pitchL[1] far outside the LTP memory
+    h[2, 0] = 9               # nb_subfr
+    h[4, 3] = 4000            # ltp_mem_length
+    h[6, 4] = 40              # predictLPCOrder
+    bad = sorted({v, 2, 4, 6})
+    st = _dev(rec["nsq_state_in"])
+    pulses = ca.silk_NSQ(_dev(ni), st)
+    torch.cuda.synchronize()
+    assert ca.silk.bad_records() == len(bad)
+    good = np.setdiff1d(np.arange(80), bad)
+    assert np.array_equal(pulses.cpu().numpy().view(np.uint8)[good], rec["nsq_out"][good])
+    assert np.array_equal(st.cpu().numpy()[good], rec["nsq_state_out"][good])
+    assert np.array_equal(st.cpu().numpy()[bad], rec["nsq_state_in"][bad]) and (pulses.cpu().numpy()[bad] == 0).all()
+    gd = np.load(GOLD_DD)
+    dd = {k[5:]: gd[k].copy() for k in gd.files}
+    di = dd["dd_in"].copy()
+    di[1, 1640:1644].view(np.int32)[0] = 7          # nStatesDelayedDecision
+    di[3, 4:8].view(np.int32)[0] = 500              # subfr_length
+    st = _dev(dd["dd_state_in"])
+    out = ca.silk_NSQ_del_dec(_dev(di), st)
+    torch.cuda.synchronize()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(di.shape[0]), [1, 3])
+    assert np.array_equal(st.cpu().numpy()[good], dd["dd_state_out"][good])
+    assert np.array_equal(st.cpu().numpy()[[1, 3]], dd["dd_state_in"][[1, 3]])
+    assert ca.silk.bad_records() == 0
