@@ -22,7 +22,10 @@ def cases():
 
 def load_case(name):
     g = np.load(GOLD)
-    return g[name + "_pcm"], g[name + "_packets"], g[name + "_len"], g[name + "_rng"]
+    pcm_key = name + "_pcm"
+    if pcm_key not in g.files:          # cases that share one input (the real-audio file) store it once under their kind
+        pcm_key = [c[1] for c in cases() if c[0] == name][0] + "_pcm"
+    return g[pcm_key], g[name + "_packets"], g[name + "_len"], g[name + "_rng"]
 
 
 def assert_packets_equal(got_pk, got_len, got_rng, exp_pk, exp_len, exp_rng, what=""):

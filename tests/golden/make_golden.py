@@ -75,6 +75,19 @@ def synth_pcm(kind, nframes, seed):
     rng = np.random.default_rng(seed)
     if kind == "noise":
         return rng.integers(-8192, 8192, size=(nframes, 960, 2), dtype=np.int16)
+    if kind == "gmusic":
+        # the reference's own encoder-test signal (tests/test_opus_encode.c:59-88 generate_music), restated in
+        # oracle/oracle_testsignals.c and pinned against the reference's function by tests/test_oracle_signals.py;
+        # seed 13371337 + one banner draw is what the reference's test uses
+        import oraclelib
+        buf = np.zeros((nframes * 960, 2), np.int16)
+        oraclelib.lib().orc_generate_music(oraclelib.ptr(buf), nframes * 960, C.c_uint32(seed), 1)
+        return buf.reshape(nframes, 960, 2)
+    if kind == "real48":
+        # real music shipped with the reference's Java test console; whole 20 ms frames only
+        raw = np.fromfile(REAL48, dtype="<i2")
+        n = min(nframes, raw.size // 1920)
+        return np.ascontiguousarray(raw[:n * 1920].reshape(n, 960, 2))
     if kind == "music":
         t = np.arange(nframes * 960)
         f0 = 220.0 * (1 + (seed % 7))
@@ -92,6 +105,9 @@ def synth_pcm(kind, nframes, seed):
         elif m == 3:
             pcm[n, :, :] = 12345
     return pcm
+
+
+REAL48 = "/root/reference/Java/ConcentusTestConsole/src/main/resources/AudioData/48Khz Stereo.raw"
 
 
 def ref_encode(cfg, pcm, frames_per_stream, threads=4):
@@ -118,6 +134,12 @@ ENCODE_CASES = [
     # 30-38.2 kb/s: the Opus layer narrows the stereo image (stereo_fade, src/opus_encoder.c:1790-1809)
     ("music_34k_cbr_stream", "music", 16, 8, 11, (34000, 0, 0, 10)),
     ("noise_33k_vbr_indep", "noise", 8, 1, 12, (33000, 1, 0, 7)),
+    # the reference's own test signal (generate_music, seed 13371337) and its own audio file, as streams and as
+    # independent frames; the real-audio PCM is stored once ("real48_pcm") for both cases
+    ("gmusic_vbr_indep", "gmusic", 48, 1, 13371337, (96000, 1, 0, 10)),
+    ("gmusic_cvbr_stream", "gmusic", 96, 48, 13371337, (64000, 1, 1, 10)),
+    ("real48_vbr_stream", "real48", 873, 873, 0, (96000, 1, 0, 10)),
+    ("real48_vbr_indep", "real48", 873, 1, 0, (96000, 1, 0, 10)),
 ]
 
 
@@ -128,7 +150,7 @@ def encode_vectors():
         pcm = synth_pcm(kind, n, seed)
         pk, ln, rg = ref_encode(cfg, pcm, fps)
         assert (ln > 0).all(), name
-        out[name + "_pcm"] = pcm
+        out[(kind if kind == "real48" else name) + "_pcm"] = pcm
         out[name + "_packets"] = pk[:, :int(ln.max())]
         out[name + "_len"] = ln
         out[name + "_rng"] = rg
@@ -167,6 +189,8 @@ def decode_vectors():
     out = {}
     enc = np.load(os.path.join(HERE, "encode_golden.npz"))
     for name, kind, n, fps, seed, _cfg in ENCODE_CASES:
+        if kind == "real48":
+            continue               # 3.3 MB of PCM per case: decoded against the live reference instead (tests/test_decode_gpu.py)
         pcm, rng, ret = ref_decode(enc[name + "_packets"], enc[name + "_len"], fps)
         assert (ret == 960).all() and (rng == enc[name + "_rng"]).all(), name
         out[name + "_dpcm"] = pcm

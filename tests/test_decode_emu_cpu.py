@@ -27,7 +27,17 @@ def load_decode_case(name, from_encode):
         _pcm, pk, ln, rg = ec.load_case(name)
     else:
         pk, ln, rg = g[name + "_packets"], g[name + "_len"], g[name + "_rng"]
-    return np.ascontiguousarray(pk), np.ascontiguousarray(ln.astype(np.int32)), rg, g[name + "_dpcm"]
+    pk, ln = np.ascontiguousarray(pk), np.ascontiguousarray(ln.astype(np.int32))
+    if name + "_dpcm" in g.files:
+        return pk, ln, rg, g[name + "_dpcm"]
+    # the real-audio cases carry no committed PCM (3.3 MB each): their expected output comes from the live reference
+    gm = ec.golden_module()
+    if not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("no committed PCM for this case and oracle/_ref is absent")
+    fps = [c[3] for c in gm.ENCODE_CASES if c[0] == name][0]
+    want, wrng, wret = gm.ref_decode(pk, ln, fps)
+    assert (wret == 960).all() and np.array_equal(wrng, rg)
+    return pk, ln, rg, want
 
 
 @pytest.mark.parametrize("case", decode_cases(), ids=lambda c: c[0])
