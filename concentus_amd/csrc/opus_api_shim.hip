@@ -126,6 +126,28 @@ extern "C" int opusgpu_encoder_ctl(OpusGpuEncoder *st, int request, ...)
         if (!p) ret = OPUSGPU_BAD_ARG; else *p = st->final_range;
         break;
     }
+    // getters (src/opus_encoder.c:2084-2431): every one takes an opus_int32 *
+    case 4001: case 4003: case 4007: case 4009: case 4011: case 4013: case 4015: case 4017: case 4021: case 4023:
+    case 4027: case 4029: case 4037: case 4041: {
+        int32_t *p = va_arg(ap, int32_t *);
+        if (!p) { ret = OPUSGPU_BAD_ARG; break; }
+        switch (request) {
+        case 4001: *p = 2051; break;                                              // OPUS_GET_APPLICATION: RESTRICTED_LOWDELAY
+        case 4003: *p = st->bitrate_is_max ? 1276 * 400 : st->cfg.bitrate; break; // OPUS_GET_BITRATE (:2086-2093)
+        case 4007: *p = st->cfg.vbr; break;
+        case 4009: *p = 1105; break;                                              // OPUS_GET_BANDWIDTH: OPUS_BANDWIDTH_FULLBAND
+        case 4011: *p = st->cfg.complexity; break;
+        case 4013: case 4017: *p = 0; break;                                      // in-band FEC / DTX: off
+        case 4015: *p = st->cfg.loss_rate; break;
+        case 4021: *p = st->cfg.constrained_vbr; break;
+        case 4023: *p = -1000; break;                                             // OPUS_GET_FORCE_CHANNELS: OPUS_AUTO
+        case 4027: *p = 48000 / 400; break;                                       // OPUS_GET_LOOKAHEAD, restricted-lowdelay (:2336-2338)
+        case 4029: *p = 48000; break;
+        case 4037: *p = st->cfg.lsb_depth; break;
+        default: *p = 5000; break;                                                // OPUS_GET_EXPERT_FRAME_DURATION: OPUS_FRAMESIZE_ARG
+        }
+        break;
+    }
     case 4028:                                                                    // OPUS_RESET_STATE
         ret = opusgpu_celt_state_init(st->d_state, 1, st->stream);
         st->final_range = 0;
@@ -168,6 +190,7 @@ struct OpusGpuDecoder {
     uint32_t *d_rng;
     int16_t *d_pcm;
     uint32_t final_range;
+    int last_packet_duration;
     hipStream_t stream;
 };
 
@@ -224,9 +247,19 @@ extern "C" int opusgpu_decoder_ctl(OpusGpuDecoder *st, int request, ...)
         if (!p) ret = OPUSGPU_BAD_ARG; else *p = st->final_range;
         break;
     }
+    case 4009: case 4029: case 4039: case 4045: {                                 // getters (src/opus_decoder.c:828-938)
+        int32_t *p = va_arg(ap, int32_t *);
+        if (!p) ret = OPUSGPU_BAD_ARG;
+        else *p = request == 4009 ? 1105 : request == 4029 ? 48000 : request == 4039 ? st->last_packet_duration : 0;
+        break;
+    }
+    case 4034:                                                                    // OPUS_SET_GAIN: only 0 dB
+        if (va_arg(ap, int32_t) != 0) ret = OPUSGPU_UNIMPLEMENTED;
+        break;
     case 4028:                                                                    // OPUS_RESET_STATE
         ret = opusgpu_celt_dec_state_init(st->d_state, 1, st->stream);
         st->final_range = 0;
+        st->last_packet_duration = 0;
         break;
     default: ret = OPUSGPU_UNIMPLEMENTED;
     }
@@ -252,6 +285,7 @@ extern "C" int opusgpu_decode(OpusGpuDecoder *st, const unsigned char *data, int
         hipStreamSynchronize(st->stream) != hipSuccess)
         return OPUSGPU_INTERNAL_ERROR;
     if (ret > 0) {
+        st->last_packet_duration = ret;
         if (hipMemcpy(pcm, st->d_pcm, (size_t)ret * 2 * sizeof(int16_t), hipMemcpyDeviceToHost) != hipSuccess) return OPUSGPU_INTERNAL_ERROR;
     }
     return ret;

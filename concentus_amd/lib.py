@@ -47,6 +47,12 @@ SYMBOLS = [
     ("opusgpu_decode", _i, [_vp, _vp, _i, _vp, _i, _i]),
     ("opusgpu_decoder_ctl", _i, None),          # variadic
     ("opusgpu_decoder_destroy", None, [_vp]),
+    ("opusgpu_opus_ifft", None, [_vp, _vp, _vp]),
+    ("opusgpu_comb_filter_const", None, [_vp, _vp, _i, _i, _i, _i, _i]),
+    ("opusgpu_exp_rotation1", None, [_vp, _i, _i, _i, _i]),
+    ("opusgpu_renormalise_vector", None, [_vp, _i, _i, _i]),
+    ("opusgpu_silk_NSQ", None, [_vp] * 13 + [_i, _i]),
+    ("opusgpu_silk_NSQ_del_dec", None, [_vp] * 13 + [_i, _i]),
     ("opusgpu_decode_lane_diag", _i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_back_lane_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),

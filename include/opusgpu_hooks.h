@@ -1,0 +1,73 @@
+/* opusgpu_hooks.h -- the reference's per-kernel operator API (its RTCD / OVERRIDE_* hooks), per call, with the
+ * reference's OWN argument lists and host pointers (SURVEY.md 8b "inner boundary").
+ *
+ * Every entry below is what the reference's macro or OVERRIDE_ guard for that kernel would be pointed at: same arguments,
+ * same meaning, same in-place behaviour, results bit-exact. One call = one launch bracketed by small copies, so these are
+ * for plumbing and parity (latency-dominated); throughput comes from the batch entry points of opusgpu.h /
+ * opusgpu_silk.h, which run the same device code over N frames. Errors: opusgpu_get_last_error() (OPUSGPU_OK after a
+ * successful call); on error the outputs are left untouched.
+ *
+ * (The hooks that existed before live in opusgpu.h / opusgpu_silk.h: opusgpu_clt_mdct_forward / _backward,
+ * opusgpu_opus_fft, opusgpu_celt_pitch_xcorr, opusgpu_silk_burg_modified_c.)
+ */
+#ifndef OPUSGPU_HOOKS_H
+#define OPUSGPU_HOOKS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* opus_ifft(cfg, fin, fout) -- macro at opus-fix/celt/kiss_fft.h:135-178 -> opus_ifft_c (celt/kiss_fft.c:602-614):
+ * unscaled inverse FFT (bit-reverse, conjugate, forward butterflies, conjugate), out of place. `cfg` must be one of the
+ * four kiss_fft_state of the static 48 kHz mode (nfft 480 / 240 / 120 / 60); its head is validated, its tables are not
+ * read on the device. fin / fout: kiss_fft_cpx = { int32 r, i }. */
+void opusgpu_opus_ifft(const void *cfg, const void *fin, void *fout);
+
+/* comb_filter_const(y, x, T, N, g10, g11, g12) -- guard OVERRIDE_COMB_FILTER_CONST, opus-fix/celt/celt.c:92-181
+ * (comb_filter_const_c :156-181):  y[i] = x[i] + g10*x[i-T] + g11*(x[i-T+1]+x[i-T-1]) + g12*(x[i-T+2]+x[i-T-2]) in
+ * MULT16_32_Q15. Reads x[-T-2 .. N-T+2) and x[0 .. N). y may equal x (the decoder's post-filter runs in place and is
+ * then recursive through the already filtered samples, exactly as the C loop is); any other overlap of the two spans is
+ * rejected with OPUSGPU_BAD_ARG. 1 <= N <= 8192, 3 <= T <= 4096. opus_val16 gains travel as int (C promotion). */
+void opusgpu_comb_filter_const(int32_t *y, int32_t *x, int T, int N, int g10, int g11, int g12);
+
+/* exp_rotation1(X, len, stride, c, s) -- guard OVERRIDE_vq_exp_rotation1, opus-fix/celt/vq.c:42-68: the forward and
+ * backward sweep of Givens rotations over X[0..len), in place. 1 <= stride < len <= 4096. */
+void opusgpu_exp_rotation1(int16_t *X, int len, int stride, int c, int s);
+
+/* renormalise_vector(X, N, gain, arch) -- guard OVERRIDE_renormalise_vector, opus-fix/celt/vq.c:347-374: scales X to
+ * norm `gain` (Q15) in place. 1 <= N <= 4096. */
+void opusgpu_renormalise_vector(int16_t *X, int N, int gain, int arch);
+
+/* silk_NSQ / silk_NSQ_del_dec with the reference's 15-argument list -- macros at opus-fix/silk/main.h:245-268 and
+ * :271-296 (guards OVERRIDE_silk_NSQ / OVERRIDE_silk_NSQ_del_dec) -> silk_NSQ_c (silk/NSQ.c:74), silk_NSQ_del_dec_c
+ * (silk/NSQ_del_dec.c:112). psEncC / NSQ / psIndices are the reference's own silk_encoder_state / silk_nsq_state /
+ * SideInfoIndices (opus-fix/silk/structs.h; x86-64 layout): only the fields the two functions read are touched, at the
+ * offsets below (pinned against the reference's headers by tests/test_hooks_layout.py); NSQ is read and written whole
+ * (same layout as opusgpu_nsq_state); silk_NSQ_del_dec also writes psIndices->Seed (NSQ_del_dec.c:297). */
+#define OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE 7224
+#define OPUSGPU_REF_OFF_NB_SUBFR 4604               /* silk_encoder_state.nb_subfr                (opus_int) */
+#define OPUSGPU_REF_OFF_FRAME_LENGTH 4608           /* .frame_length */
+#define OPUSGPU_REF_OFF_SUBFR_LENGTH 4612           /* .subfr_length */
+#define OPUSGPU_REF_OFF_LTP_MEM_LENGTH 4616         /* .ltp_mem_length */
+#define OPUSGPU_REF_OFF_N_STATES_DEL_DEC 4652       /* .nStatesDelayedDecision */
+#define OPUSGPU_REF_OFF_SHAPING_LPC_ORDER 4660      /* .shapingLPCOrder */
+#define OPUSGPU_REF_OFF_PREDICT_LPC_ORDER 4664      /* .predictLPCOrder */
+#define OPUSGPU_REF_OFF_WARPING_Q16 4704            /* .warping_Q16 */
+#define OPUSGPU_REF_SIZEOF_SIDE_INFO_INDICES 36
+#define OPUSGPU_REF_OFF_SIGNAL_TYPE 29              /* SideInfoIndices.signalType                 (opus_int8) */
+#define OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE 30        /* .quantOffsetType */
+#define OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2 31      /* .NLSFInterpCoef_Q2 */
+#define OPUSGPU_REF_OFF_SEED 34                     /* .Seed */
+void opusgpu_silk_NSQ(const void *psEncC, void *NSQ, void *psIndices, const int32_t x_Q3[], int8_t pulses[],
+                      const int16_t PredCoef_Q12[/*2 * 16*/], const int16_t LTPCoef_Q14[/*5 * 4*/], const int16_t AR2_Q13[/*4 * 16*/],
+                      const int HarmShapeGain_Q14[/*4*/], const int Tilt_Q14[/*4*/], const int32_t LF_shp_Q14[/*4*/],
+                      const int32_t Gains_Q16[/*4*/], const int pitchL[/*4*/], const int Lambda_Q10, const int LTP_scale_Q14);
+void opusgpu_silk_NSQ_del_dec(const void *psEncC, void *NSQ, void *psIndices, const int32_t x_Q3[], int8_t pulses[],
+                              const int16_t PredCoef_Q12[/*2 * 16*/], const int16_t LTPCoef_Q14[/*5 * 4*/], const int16_t AR2_Q13[/*4 * 16*/],
+                              const int HarmShapeGain_Q14[/*4*/], const int Tilt_Q14[/*4*/], const int32_t LF_shp_Q14[/*4*/],
+                              const int32_t Gains_Q16[/*4*/], const int pitchL[/*4*/], const int Lambda_Q10, const int LTP_scale_Q14);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPUSGPU_HOOKS_H */

@@ -1,0 +1,23 @@
+/* oracle/ref_layout_probe.c -- TEST INFRASTRUCTURE ONLY.
+ * Prints, as JSON, the x86-64 offsets of the reference's struct fields that the per-call SILK hooks read through the
+ * reference's own pointer types (silk_encoder_state / SideInfoIndices, opus-fix/silk/structs.h), so that
+ * tests/test_hooks_layout.py can pin the constants hard-coded in include/opusgpu_hooks.h. Compiled against the
+ * reference's headers where they lie (oracle/Makefile -> oracle/_ref/layout_probe). */
+#include <stddef.h>
+#include <stdio.h>
+#include "main.h"
+
+#define F(T, f) printf("  \"%s.%s\": %zu,\n", #T, #f, offsetof(T, f))
+
+int main(void)
+{
+    printf("{\n");
+    F(silk_encoder_state, nb_subfr); F(silk_encoder_state, subfr_length); F(silk_encoder_state, frame_length);
+    F(silk_encoder_state, ltp_mem_length); F(silk_encoder_state, predictLPCOrder); F(silk_encoder_state, shapingLPCOrder);
+    F(silk_encoder_state, nStatesDelayedDecision); F(silk_encoder_state, warping_Q16); F(silk_encoder_state, arch);
+    F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
+    F(SideInfoIndices, Seed);
+    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu\n}\n",
+           sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state));
+    return 0;
+}

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _declared():
     names = set()
-    for h in ("opusgpu.h", "opusgpu_silk.h"):
+    for h in ("opusgpu.h", "opusgpu_silk.h", "opusgpu_hooks.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         names |= set(re.findall(r"\b(opusgpu_\w+)\s*\(", src))
@@ -56,3 +56,23 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         lib.load()
+
+
+def test_compat_library_exports_the_libopus_names():
+    """concentus_amd/compat/libopus.so: the link target for unedited callers of <opus.h> (src/opus_demo.c, the P/Invoke
+    harness CSharp/ParityTest/TestDriver.cs:22-41) must export exactly the names they bind."""
+    _ensure_built()
+    path = os.path.join(ROOT, "concentus_amd", "compat", "libopus.so")
+    assert os.path.exists(path), "make -C concentus_amd/csrc builds it"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    need = {"opus_encoder_create", "opus_encoder_ctl", "opus_encode", "opus_encoder_destroy", "opus_decoder_create",
+            "opus_decoder_ctl", "opus_decode", "opus_decoder_destroy", "opus_strerror", "opus_get_version_string",
+            "opus_packet_get_samples_per_frame", "opus_packet_get_nb_frames", "opus_packet_get_nb_samples"}
+    assert need <= exported, sorted(need - exported)
+    import ctypes
+    L = ctypes.CDLL(path)                                     # pulls libopusgpu.so in through its rpath
+    L.opus_get_version_string.restype = ctypes.c_char_p
+    assert b"gfx950" in L.opus_get_version_string()
+    toc = (ctypes.c_ubyte * 2)(0xFC, 0)
+    assert L.opus_packet_get_samples_per_frame(toc, 48000) == 960 and L.opus_packet_get_nb_frames(toc, 2) == 1

@@ -129,10 +129,10 @@ def test_config5_mixed_shard_on_one_gpu(ca):
     rng = np.random.default_rng(5)
     pcm = rng.integers(-8192, 8192, size=(F, 960, 2), dtype=np.int16)
     d = torch.from_numpy(pcm).cuda()
-    bi, ni, st = (torch.from_numpy(np.ascontiguousarray(rec[k])).cuda() for k in ("burg_in", "nsq_in", "nsq_state_in"))
+    bi, ni, st = (torch.from_numpy(np.array(rec[k])).cuda() for k in ("burg_in", "nsq_in", "nsq_state_in"))
     side = torch.cuda.Stream()
     for _ in range(2):                      # twice: the second pass runs with both workspaces already allocated
-        st.copy_(torch.from_numpy(np.ascontiguousarray(rec["nsq_state_in"])).cuda())
+        st.copy_(torch.from_numpy(np.array(rec["nsq_state_in"])).cuda())
         torch.cuda.synchronize()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

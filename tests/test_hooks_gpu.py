@@ -1,0 +1,163 @@
+"""GPU tier: the per-call hooks of include/opusgpu_hooks.h, called with the reference's own argument lists, against the
+SAME functions of the compiled reference (oracle/_ref/libopus_ref.so; the two that are static in the reference through
+the trampolines of oracle/_ref/librefhooks.so): opus_ifft, comb_filter_const, exp_rotation1, renormalise_vector,
+silk_NSQ, silk_NSQ_del_dec. Bit-exact, including the in-place / state side effects."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import reflib
+from test_hooks_layout import header_defines
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFHOOKS = os.path.join(ROOT, "oracle", "_ref", "librefhooks.so")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import torch
+    assert torch.cuda.is_available()
+    import concentus_amd
+    return concentus_amd.lib.load()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not (reflib.available() and os.path.exists(REFHOOKS)):
+        pytest.skip("oracle/_ref did not travel")
+    return reflib.lib(), C.CDLL(REFHOOKS)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_opus_ifft(L, ref):
+    r, _ = ref
+    m = reflib.mode()
+    rng = np.random.default_rng(21)
+    for k in range(4):
+        st = m.mdct.kfft[k]
+        n = 480 >> k
+        fin = rng.integers(-(1 << 24), 1 << 24, size=(n, 2), dtype=np.int32)
+        want = np.zeros((n, 2), np.int32)
+        r.opus_ifft_c(st, p(fin), p(want))
+        got = np.zeros((n, 2), np.int32)
+        L.opusgpu_opus_ifft(st, p(fin), p(got))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(got, want), k
+    L.opusgpu_opus_ifft(m.mdct.kfft[0], p(fin), p(fin))                # in place: rejected like the reference's assert
+    assert L.opusgpu_get_last_error() == -1
+
+
+def test_comb_filter_const(L, ref):
+    _, h = ref
+    rng = np.random.default_rng(22)
+    for T, N, g in ((15, 960, (9830, 7000, 4200)), (1022, 960, (-15000, 8784, 0)), (300, 840, (26208, 3280, 0)), (77, 5, (1, 2, 3))):
+        buf = rng.integers(-(1 << 27), 1 << 27, size=T + 2 + N + 8, dtype=np.int32)
+        # separate output (the encoder's pre-filter): pure FIR
+        y0 = np.zeros(N, np.int32)
+        x = buf.copy()
+        h.refhook_comb_filter_const(p(y0), C.c_void_p(x.ctypes.data + 4 * (T + 2)), T, N, *g)
+        y1 = np.zeros(N, np.int32)
+        x1 = buf.copy()
+        L.opusgpu_comb_filter_const(p(y1), C.c_void_p(x1.ctypes.data + 4 * (T + 2)), T, N, *g)
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(y1, y0) and np.array_equal(x1, buf), (T, N)
+        # in place (the decoder's post-filter): recursive through the samples already filtered
+        a, b = buf.copy(), buf.copy()
+        pa, pb = C.c_void_p(a.ctypes.data + 4 * (T + 2)), C.c_void_p(b.ctypes.data + 4 * (T + 2))
+        h.refhook_comb_filter_const(pa, pa, T, N, *g)
+        L.opusgpu_comb_filter_const(pb, pb, T, N, *g)
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(a, b), (T, N, "in place")
+    a = buf.copy()
+    L.opusgpu_comb_filter_const(C.c_void_p(a.ctypes.data + 4 * 10), C.c_void_p(a.ctypes.data + 4 * 100), 50, 60, 1, 2, 3)
+    assert L.opusgpu_get_last_error() == -1                             # partially overlapping spans
+
+
+def test_exp_rotation1(L, ref):
+    _, h = ref
+    rng = np.random.default_rng(23)
+    for n, stride in ((8, 1), (16, 1), (24, 3), (48, 1), (96, 4), (176, 1), (176, 13), (144, 8), (5, 4), (3, 1), (64, 63)):
+        X = rng.integers(-16384, 16384, size=n, dtype=np.int16)
+        c, s = int(rng.integers(1, 32767)), int(rng.integers(-32767, 32767))
+        a, b = X.copy(), X.copy()
+        h.refhook_exp_rotation1(p(a), n, stride, c, s)
+        L.opusgpu_exp_rotation1(p(b), n, stride, c, s)
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(a, b), (n, stride)
+
+
+def test_renormalise_vector(L, ref):
+    r, _ = ref
+    rng = np.random.default_rng(24)
+    for n in (2, 8, 13, 24, 96, 176, 960):
+        for amp, gain in ((16000, 32767), (300, 32767), (16000, 23170), (3, 12345)):
+            X = rng.integers(-amp, amp + 1, size=n, dtype=np.int16)
+            a, b = X.copy(), X.copy()
+            r.renormalise_vector(p(a), n, gain, 0)
+            L.opusgpu_renormalise_vector(p(b), n, gain, 0)
+            assert L.opusgpu_get_last_error() == 0
+            assert np.array_equal(a, b), (n, amp, gain)
+
+
+def _ref_structs(rec_in, dd):
+    """The reference's silk_encoder_state / SideInfoIndices (zeroed, only the fields the quantisers read are set, at the
+    offsets of include/opusgpu_hooks.h) from one function-boundary record."""
+    d = header_defines()
+    hdr = rec_in[:48].view(np.int32)          # nb_subfr, subfr_length, frame_length, ltp_mem_length, predictLPCOrder, shapingLPCOrder, signalType, quantOffsetType, NLSFInterpCoef_Q2, Seed, Lambda_Q10, LTP_scale_Q14
+    enc = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE"], np.uint8)
+    for off, v in ((d["OPUSGPU_REF_OFF_NB_SUBFR"], hdr[0]), (d["OPUSGPU_REF_OFF_SUBFR_LENGTH"], hdr[1]),
+                   (d["OPUSGPU_REF_OFF_FRAME_LENGTH"], hdr[2]), (d["OPUSGPU_REF_OFF_LTP_MEM_LENGTH"], hdr[3]),
+                   (d["OPUSGPU_REF_OFF_PREDICT_LPC_ORDER"], hdr[4]), (d["OPUSGPU_REF_OFF_SHAPING_LPC_ORDER"], hdr[5])):
+        enc[off:off + 4].view(np.int32)[0] = v
+    if dd is not None:
+        enc[d["OPUSGPU_REF_OFF_N_STATES_DEL_DEC"]:][:4].view(np.int32)[0] = dd[0]
+        enc[d["OPUSGPU_REF_OFF_WARPING_Q16"]:][:4].view(np.int32)[0] = dd[1]
+    idx = np.zeros(d["OPUSGPU_REF_SIZEOF_SIDE_INFO_INDICES"], np.int8)
+    idx[d["OPUSGPU_REF_OFF_SIGNAL_TYPE"]] = hdr[6]
+    idx[d["OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE"]] = hdr[7]
+    idx[d["OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2"]] = hdr[8]
+    idx[d["OPUSGPU_REF_OFF_SEED"]] = hdr[9]
+    return enc, idx, int(hdr[10]), int(hdr[11])
+
+
+def _arrays(rec_in):
+    i32 = lambda lo, n: np.ascontiguousarray(rec_in[lo:lo + 4 * n].view(np.int32))
+    harm, tilt, lf, gains, pitch = (i32(48 + 16 * k, 4) for k in range(5))
+    x_Q3 = i32(128, 320)
+    i16 = lambda lo, n: np.ascontiguousarray(rec_in[lo:lo + 2 * n].view(np.int16))
+    return x_Q3, i16(1408, 32), i16(1472, 20), i16(1512, 64), harm, tilt, lf, gains, pitch
+
+
+@pytest.mark.parametrize("which", ["nsq", "del_dec"])
+def test_silk_nsq_hooks_with_the_reference_argument_list(L, ref, which):
+    r, _ = ref
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz" if which == "nsq" else "silk_dd_golden.npz"))
+    key = "silk_nsq_" if which == "nsq" else "silk_dd_"
+    rin = gold["silk_nsq_in" if which == "nsq" else "silk_dd_in"]
+    st_in = gold[key + "state_in"]
+    fn_ref = r.silk_NSQ_c if which == "nsq" else r.silk_NSQ_del_dec_c
+    fn_gpu = L.opusgpu_silk_NSQ if which == "nsq" else L.opusgpu_silk_NSQ_del_dec
+    for k in range(0, rin.shape[0], 5):
+        rec = np.ascontiguousarray(rin[k])
+        dd = None if which == "nsq" else rec[1640:1648].view(np.int32)
+        x_Q3, pred, ltp, ar2, harm, tilt, lf, gains, pitch = _arrays(rec)
+        out = []
+        for fn in (fn_ref, fn_gpu):
+            enc, idx, lam, ltps = _ref_structs(rec, dd)
+            st = np.ascontiguousarray(st_in[k]).copy()
+            pulses = np.zeros(320, np.int8)
+            fn(p(enc), p(st), p(idx), p(x_Q3), p(pulses), p(pred), p(ltp), p(ar2), p(harm), p(tilt), p(lf), p(gains), p(pitch),
+               C.c_int(lam), C.c_int(ltps))
+            out.append((st, pulses, idx))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(out[0][1], out[1][1]), (which, k, "pulses")
+        assert np.array_equal(out[0][0], out[1][0]), (which, k, "silk_nsq_state")
+        assert np.array_equal(out[0][2], out[1][2]), (which, k, "SideInfoIndices (Seed)")
+        if which == "nsq":
+            assert np.array_equal(out[1][1].view(np.uint8), gold["silk_nsq_out"][k])

@@ -1,0 +1,45 @@
+"""CPU tier: the struct offsets hard-coded in include/opusgpu_hooks.h (the SILK per-call hooks read a few fields through
+the reference's own silk_encoder_state / SideInfoIndices pointers) against the reference's headers: oracle/Makefile
+compiles oracle/ref_layout_probe.c against opus-fix/silk/structs.h and writes oracle/_ref/layout.json."""
+import json
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAYOUT = os.path.join(ROOT, "oracle", "_ref", "layout.json")
+
+PAIRS = {
+    "OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE": "sizeof.silk_encoder_state",
+    "OPUSGPU_REF_OFF_NB_SUBFR": "silk_encoder_state.nb_subfr",
+    "OPUSGPU_REF_OFF_FRAME_LENGTH": "silk_encoder_state.frame_length",
+    "OPUSGPU_REF_OFF_SUBFR_LENGTH": "silk_encoder_state.subfr_length",
+    "OPUSGPU_REF_OFF_LTP_MEM_LENGTH": "silk_encoder_state.ltp_mem_length",
+    "OPUSGPU_REF_OFF_N_STATES_DEL_DEC": "silk_encoder_state.nStatesDelayedDecision",
+    "OPUSGPU_REF_OFF_SHAPING_LPC_ORDER": "silk_encoder_state.shapingLPCOrder",
+    "OPUSGPU_REF_OFF_PREDICT_LPC_ORDER": "silk_encoder_state.predictLPCOrder",
+    "OPUSGPU_REF_OFF_WARPING_Q16": "silk_encoder_state.warping_Q16",
+    "OPUSGPU_REF_SIZEOF_SIDE_INFO_INDICES": "sizeof.SideInfoIndices",
+    "OPUSGPU_REF_OFF_SIGNAL_TYPE": "SideInfoIndices.signalType",
+    "OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE": "SideInfoIndices.quantOffsetType",
+    "OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2": "SideInfoIndices.NLSFInterpCoef_Q2",
+    "OPUSGPU_REF_OFF_SEED": "SideInfoIndices.Seed",
+}
+
+
+def header_defines():
+    src = open(os.path.join(ROOT, "include", "opusgpu_hooks.h")).read()
+    return {k: int(v) for k, v in re.findall(r"#define\s+(OPUSGPU_REF_\w+)\s+(\d+)", src)}
+
+
+@pytest.mark.ref
+def test_hook_struct_offsets_match_the_reference_headers():
+    if not os.path.exists(LAYOUT):
+        pytest.skip("oracle/_ref/layout.json not built")
+    ref = json.load(open(LAYOUT))
+    have = header_defines()
+    assert set(have) == set(PAIRS)
+    for macro, key in PAIRS.items():
+        assert have[macro] == ref[key], (macro, have[macro], ref[key])
+    assert ref["sizeof.silk_nsq_state"] == 4380          # == sizeof(opusgpu_nsq_state), include/opusgpu_silk.h

@@ -24,7 +24,7 @@ def ca():
 
 def _dev(a):
     import torch
-    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return torch.from_numpy(np.array(a)).cuda()
 
 
 def _run_gpu(ca, rec):
