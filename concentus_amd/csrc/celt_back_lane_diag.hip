@@ -19,9 +19,9 @@ __global__ __launch_bounds__(64) void celt_back_lane_diag_kernel(opusgpu_celt_co
     const int n = blockIdx.x * 64 + threadIdx.x;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = g_lds_pvq16 + threadIdx.x;
-    F.lds_pvq32 = g_lds_pvq32 + threadIdx.x;
-    F.lds_xs = g_lds_xs + threadIdx.x;
+    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + threadIdx.x);
+    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + threadIdx.x);
+    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + threadIdx.x);
     unsigned long long acc[NSTAGES];
     for (int k = 0; k < NSTAGES; k++) acc[k] = 0;
     StageClock clk;

@@ -29,9 +29,31 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_c
     const int n = blockIdx.x * 64 + slot;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = g_lds_pvq16 + slot;
-    F.lds_pvq32 = g_lds_pvq32 + slot;
-    F.lds_xs = g_lds_xs + slot;
+    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
+    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
+    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + slot);
+    opusgpu_celt_state *st = states ? states + n : nullptr;
+    FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
+    out_len[n] = r.bytes;
+    out_rng[n] = r.final_range;
+}
+
+// A = 16 with the register budget of four wavefronts per SIMD (128 VGPRs): the 64-frame workgroup is then four quarter-filled
+// wavefronts and all four workgroups a CU's LDS admits are resident at once (16 wavefronts per CU).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void celt_back_lane16_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out, int out_stride,
+                             int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+{
+    fill_lds_tables();
+    const int l = threadIdx.x & 63;
+    if (l >= 16) return;
+    const int slot = (threadIdx.x >> 6) * 16 + l;
+    const int n = blockIdx.x * 64 + slot;
+    if (n >= nframes) return;
+    BackLds F;
+    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
+    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
+    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + slot);
     opusgpu_celt_state *st = states ? states + n : nullptr;
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;
@@ -58,6 +80,7 @@ extern "C" void opusgpu_launch_back_lane(const opusgpu_celt_config *cfg, void *s
 #define CA_LAUNCH(A) hipLaunchKernelGGL(ca::celt_back_lane_kernel<A>, grid, block, 0, s, *cfg, (opusgpu_celt_state *)states, \
                                         (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n)
     if (a == 32) CA_LAUNCH(32);
+    else if (a == 16 && getenv("OPUSGPU_LANE16_OCC4")) hipLaunchKernelGGL(ca::celt_back_lane16_kernel, grid, block, 0, s, *cfg, (opusgpu_celt_state *)states, (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n);
     else if (a == 16) CA_LAUNCH(16);
     else CA_LAUNCH(64);
 #undef CA_LAUNCH

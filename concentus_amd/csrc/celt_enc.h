@@ -577,7 +577,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     const int transient_got_disabled = uni(mid->transient_got_disabled);
     RangeEnc enc;
 #if defined(CA_LANE_FRAME)
-    F.x16 = const_cast<i16 *>(mid->X);
+    F.x16 = (x16_t *)const_cast<i16 *>(mid->X);
     F.packet = out;
 #endif
     enc.buf = F.packet + 1;

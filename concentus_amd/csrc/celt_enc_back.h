@@ -369,8 +369,8 @@ CA_DEV void exp_rotation_wave(P X, int len, int stride, int K, int spread)      
 }
 
 // encode_pulses(iy, N, K) = ec_enc_uint(icwrs(N, iy), V(N,K))  (cwrs.c:440-460)
-template <class L>
-CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K, LP<i32> y)
+template <class L, class PI>
+CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K, PI y)
 {
     u32 idx;
     if (LANES == 1) {
@@ -430,26 +430,216 @@ CA_DEV void pvq_argmax(i32 &num, i32 &den, int &id)
 }
 #endif
 
-// alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build
-template <class L>
-CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spread, int B)
+#if defined(CA_LANE_FRAME)
+// ---- lane build: the leaf quantiser on this lane's LDS columns, written for the instruction stream it produces --------
+// One lane owns the leaf, 32 (or 64) leaves of different N and K share the wavefront. What costs here is (a) every
+// instruction of the wavefront's serial timeline, address arithmetic included, and (b) the trip counts of nested loops,
+// which a wavefront pays as max x max over its lanes. Hence:
+//  * columns are walked in chunks of eight elements through ONE moving pointer, so that the eight accesses of a chunk
+//    are ds_read / ds_write with immediate offsets (u * 128 bytes) instead of eight address computations;
+//  * the greedy search runs as ONE loop over (pulse, chunk) steps per lane: the wavefront pays max(pulses x chunks)
+//    instead of max(pulses) x max(chunks);
+//  * 2*iy is not stored (Ryy = yy + 2*iy[j] is one v_lshl_add), the signs of X are kept in a 64-bit mask and |X|
+//    overwrites the leaf copy in place;
+//  * icwrs runs in two passes per chunk -- the running pulse counts in registers, then all table look-ups of the chunk
+//    issued together -- instead of three dependent LDS round trips per element.
+// Arithmetic and the order of every comparison are those of vq.c:161-325 / cwrs.c:440-460.
+enum { LDS_COL = 64 };          // elements between consecutive entries of one lane's column
+
+// (i16)a * (i16)b as ONE full-rate instruction: the 24-bit multiplier on the sign-extended low halves (SDWA selects)
+CA_DEV i32 mul16x16_lo(i32 a, i32 b)
 {
-    // search state: |X|, 2*iy, iy. Lane build: leaves of up to PVQ_LDS_N elements keep it in LDS.
-#if defined(CA_LANE_FRAME)
-    const bool in_lds = N <= PVQ_LDS_N;
-    LP<i16> y = in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.pvq.y, 1);
-    LP<i16> xa = in_lds ? lp_make(F.lds_pvq16 + PVQ_LDS_N * 64, 64) : lp_make((i16 *)F.s.pvq.xabs, 1);
-    LP<i32> iy = in_lds ? lp_make(F.lds_pvq32, 64) : lp_make((i32 *)F.s.pvq.iy, 1);
-#else
-    i16 *y = F.s.pvq.y, *xa = F.s.pvq.xabs;
-    i32 *iy = F.s.pvq.iy;
+    i32 r;
+    asm("v_mul_i32_i24_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0"
+        : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+CA_DEV u32 pvq_u_lds(int n, int k)
+{
+    const int lo = n < k ? n : k, hi = n < k ? k : n;
+    return CLT_pvq_u_data[CLT_pvq_u_row[lo] + hi];
+}
+
+template <class L>
+CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B)
+{
+    CA_AS_LDS i16 *const X = F.lds_xs;                 // the leaf (copied by the caller), becomes |X|
+    CA_AS_LDS i32 *const iy = F.lds_pvq32;
+    CA_STAMP_F(F, 22);
+    exp_rotation_wave(lds_col(X), N, B, K, spread);
+    CA_STAMP_F(F, 17);
+    const int nch = (N + 7) >> 3;
+    // |X| in place, sign mask, iy = 0, sum |X|; slots past N (up to the next multiple of eight) are zeroed
+    unsigned long long neg = 0;                         // bit j: X[j] <= 0  (signx of vq.c:189-199)
+    i32 sum = 0;
+    {
+        CA_AS_LDS i16 *qx = X;
+        CA_AS_LDS i32 *qi = iy;
+        for (int c = 0; c < nch; c++, qx += 8 * LDS_COL, qi += 8 * LDS_COL) {
+            i32 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = qx[u * LDS_COL];
+            unsigned m = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool in = c * 8 + u < N;
+                m |= (unsigned)(in && v[u] <= 0) << u;
+                const i32 a = in ? (i32)(i16)(v[u] > 0 ? v[u] : -v[u]) : 0;
+                sum += a;
+                qx[u * LDS_COL] = (i16)a;
+                qi[u * LDS_COL] = 0;
+            }
+            neg |= (unsigned long long)m << (c * 8);
+        }
+    }
+    i32 xy = 0, yy = 0;
+    int pulsesLeft = K;
+    if (K > (N >> 1)) {
+        if (sum <= K) {
+            CA_AS_LDS i16 *qx = X;
+            for (int c = 0; c < nch; c++, qx += 8 * LDS_COL)
+#pragma unroll
+                for (int u = 0; u < 8; u++) qx[u * LDS_COL] = 0;
+            X[0] = 16384;
+            sum = 16384;
+        }
+        const i32 rcp = (i16)mul16_32_q16((i16)(K - 1), celt_rcp(sum));
+        i32 pyy = 0, ppl = 0;
+        CA_AS_LDS i16 *qx = X;
+        CA_AS_LDS i32 *qi = iy;
+        for (int c = 0; c < nch; c++, qx += 8 * LDS_COL, qi += 8 * LDS_COL) {
+            i32 a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = qx[u * LDS_COL];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i32 q = mul16_16_q15(a[u], rcp);           // pad slots hold 0 -> q = 0
+                qi[u * LDS_COL] = q;
+                const i32 yj = (i16)q;
+                pyy = mac16_16(pyy, yj, yj);
+                xy = mac16_16(xy, a[u], yj);
+                ppl += q;
+            }
+        }
+        yy = (i16)pyy;
+        pulsesLeft -= ppl;
+    }
+    if (pulsesLeft > N + 3) {
+        const i32 tmp = (i16)pulsesLeft;
+        const i32 y0 = (i16)(2 * iy[0]);
+        yy = (i16)mac16_16(yy, tmp, tmp);
+        yy = (i16)mac16_16(yy, tmp, y0);
+        iy[0] = iy[0] + pulsesLeft;
+        pulsesLeft = 0;
+    }
+    CA_STAMP_F(F, 18);
+    // greedy search (vq.c:259-306): steps = pulses x chunks, one chunk of eight positions per step
+    {
+        const int steps = pulsesLeft * nch;
+        int i = 0, c = 0, rshift = 0;
+        i32 best_num = 0, best_den = 0;
+        int best_id = 0;
+        CA_AS_LDS i16 *qx = X;
+        CA_AS_LDS i32 *qi = iy;
+        for (int s = 0; s < steps; s++) {
+            if (c == 0) {
+                rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
+                yy = (i16)add32(yy, 1);
+                best_num = -32767;
+                best_den = 0;
+                best_id = 0;
+                qx = X;
+                qi = iy;
+            }
+            i32 a[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u] = qx[u * LDS_COL]; w[u] = qi[u * LDS_COL]; }
+            int best_u = -1;                            // position inside this chunk of the best candidate so far, if it is here
+            const int rem = N - c * 8;                  // positions u < rem of this chunk exist
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                // Rxy, Ryy, best_num, best_den are 16-bit quantities of the reference (opus_val16); they are kept here
+                // WITHOUT the truncating sign extension and every consumer reads their low half sign-extended (SDWA), which
+                // is the same number. Both cross products are 16 x 16 bit: the full-rate 24-bit multiplier, stated as such --
+                // left to itself the compiler loses the operand ranges through the loop-carried best_* and emits quarter-rate
+                // v_mul_lo_u32. No short-circuit either: a branch per position costs more than the multiplies it would skip.
+                const i32 t = add32(xy, a[u]) >> rshift;
+                const i32 Rxy = mul16x16_lo(t, t) >> 15;
+                const i32 Ryy = yy + 2 * w[u];
+                const bool take = (u < rem) & (mul16x16_lo(best_den, Rxy) > mul16x16_lo(Ryy, best_num));
+                best_den = take ? Ryy : best_den;
+                best_num = take ? Rxy : best_num;
+                best_u = take ? u : best_u;
+            }
+            best_id = best_u >= 0 ? c * 8 + best_u : best_id;
+            qx += 8 * LDS_COL;
+            qi += 8 * LDS_COL;
+            if (++c == nch) {
+                const i32 wb = iy[best_id * LDS_COL];
+                xy = add32(xy, (i32)X[best_id * LDS_COL]);
+                yy = add16(yy, (i16)(2 * wb));
+                iy[best_id * LDS_COL] = wb + 1;
+                c = 0;
+                i++;
+            }
+        }
+    }
+    CA_STAMP_F(F, 19);
+    // encode_pulses: icwrs(N, y) with y[j] = neg[j] ? -iy[j] : iy[j]  (cwrs.c:440-460), walked from the last element down
+    u32 idx;
+    {
+        int j = N - 1;
+        i32 k = iy[j * LDS_COL];
+        idx = (u32)((neg >> j) & 1 && k != 0);
+        // element j contributes U(N-j, k_after_previous) and, if negative, U(N-j, k_including_it + 1)
+        while (j > 0) {
+            const int j0 = j - 1;                      // highest element of this chunk
+            int n8 = j0 + 1 < 8 ? j0 + 1 : 8;          // elements j0, j0-1, ..., j0-n8+1
+            i32 mag[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) mag[u] = u < n8 ? iy[(j0 - u) * LDS_COL] : 0;
+            u32 r1[8], r2[8];
+            int kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                kk[u] = k;                              // pulses in the elements above this one
+                k += mag[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int n = N - (j0 - u);
+                r1[u] = u < n8 ? pvq_u_lds(n, kk[u]) : 0u;
+                const bool ng = u < n8 && mag[u] != 0 && ((neg >> (j0 - u)) & 1);
+                r2[u] = ng ? pvq_u_lds(n, kk[u] + mag[u] + 1) : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) idx += r1[u] + r2[u];
+            j -= n8;
+        }
+    }
+    const u32 V = pvq_u_lds(N, K) + pvq_u_lds(N, K + 1);
+    ec_enc_uint(ec, idx, V);
+    CA_STAMP_F(F, 20);
+}
 #endif
+
+// alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build.
+// The body is a template over where the leaf X and the search state (2*iy, |X|, iy) live: plain pointers into the
+// wave's LDS struct (wave build, host emulation); in the lane build either this lane's columns of the workgroup's LDS
+// scratch (leaves of up to PVQ_LDS_N bins: typed LdsCol accessors -> ds_read / ds_write) or, for the rare larger leaf,
+// private memory and the frame's own row in HBM.
+template <class L, class PX, class PY, class PI>
+CA_DEVFN void alg_quant_body(L &F, RangeEnc &ec, PX X, PY y, PY xa, PI iy, int N, int K, int spread, int B);
+
+template <class L>
+CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, x16_t *Xg, int N, int K, int spread, int B)
+{
 #if defined(CA_LANE_FRAME)
-    // leaves of up to PVQ_LDS_N bins are rotated, searched and sign-fixed on an LDS copy ([element][lane]); the
-    // encoder never reads X again after coding it, so nothing is copied back
-    LP<i16> X = lp_make(Xg, 1);
-    if (in_lds) {
-        LP<i16> st = lp_make(F.lds_xs, 64);
+    if (N <= PVQ_LDS_N) {
+        // leaves of up to PVQ_LDS_N bins are rotated, searched and sign-fixed on an LDS copy ([element][lane]); the
+        // encoder never reads X again after coding it, so nothing is copied back
+        LdsCol<i16> st = lds_col(F.lds_xs);
         if (((uintptr_t)Xg & 15) == 0) {
             // 16-byte aligned leaf: whole groups of eight bins per load (a group may reach past the leaf into the
             // following bins of the same frame; they are loaded, not used)
@@ -470,11 +660,18 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spre
                     if (k + u < N) st[k + u] = (i16)v[u];
             }
         }
-        X = st;
+        alg_quant_lane(F, ec, N, K, spread, B);
+    } else {
+        alg_quant_body(F, ec, Xg, priv((i16 *)F.s.pvq.y), priv((i16 *)F.s.pvq.xabs), priv((i32 *)F.s.pvq.iy), N, K, spread, B);
     }
 #else
-    i16 *X = Xg;
+    alg_quant_body(F, ec, Xg, (i16 *)F.s.pvq.y, (i16 *)F.s.pvq.xabs, (i32 *)F.s.pvq.iy, N, K, spread, B);
 #endif
+}
+
+template <class L, class PX, class PY, class PI>
+CA_DEVFN void alg_quant_body(L &F, RangeEnc &ec, PX X, PY y, PY xa, PI iy, int N, int K, int spread, int B)
+{
     CA_STAMP_F(F, 22);
     CA_COUNT("leaf.N", N);
     CA_COUNT("leaf.K", K);
@@ -560,7 +757,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, i16 *Xg, int N, int K, int spre
     CA_STAMP_F(F, 20);
 }
 
-CA_DEV int stereo_itheta_wave(const i16 *X, const i16 *Y, int stereo, int N)               // vq.c:376-408
+CA_DEV int stereo_itheta_wave(const x16_t *X, const x16_t *Y, int stereo, int N)               // vq.c:376-408
 {
     i32 pm = 0, ps = 0;
 #if defined(CA_LANE_FRAME)
@@ -615,7 +812,7 @@ struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
 
 // compute_theta (bands.c:645-817), encode = 1
 template <class L>
-CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i16 *Y, int N, int *b, int B,
+CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X, x16_t *Y, int N, int *b, int B,
                                      int B0, int LM, int stereo)
 {
     (void)B;
@@ -734,9 +931,9 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *X, i
     return sc;
 }
 
-CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i16 *Y)     // bands.c:819-862
+CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const x16_t *X, const x16_t *Y)     // bands.c:819-862
 {
-    const i16 *x = X;
+    const x16_t *x = X;
     for (int c = 0; c < (Y ? 2 : 1); c++) {
         if (ctx.remaining_bits >= 1 << BITRES) {
             ec_enc_bits(ec, (u32)(uni((i32)x[0]) < 0), 1);
@@ -746,16 +943,10 @@ CA_DEV void quant_band_n1_wave(RangeEnc &ec, BandCtx &ctx, const i16 *X, const i
     }
 }
 
-template <class L>
-CA_DEV void deinterleave_hadamard_wave(L &F, i16 *X, int N0, int stride, int hadamard)   // bands.c:524-549
+template <class PT>
+CA_DEV void deinterleave_hadamard_via(x16_t *X, PT tmp, int N0, int stride, int hadamard)   // bands.c:524-549
 {
     const int N = N0 * stride;
-#if defined(CA_LANE_FRAME)
-    // the PVQ search scratch is idle here: bands of up to 2*PVQ_LDS_N bins bounce through its LDS copy
-    LP<i16> tmp = N <= 2 * PVQ_LDS_N ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.pvq.xabs, 1);
-#else
-    i16 *tmp = F.s.pvq.xabs;
-#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
     if (LANES == 1) {
         // one lane owns the frame: walk the N outputs flat, eight loads in flight before the first store
@@ -786,13 +977,25 @@ CA_DEV void deinterleave_hadamard_wave(L &F, i16 *X, int N0, int stride, int had
     wave_sync();
 }
 
+template <class L>
+CA_DEV void deinterleave_hadamard_wave(L &F, x16_t *X, int N0, int stride, int hadamard)
+{
+#if defined(CA_LANE_FRAME)
+    // the PVQ search scratch is idle here: bands of up to 2*PVQ_LDS_N bins bounce through its LDS copy
+    if (N0 * stride <= 2 * PVQ_LDS_N) deinterleave_hadamard_via(X, lds_col(F.lds_pvq16), N0, stride, hadamard);
+    else deinterleave_hadamard_via(X, priv((i16 *)F.s.pvq.xabs), N0, stride, hadamard);
+#else
+    deinterleave_hadamard_via(X, (i16 *)F.s.pvq.xabs, N0, stride, hadamard);
+#endif
+}
+
 // quant_band (bands.c:1044-1174) + quant_partition (bands.c:864-1042), encode only, no lowband.
 // The reference recurses (a partition splits into two half-size partitions, LM 3 -> -1, depth <= 4); here
 // the recursion is an explicit depth-first walk: when a node splits, its second child is parked in a
 // 4-entry LDS stack (F.pstack) and revived -- with the re-balanced bit budget, bands.c:961-981 -- once the
 // first child's subtree has been coded. One call site of alg_quant, no device-side recursion.
 template <class L>
-CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N, int b, int B, int LM)
+CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM)
 {
     CA_STAMP_F(F, 22);
     CA_COUNT("quant_band", N);
@@ -811,9 +1014,9 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
     // idle per-lane scratch in LDS (all bands but the last fit: N <= LANE_SCRATCH_N = 144) with 16-byte loads, transformed
     // there, and written back once, in output order, with 16-byte stores.
     if (N <= LANE_SCRATCH_N && (N & 7) == 0 && (recombine > 0 || B > 1 || ((N_B & 1) == 0 && tf_change < 0))) {
-        LP<i16> T = lp_make(F.lds_pvq16, 64);
+        LdsCol<i16> T = lds_col(F.lds_pvq16);
         for (int k = 0; k < N; k += 8) {
-            const int4 v = *reinterpret_cast<const int4 *>(Xband + k);
+            const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
             T[k + 0] = (i16)v.x; T[k + 1] = (i16)(v.x >> 16); T[k + 2] = (i16)v.y; T[k + 3] = (i16)(v.y >> 16);
             T[k + 4] = (i16)v.z; T[k + 5] = (i16)(v.z >> 16); T[k + 6] = (i16)v.w; T[k + 7] = (i16)(v.w >> 16);
         }
@@ -847,10 +1050,10 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
                     if (stride > 1 && longBlocks && d < stride) { sidx = 0; while (ordery[sidx] != d) sidx++; }
                 }
             }
-            int4 v;
+            v4i v;
             v.x = (i32)(w[0] | (w[1] << 16)); v.y = (i32)(w[2] | (w[3] << 16));
             v.z = (i32)(w[4] | (w[5] << 16)); v.w = (i32)(w[6] | (w[7] << 16));
-            *reinterpret_cast<int4 *>(Xband + k) = v;
+            *reinterpret_cast<CA_AS_GLB v4i *>(Xband + k) = v;
         }
         wave_sync();
         recombine = 0;
@@ -883,10 +1086,10 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
         // descend: split until the current node is a leaf. Written as an inner loop so that, in the
         // lane-per-frame build, the lanes of a wavefront split together and then code their leaves together.
         while (LM != -1 && N > 2 && b > pulse_cache_max(ctx.i, LM) + 12) {
-            i16 *X = Xband + xoff;
+            x16_t *X = Xband + xoff;
             const int B0 = B;
             N >>= 1;
-            i16 *Y = X + N;
+            x16_t *Y = X + N;
             LM -= 1;
             B = (B + 1) >> 1;
             SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B0, LM, 0);
@@ -917,7 +1120,7 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, i16 *Xband, int N,
             if (!mid_first) xoff += N;
             b = mid_first ? mbits : sbits;
         }
-        i16 *X = Xband + xoff;
+        x16_t *X = Xband + xoff;
         // leaf: the basic no-split case (bands.c:983-1039)
         int q = bits2pulses(ctx.i, LM, b);
         CA_COUNT(q ? "node.leaf" : "node.leaf_q0", N);
@@ -952,14 +1155,14 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
 {
     const int LM = LM3, M = M8;
     const int B = shortBlocks ? M : 1;
-    i16 *X_ = frame_X(F), *Y_ = C == 2 ? X_ + FRAME : nullptr;
+    x16_t *X_ = frame_X(F), *Y_ = C == 2 ? X_ + FRAME : nullptr;
     BandCtx ctx;
     ctx.intensity = intensity;
     ctx.spread = spread;
     for (int i = 0; i < NB; i++) {
         ctx.i = i;
-        i16 *X = X_ + M * CLT_eband5ms[i];
-        i16 *Y = Y_ ? Y_ + M * CLT_eband5ms[i] : nullptr;
+        x16_t *X = X_ + M * CLT_eband5ms[i];
+        x16_t *Y = Y_ ? Y_ + M * CLT_eband5ms[i] : nullptr;
         const int N = M * CLT_eband5ms[i + 1] - M * CLT_eband5ms[i];
         i32 tell = (i32)ec_tell_frac(ec);
         if (i != 0) balance -= tell;
@@ -977,7 +1180,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
 
         // plan the jobs
         int njobs = 0, rebal = 0, allow2 = 0;
-        i16 *jx0 = X, *jx1 = Y;
+        x16_t *jx0 = X, *jx1 = Y;
         int jb0 = b, jb1 = 0;
         if (dual_stereo) {
             njobs = 2; jb0 = b / 2; jb1 = b / 2;
@@ -993,7 +1196,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
                     mbits -= sbits;
                     const int c = itheta > 8192;
                     ctx.remaining_bits -= sc.qalloc + sbits;
-                    i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
+                    x16_t *x2 = c ? Y : X, *y2 = c ? X : Y;
                     if (sbits) {
                         int sign = (uni((i32)x2[0]) * uni((i32)y2[1]) - uni((i32)x2[1]) * uni((i32)y2[0])) < 0;
                         ec_enc_bits(ec, (u32)sign, 1);
@@ -1013,7 +1216,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
         }
         const i32 rebalance0 = ctx.remaining_bits;
         for (int j = 0; j < njobs; j++) {
-            i16 *jx = j == 0 ? jx0 : jx1;
+            x16_t *jx = j == 0 ? jx0 : jx1;
             int jb = j == 0 ? jb0 : jb1;
             if (j == 1 && rebal) {
                 i32 rebalance = jb0 - (rebalance0 - ctx.remaining_bits);

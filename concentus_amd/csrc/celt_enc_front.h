@@ -33,7 +33,7 @@ namespace ca {
 enum { NB = 21, OVL = 120, FRAME = 960, MAXP = 1024, MINP = 15, LM3 = 3, M8 = 8 };
 enum { SPREAD_NONE = 0, SPREAD_LIGHT = 1, SPREAD_NORMAL = 2, SPREAD_AGGRESSIVE = 3 };
 
-template <class T> CA_DEV void st0(T *p, T v) { if (lane() == 0) *p = v; }
+template <class P, class V> CA_DEV void st0(P p, V v) { if (lane() == 0) *p = v; }
 
 // ---- per-frame LDS working sets (one per wavefront) --------------------------------------------------
 // The frame is encoded by two kernels so that each phase keeps only what it needs in LDS:
@@ -67,11 +67,13 @@ struct __attribute__((aligned(16))) BackLds {
 #if defined(CA_LANE_FRAME)
     // lane-per-frame build: the working set is private memory, so the two big sequentially walked arrays
     // stay where they already are in HBM (per-lane sequential access is what the L1/L2 lines are good at)
-    i16 *x16;                      // -> FrameMid::X of this frame (transformed in place)
+    // (the pointer types carry the address space, see wave.h: reloaded from this private struct a generic pointer
+    // would turn every access into a FLAT instruction)
+    x16_t *x16;                    // -> FrameMid::X of this frame (transformed in place), HBM
     u8 *packet;                    // -> the output slab of this frame
-    i16 *lds_pvq16;                // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
-    i32 *lds_pvq32;
-    i16 *lds_xs;                   // -> this lane's column of the leaf copy of X ([element][lane])
+    CA_AS_LDS i16 *lds_pvq16;      // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
+    CA_AS_LDS i32 *lds_pvq32;
+    CA_AS_LDS i16 *lds_xs;         // -> this lane's column of the leaf copy of X ([element][lane])
 #else
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
 #endif
@@ -142,7 +144,7 @@ CA_DEV i32 *tsig(Front2Lds &F, int c) { return F.in_g + c * (FRAME + OVL); }
 CA_DEV i16 *frame_X(FrontLds &F) { return reinterpret_cast<i16 *>(&F.in[0][0]); }      // X[c*960 + j]
 CA_DEV i16 *frame_X(Front2Lds &F) { return F.x_g; }
 CA_DEV i16 *frame_pcmf(Front1Lds &F) { return reinterpret_cast<i16 *>(&F.xf[0][0]); }
-CA_DEV i16 *frame_X(BackLds &F) { return F.x16; }
+CA_DEV x16_t *frame_X(BackLds &F) { return F.x16; }
 CA_DEV i16 *frame_pcmf(FrontLds &F) { return reinterpret_cast<i16 *>(&F.xf[0][0]); }   // pcmf[c*960 + i]
 
 // Uniform per-frame scalars (identical in every lane).

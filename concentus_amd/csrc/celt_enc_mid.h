@@ -21,19 +21,19 @@ CA_DEV int iabs(int a) { return a < 0 ? -a : a; }
 // Lane build: eight consecutive bins of this lane's X (16-byte aligned: every band starts at a multiple of eight bins
 // and holds a multiple of eight) with ONE 16-byte load. A lane's row of X lies 4.7 KB from its neighbours', so every
 // load instruction costs the wavefront one cache line per lane whatever its width.
-CA_DEV void ld_bins8(const i16 *p, i32 v[8])
+CA_DEV void ld_bins8(const x16_t *p, i32 v[8])
 {
-    const int4 w = *reinterpret_cast<const int4 *>(p);
+    const v4i w = *reinterpret_cast<const CA_AS_GLB v4i *>(p);
     v[0] = (i16)w.x; v[1] = w.x >> 16; v[2] = (i16)w.y; v[3] = w.y >> 16;
     v[4] = (i16)w.z; v[5] = w.z >> 16; v[6] = (i16)w.w; v[7] = w.w >> 16;
 }
 // ... and the store of eight bins (values taken modulo 2^16)
-CA_DEV void st_bins8(i16 *p, const i32 v[8])
+CA_DEV void st_bins8(x16_t *p, const i32 v[8])
 {
-    int4 w;
+    v4i w;
     w.x = (i32)(((u32)v[0] & 0xffffu) | ((u32)v[1] << 16)); w.y = (i32)(((u32)v[2] & 0xffffu) | ((u32)v[3] << 16));
     w.z = (i32)(((u32)v[4] & 0xffffu) | ((u32)v[5] << 16)); w.w = (i32)(((u32)v[6] & 0xffffu) | ((u32)v[7] << 16));
-    *reinterpret_cast<int4 *>(p) = w;
+    *reinterpret_cast<CA_AS_GLB v4i *>(p) = w;
 }
 #endif
 
@@ -88,56 +88,71 @@ CA_DEV i32 l1_metric_wave(P tmp, int N, int LM, i32 bias)              // celt_e
     return mac16_32_q15(L1, (i16)(LM * bias), L1);
 }
 
+// One band of tf_analysis (celt_encoder.c:585-640): the band's L1 metric at every time-frequency resolution, on copies
+// of the band in tmp / tmp_1 (wherever the caller keeps them).
+template <class PT, class PT1>
+CA_DEV int tf_band_metric(const x16_t *Xb, PT tmp, PT1 tmp_1, int N, int narrow, int isTransient, i32 bias)
+{
+    const int LM = LM3;
+#if defined(CA_LANE_FRAME)
+    for (int j = 0; j < N; j += 8) {
+        i32 v[8];
+        ld_bins8(Xb + j, v);
+#pragma unroll
+        for (int u = 0; u < 8; u++) tmp[j + u] = (i16)v[u];
+    }
+#else
+    CA_UNROLL_LANE
+    for (int j = lane(); j < N; j += LANES) tmp[j] = Xb[j];
+#endif
+    wave_sync();
+    i32 L1 = l1_metric_wave(tmp, N, isTransient ? LM : 0, bias);
+    i32 best_L1 = L1;
+    int best_level = 0;
+    if (isTransient && !narrow) {
+        CA_UNROLL_LANE
+        for (int j = lane(); j < N; j += LANES) tmp_1[j] = tmp[j];
+        wave_sync();
+        haar1_wave(tmp_1, N >> LM, 1 << LM);
+        L1 = l1_metric_wave(tmp_1, N, LM + 1, bias);
+        if (L1 < best_L1) { best_L1 = L1; best_level = -1; }
+    }
+    for (int k = 0; k < LM + !(isTransient || narrow); k++) {
+        int B = isTransient ? (LM - k - 1) : (k + 1);
+        haar1_wave(tmp, N >> k, 1 << k);
+        L1 = l1_metric_wave(tmp, N, B, bias);
+        if (L1 < best_L1) { best_L1 = L1; best_level = k + 1; }
+    }
+    int metric = isTransient ? 2 * best_level : -2 * best_level;
+    if (narrow && (metric == 0 || metric == -2 * LM)) metric -= 1;
+    return metric;
+}
+
 // tf_analysis(m, len = 21, isTransient, tf_res, lambda, X, N0 = 960, LM = 3, &tf_sum, tf_estimate, tf_chan)
 template <class L>
 CA_DEVFN int tf_analysis_wave(L &F, int isTransient, int lambda, i32 tf_estimate, int tf_chan)
 {
     const int len = NB, LM = LM3;
-    const i16 *X = frame_X(F);
+    const x16_t *X = frame_X(F);
     i32 bias = (i16)mul16_16_q14(1311, imax(-4096, 8192 - tf_estimate));          // .04 Q15, -.25 Q14, .5 Q14
     for (int i = 0; i < len; i++) {
         const int width = CLT_eband5ms[i + 1] - CLT_eband5ms[i];
         const int N = width << LM, narrow = width == 1;
+        const x16_t *Xb = X + tf_chan * FRAME + (CLT_eband5ms[i] << LM);
+        int metric;
 #if defined(CA_LANE_FRAME)
         // the band is analysed in the workgroup's LDS scratch ([element][lane], LANE_SCRATCH_N slots per lane); its second
-        // copy (transient frames) too when both fit
-        const bool one_in_lds = N <= LANE_SCRATCH_N, two_in_lds = 2 * N <= LANE_SCRATCH_N;
-        LP<i16> tmp = one_in_lds ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.s.tf.tmp, 1);
-        LP<i16> tmp_1 = two_in_lds ? lp_make(F.lds_pvq16 + (LANE_SCRATCH_N / 2) * 64, 64) : lp_make((i16 *)F.s.tf.tmp1, 1);
+        // copy (transient frames) too when both fit. The accessor TYPES differ (LDS column / private array), hence the
+        // three instantiations.
+        if (2 * N <= LANE_SCRATCH_N)
+            metric = tf_band_metric(Xb, lds_col(F.lds_pvq16), lds_col(F.lds_pvq16) + LANE_SCRATCH_N / 2, N, narrow, isTransient, bias);
+        else if (N <= LANE_SCRATCH_N)
+            metric = tf_band_metric(Xb, lds_col(F.lds_pvq16), priv((i16 *)F.s.tf.tmp1), N, narrow, isTransient, bias);
+        else
+            metric = tf_band_metric(Xb, priv((i16 *)F.s.tf.tmp), priv((i16 *)F.s.tf.tmp1), N, narrow, isTransient, bias);
 #else
-        i16 *tmp = F.s.tf.tmp, *tmp_1 = F.s.tf.tmp1;
+        metric = tf_band_metric(Xb, F.s.tf.tmp, F.s.tf.tmp1, N, narrow, isTransient, bias);
 #endif
-#if defined(CA_LANE_FRAME)
-        for (int j = 0; j < N; j += 8) {
-            i32 v[8];
-            ld_bins8(X + tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j, v);
-#pragma unroll
-            for (int u = 0; u < 8; u++) tmp[j + u] = (i16)v[u];
-        }
-#else
-        CA_UNROLL_LANE
-        for (int j = lane(); j < N; j += LANES) tmp[j] = X[tf_chan * FRAME + (CLT_eband5ms[i] << LM) + j];
-#endif
-        wave_sync();
-        i32 L1 = l1_metric_wave(tmp, N, isTransient ? LM : 0, bias);
-        i32 best_L1 = L1;
-        int best_level = 0;
-        if (isTransient && !narrow) {
-            CA_UNROLL_LANE
-            for (int j = lane(); j < N; j += LANES) tmp_1[j] = tmp[j];
-            wave_sync();
-            haar1_wave(tmp_1, N >> LM, 1 << LM);
-            L1 = l1_metric_wave(tmp_1, N, LM + 1, bias);
-            if (L1 < best_L1) { best_L1 = L1; best_level = -1; }
-        }
-        for (int k = 0; k < LM + !(isTransient || narrow); k++) {
-            int B = isTransient ? (LM - k - 1) : (k + 1);
-            haar1_wave(tmp, N >> k, 1 << k);
-            L1 = l1_metric_wave(tmp, N, B, bias);
-            if (L1 < best_L1) { best_L1 = L1; best_level = k + 1; }
-        }
-        int metric = isTransient ? 2 * best_level : -2 * best_level;
-        if (narrow && (metric == 0 || metric == -2 * LM)) metric -= 1;
         st0(&F.metric[i], metric);
         wave_sync();
     }
@@ -339,14 +354,14 @@ template <class L>
 CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
 {
     const int C = fc.C, M = M8, end = NB;
-    const i16 *X = frame_X(F);
+    const x16_t *X = frame_X(F);
     int sum = 0, nbBands = 0, hf_sum = 0;
     // M*(eBands[end]-eBands[end-1]) = 176 > 8: never SPREAD_NONE by width
     for (int c = 0; c < C; c++) {
         for (int i = 0; i < end; i++) {
             const int N = M * (CLT_eband5ms[i + 1] - CLT_eband5ms[i]);
             if (N <= 8) continue;
-            const i16 *x = X + M * CLT_eband5ms[i] + c * FRAME;
+            const x16_t *x = X + M * CLT_eband5ms[i] + c * FRAME;
             i32 t = 0;                                                            // three 10-bit counters
 #if defined(CA_LANE_FRAME)
             for (int j = 0; j < N; j += 8) {
@@ -507,7 +522,7 @@ CA_DEVFN i32 dynalloc_analysis_wave(L &F, const FrameCtx &fc, int lsb_depth, int
 template <class L>
 CA_DEVFN int stereo_analysis_wave(L &F)
 {
-    const i16 *X = frame_X(F);
+    const x16_t *X = frame_X(F);
     i32 pLR = 0, pMS = 0;
     const int jend = CLT_eband5ms[13] << LM3;
 #if defined(CA_LANE_FRAME)
@@ -554,7 +569,7 @@ template <class L>
 CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int intensity)
 {
     const int C = fc.C, LM = LM3, end = NB;
-    const i16 *X = frame_X(F);
+    const x16_t *X = frame_X(F);
     i32 diff = 0;
     i32 trim = 1280;                                                                // QCONST16(5.f,8)
     if (C == 2) {

@@ -166,7 +166,42 @@ CA_DEV int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 CA_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int32_t)v); }
 #endif
 
-// LP<T>: pointer to a per-frame array. In the lane-per-frame build the hot little arrays live in LDS laid out
+}  // namespace ca
+
+// Address spaces of the lane-per-frame build. A per-frame array there lives in one of three places -- the workgroup's
+// LDS scratch ([element][lane], one column per lane), this lane's private memory, or the frame's rows in HBM -- and
+// the pointer TYPE says which: a generic pointer (the struct member reloaded from private memory has lost its
+// provenance) makes the compiler emit FLAT loads/stores, which take the slow aperture path for LDS, count as vector
+// memory AND as LDS operations and force s_waitcnt vmcnt(0) lgkmcnt(0) on every use. With the address space in the
+// type the same accesses are ds_read/ds_write, scratch_* and global_* instructions.
+//   x16_t      element of the frame's normalised-band array X: HBM (address space 1) in the lane build
+//   LdsCol<T>  one lane's column of an [element][64] LDS array (address space 3, stride 64 elements)
+//   Priv<T>    an array in this lane's private memory (stride 1)
+#if defined(CA_LANE_FRAME)
+#define CA_AS_LDS __attribute__((address_space(3)))
+#define CA_AS_GLB __attribute__((address_space(1)))
+namespace ca {
+typedef CA_AS_GLB int16_t x16_t;
+typedef int v4i __attribute__((ext_vector_type(4)));      // 16 bytes moved by one instruction through an address-space-qualified pointer
+template <class T> struct LdsCol {
+    CA_AS_LDS T *p;
+    __device__ __forceinline__ CA_AS_LDS T &operator[](int j) const { return p[j * 64]; }
+    __device__ __forceinline__ LdsCol operator+(int o) const { LdsCol r; r.p = p + o * 64; return r; }
+};
+template <class T> __device__ __forceinline__ LdsCol<T> lds_col(CA_AS_LDS T *p) { LdsCol<T> r; r.p = p; return r; }
+template <class T> struct Priv {
+    T *p;
+    __device__ __forceinline__ T &operator[](int j) const { return p[j]; }
+    __device__ __forceinline__ Priv operator+(int o) const { Priv r; r.p = p + o; return r; }
+};
+template <class T> __device__ __forceinline__ Priv<T> priv(T *p) { Priv<T> r; r.p = p; return r; }
+}
+#else
+namespace ca { typedef int16_t x16_t; }
+#endif
+
+namespace ca {
+// LP<T>: pointer to a per-frame array (decoder sources). In the lane-per-frame build the hot little arrays live in LDS laid out
 // [element][lane] (stride 64), the rest stays contiguous (stride 1): one runtime stride covers both. In the
 // other builds it is a plain pointer.
 #if defined(CA_LANE_FRAME)
