@@ -461,36 +461,39 @@ CA_DEV u32 pvq_u_lds(int n, int k)
     return CLT_pvq_u_data[CLT_pvq_u_row[lo] + hi];
 }
 
+// One lane's LDS column, in 16-bit slots (celt_lane_tables.h: 240 slots per lane): two band buffers of LANE_HALF bins
+// (bands of up to 96 bins ping-pong between them for the de-interleave; the two widest bands, 144 and 176 bins, lie
+// across both) and LANE_IYN slots of pulse counts for leaves of up to 48 bins.
+enum { LANE_HALF = 96, LANE_IY = 192, LANE_IYN = 48 };
+
+// X: the leaf, in place in the band buffer (becomes |X|); iy: N slots (rounded up to a multiple of eight) for the pulse
+// counts, bit 15 of a slot = "X[j] <= 0" (signx of vq.c:189-199; the counts stay below 2^8, and 2 * slot read as a 16-bit
+// number is 2 * count whatever bit 15 holds).
 template <class L>
-CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B)
+CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, CA_AS_LDS i16 *const X, CA_AS_LDS u16 *const iy, int N, int K, int spread, int B)
 {
-    CA_AS_LDS i16 *const X = F.lds_xs;                 // the leaf (copied by the caller), becomes |X|
-    CA_AS_LDS i32 *const iy = F.lds_pvq32;
     CA_STAMP_F(F, 22);
     exp_rotation_wave(lds_col(X), N, B, K, spread);
     CA_STAMP_F(F, 17);
     const int nch = (N + 7) >> 3;
-    // |X| in place, sign mask, iy = 0, sum |X|; slots past N (up to the next multiple of eight) are zeroed
-    unsigned long long neg = 0;                         // bit j: X[j] <= 0  (signx of vq.c:189-199)
+    // |X| in place, iy = sign flag, sum |X|; slots past N (up to the next multiple of eight) are zeroed
     i32 sum = 0;
     {
         CA_AS_LDS i16 *qx = X;
-        CA_AS_LDS i32 *qi = iy;
+        CA_AS_LDS u16 *qi = iy;
         for (int c = 0; c < nch; c++, qx += 8 * LDS_COL, qi += 8 * LDS_COL) {
             i32 v[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) v[u] = qx[u * LDS_COL];
-            unsigned m = 0;
+            const int rem = N - c * 8;
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const bool in = c * 8 + u < N;
-                m |= (unsigned)(in && v[u] <= 0) << u;
+                const bool in = u < rem;
                 const i32 a = in ? (i32)(i16)(v[u] > 0 ? v[u] : -v[u]) : 0;
                 sum += a;
                 qx[u * LDS_COL] = (i16)a;
-                qi[u * LDS_COL] = 0;
+                qi[u * LDS_COL] = (u16)((in & (v[u] <= 0)) ? 0x8000 : 0);
             }
-            neg |= (unsigned long long)m << (c * 8);
         }
     }
     i32 xy = 0, yy = 0;
@@ -507,15 +510,15 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
         const i32 rcp = (i16)mul16_32_q16((i16)(K - 1), celt_rcp(sum));
         i32 pyy = 0, ppl = 0;
         CA_AS_LDS i16 *qx = X;
-        CA_AS_LDS i32 *qi = iy;
+        CA_AS_LDS u16 *qi = iy;
         for (int c = 0; c < nch; c++, qx += 8 * LDS_COL, qi += 8 * LDS_COL) {
-            i32 a[8];
+            i32 a[8], w[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = qx[u * LDS_COL];
+            for (int u = 0; u < 8; u++) { a[u] = qx[u * LDS_COL]; w[u] = qi[u * LDS_COL]; }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const i32 q = mul16_16_q15(a[u], rcp);           // pad slots hold 0 -> q = 0
-                qi[u * LDS_COL] = q;
+                qi[u * LDS_COL] = (u16)(w[u] | q);
                 const i32 yj = (i16)q;
                 pyy = mac16_16(pyy, yj, yj);
                 xy = mac16_16(xy, a[u], yj);
@@ -527,10 +530,11 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
     }
     if (pulsesLeft > N + 3) {
         const i32 tmp = (i16)pulsesLeft;
-        const i32 y0 = (i16)(2 * iy[0]);
+        const i32 w0 = iy[0];
+        const i32 y0 = (i16)(2 * w0);
         yy = (i16)mac16_16(yy, tmp, tmp);
         yy = (i16)mac16_16(yy, tmp, y0);
-        iy[0] = iy[0] + pulsesLeft;
+        iy[0] = (u16)(w0 + pulsesLeft);
         pulsesLeft = 0;
     }
     CA_STAMP_F(F, 18);
@@ -541,7 +545,7 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
         i32 best_num = 0, best_den = 0;
         int best_id = 0;
         CA_AS_LDS i16 *qx = X;
-        CA_AS_LDS i32 *qi = iy;
+        CA_AS_LDS u16 *qi = iy;
         for (int s = 0; s < steps; s++) {
             if (c == 0) {
                 rshift = 1 + celt_ilog2(K - pulsesLeft + i + 1);
@@ -566,7 +570,7 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
                 // v_mul_lo_u32. No short-circuit either: a branch per position costs more than the multiplies it would skip.
                 const i32 t = add32(xy, a[u]) >> rshift;
                 const i32 Rxy = mul16x16_lo(t, t) >> 15;
-                const i32 Ryy = yy + 2 * w[u];
+                const i32 Ryy = yy + 2 * w[u];          // low half: yy + 2 * count (the sign flag shifts out of it)
                 const bool take = (u < rem) & (mul16x16_lo(best_den, Rxy) > mul16x16_lo(Ryy, best_num));
                 best_den = take ? Ryy : best_den;
                 best_num = take ? Rxy : best_num;
@@ -579,42 +583,57 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
                 const i32 wb = iy[best_id * LDS_COL];
                 xy = add32(xy, (i32)X[best_id * LDS_COL]);
                 yy = add16(yy, (i16)(2 * wb));
-                iy[best_id * LDS_COL] = wb + 1;
+                iy[best_id * LDS_COL] = (u16)(wb + 1);
                 c = 0;
                 i++;
             }
         }
     }
     CA_STAMP_F(F, 19);
-    // encode_pulses: icwrs(N, y) with y[j] = neg[j] ? -iy[j] : iy[j]  (cwrs.c:440-460), walked from the last element down
+    // encode_pulses: icwrs(N, y), y[j] = flag[j] ? -count[j] : count[j]  (cwrs.c:440-460), walked from the last element down
     u32 idx;
     {
         int j = N - 1;
-        i32 k = iy[j * LDS_COL];
-        idx = (u32)((neg >> j) & 1 && k != 0);
-        // element j contributes U(N-j, k_after_previous) and, if negative, U(N-j, k_including_it + 1)
+        const i32 wl = iy[j * LDS_COL];
+        i32 k = wl & 0x7fff;
+        idx = (u32)(wl > 0x8000);
+        // element e contributes U(N-e, pulses above it) and, if negative, U(N-e, pulses above it + its own + 1).
+        // Straight-line on purpose: every load of a chunk is unconditional (indices clamped into range, results masked
+        // afterwards), so that the eight count loads, then the sixteen row look-ups, then the sixteen table look-ups are
+        // each issued back to back and waited for once -- a conditional look-up becomes a branch with its own LDS round trip.
         while (j > 0) {
             const int j0 = j - 1;                      // highest element of this chunk
-            int n8 = j0 + 1 < 8 ? j0 + 1 : 8;          // elements j0, j0-1, ..., j0-n8+1
-            i32 mag[8];
+            const int n8 = j0 + 1 < 8 ? j0 + 1 : 8;    // elements j0, j0-1, ..., j0-n8+1
+            i32 wv[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) mag[u] = u < n8 ? iy[(j0 - u) * LDS_COL] : 0;
+            for (int u = 0; u < 8; u++) wv[u] = (i32)iy[(j0 - u > 0 ? j0 - u : 0) * LDS_COL];
+            int k1[8], k2[8], nn[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool in = u < n8;
+                const i32 m = in ? (wv[u] & 0x7fff) : 0;
+                nn[u] = in ? N - (j0 - u) : 1;
+                k1[u] = in ? k : 0;
+                k += m;
+                k2[u] = in ? k + 1 : 0;
+            }
+            int row1[8], row2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                row1[u] = CLT_pvq_u_row[nn[u] < k1[u] ? nn[u] : k1[u]];
+                row2[u] = CLT_pvq_u_row[nn[u] < k2[u] ? nn[u] : k2[u]];
+            }
             u32 r1[8], r2[8];
-            int kk[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                kk[u] = k;                              // pulses in the elements above this one
-                k += mag[u];
+                r1[u] = CLT_pvq_u_data[imin(row1[u] + (nn[u] < k1[u] ? k1[u] : nn[u]), 1271)];
+                r2[u] = CLT_pvq_u_data[imin(row2[u] + (nn[u] < k2[u] ? k2[u] : nn[u]), 1271)];
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int n = N - (j0 - u);
-                r1[u] = u < n8 ? pvq_u_lds(n, kk[u]) : 0u;
-                const bool ng = u < n8 && mag[u] != 0 && ((neg >> (j0 - u)) & 1);
-                r2[u] = ng ? pvq_u_lds(n, kk[u] + mag[u] + 1) : 0u;
+                const bool in = u < n8;
+                idx += (in ? r1[u] : 0u) + ((in & (wv[u] > 0x8000)) ? r2[u] : 0u);
             }
-#pragma unroll
-            for (int u = 0; u < 8; u++) idx += r1[u] + r2[u];
             j -= n8;
         }
     }
@@ -622,6 +641,7 @@ CA_DEVFN void alg_quant_lane(L &F, RangeEnc &ec, int N, int K, int spread, int B
     ec_enc_uint(ec, idx, V);
     CA_STAMP_F(F, 20);
 }
+
 #endif
 
 // alg_quant(X, N, K, spread, B, enc)  (vq.c:161-325), non-RESYNTH build.
@@ -660,7 +680,7 @@ CA_DEVFN void alg_quant_wave(L &F, RangeEnc &ec, x16_t *Xg, int N, int K, int sp
                     if (k + u < N) st[k + u] = (i16)v[u];
             }
         }
-        alg_quant_lane(F, ec, N, K, spread, B);
+        alg_quant_lane(F, ec, F.lds_xs, (CA_AS_LDS u16 *)F.lds_pvq16, N, K, spread, B);
     } else {
         alg_quant_body(F, ec, Xg, priv((i16 *)F.s.pvq.y), priv((i16 *)F.s.pvq.xabs), priv((i32 *)F.s.pvq.iy), N, K, spread, B);
     }
@@ -1146,6 +1166,226 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
     }
 }
 
+#if defined(CA_LANE_FRAME)
+// The non-stereo half of compute_theta (bands.c:645-817 with stereo == 0: the split of a partition into two halves),
+// on the band in LDS. X / Y are read, not modified.
+template <class L>
+CA_DEVFN SplitCtx split_theta_lane(L &F, RangeEnc &ec, BandCtx &ctx, CA_AS_LDS const i16 *X, CA_AS_LDS const i16 *Y, int N, int *b,
+                                   int B0, int LM)
+{
+    SplitCtx sc;
+    CA_STAMP_F(F, 22);
+    const int pulse_cap = CLT_logN400[ctx.i] + LM * (1 << BITRES);
+    const int offset = (pulse_cap >> 1) - QTHETA_OFFSET;
+    const int qn = compute_qn(N, *b, offset, pulse_cap, 0);
+    // stereo_itheta(X, Y, 0, N) (vq.c:376-408)
+    i32 pm = 0, ps = 0;
+    for (int k = 0; k < N; k += 8, X += 8 * LDS_COL, Y += 8 * LDS_COL) {
+        i32 xv[8], yv[8];
+        const int rem = N - k;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { xv[u] = X[u * LDS_COL]; yv[u] = Y[u * LDS_COL]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const i32 x = u < rem ? xv[u] : 0, y = u < rem ? yv[u] : 0;
+            pm = mac16_16(pm, x, x);
+            ps = mac16_16(ps, y, y);
+        }
+    }
+    const i32 mid = (i16)celt_sqrt(add32(1, pm)), side = (i16)celt_sqrt(add32(1, ps));
+    int itheta = mul16_16_q15(20861, celt_atan2p(side, mid));                     // QCONST16(0.63662f,15)
+    const i32 tell = (i32)ec_tell_frac(ec);
+    if (qn != 1) {
+        itheta = (itheta * qn + 8192) >> 14;
+        if (B0 > 1) {
+            ec_enc_uint(ec, (u32)itheta, (u32)(qn + 1));
+        } else {
+            const int ft = ((qn >> 1) + 1) * ((qn >> 1) + 1);
+            const int fs = itheta <= (qn >> 1) ? itheta + 1 : qn + 1 - itheta;
+            const int fl = itheta <= (qn >> 1) ? (itheta * (itheta + 1)) >> 1 : ft - (((qn + 1 - itheta) * (qn + 2 - itheta)) >> 1);
+            ec_encode(ec, (u32)fl, (u32)(fl + fs), (u32)ft);
+        }
+        itheta = (int)((u32)(itheta * 16384) / (u32)qn);
+    }
+    const int qalloc = (int)((i32)ec_tell_frac(ec) - tell);
+    *b -= qalloc;
+    int imid, iside, delta;
+    if (itheta == 0) { imid = 32767; iside = 0; delta = -16384; }
+    else if (itheta == 16384) { imid = 0; iside = 32767; delta = 16384; }
+    else {
+        imid = bitexact_cos((i16)itheta);
+        iside = bitexact_cos((i16)(16384 - itheta));
+        delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
+    }
+    CA_STAMP_F(F, 16);
+    sc.inv = 0; sc.imid = imid; sc.iside = iside; sc.delta = delta; sc.itheta = itheta; sc.qalloc = qalloc;
+    return sc;
+}
+
+// quant_band + quant_partition of the lane build: the band is pulled into this lane's LDS column ONCE (16-byte loads) and
+// everything that follows -- the haar1 levels, the de-interleave, the inner products of every split, the leaves -- works on
+// that copy with ds_read / ds_write; nothing goes back to HBM (the encoder never reads X again after coding it, bands.c
+// resynth == 0). Layout of the column: celt_enc_back.h LANE_HALF / LANE_IY. Bands of up to 96 bins de-interleave from one
+// half into the other and then have the free half for the leaf copy; the two widest bands (144 / 176 bins) lie across
+// both halves, de-interleave through their own rows in HBM and keep 64 slots for leaves of up to 32 bins. A leaf that
+// does not fit (an unsplit wide band: few pulses over many bins) is searched in private memory by the generic body.
+template <class L>
+CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM)
+{
+    CA_STAMP_F(F, 22);
+    CA_AS_LDS i16 *const S = F.lds_pvq16;                      // slot 0 of this lane's column
+    const int Nband = N;
+    int N_B = (int)((u32)N / (u32)B);
+    const int longBlocks = B == 1;
+    int tf_change = ctx.tf_change;
+    if (N == 1) { quant_band_n1_wave(ec, ctx, Xband, nullptr); return; }
+    int recombine = tf_change > 0 ? tf_change : 0;
+    CA_STAMP_F(F, 26);
+    {
+        CA_AS_LDS i16 *q = S;
+        for (int k = 0; k < N; k += 8, q += 8 * LDS_COL) {
+            const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
+            q[0 * LDS_COL] = (i16)v.x; q[1 * LDS_COL] = (i16)(v.x >> 16); q[2 * LDS_COL] = (i16)v.y; q[3 * LDS_COL] = (i16)(v.y >> 16);
+            q[4 * LDS_COL] = (i16)v.z; q[5 * LDS_COL] = (i16)(v.z >> 16); q[6 * LDS_COL] = (i16)v.w; q[7 * LDS_COL] = (i16)(v.w >> 16);
+        }
+    }
+    for (int k = 0; k < recombine; k++) haar1_wave(lds_col(S), N >> k, 1 << k);
+    CA_STAMP_F(F, 27);
+    B >>= recombine;
+    N_B <<= recombine;
+    while ((N_B & 1) == 0 && tf_change < 0) {
+        haar1_wave(lds_col(S), N_B, B);
+        B <<= 1;
+        N_B >>= 1;
+        tf_change++;
+    }
+    CA_STAMP_F(F, 28);
+    CA_AS_LDS i16 *cur = S;                                    // where the band lives from here on
+    if (B > 1) {
+        // deinterleave_hadamard (bands.c:524-549): output d*N0 + j takes input j*stride + s, d = ordery[s] for the Hadamard
+        // ordering of long blocks, d = s otherwise; walked in output order
+        const int stride = B << recombine, N0 = N_B >> recombine;
+        const u8 *ordery = CLT_ordery_table + stride - 2;
+        int d = 0, j = 0, sidx = 0;
+        if (longBlocks) { while (ordery[sidx] != 0) sidx++; }
+        const bool narrow = Nband <= LANE_HALF;
+        CA_AS_LDS i16 *dst = S + LANE_HALF * LDS_COL;
+        for (int k = 0; k < N; k += 8) {
+            u32 w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                w[u] = (u32)(u16)S[(j * stride + sidx) * LDS_COL];
+                if (++j == N0) {
+                    j = 0;
+                    d++;
+                    sidx = d;
+                    if (longBlocks && d < stride) { sidx = 0; while (ordery[sidx] != d) sidx++; }
+                }
+            }
+            if (narrow) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) dst[u * LDS_COL] = (i16)w[u];
+                dst += 8 * LDS_COL;
+            } else {
+                v4i v;
+                v.x = (i32)(w[0] | (w[1] << 16)); v.y = (i32)(w[2] | (w[3] << 16));
+                v.z = (i32)(w[4] | (w[5] << 16)); v.w = (i32)(w[6] | (w[7] << 16));
+                *reinterpret_cast<CA_AS_GLB v4i *>(Xband + k) = v;
+            }
+        }
+        if (narrow) {
+            cur = S + LANE_HALF * LDS_COL;
+        } else {
+            CA_AS_LDS i16 *q = S;
+            for (int k = 0; k < N; k += 8, q += 8 * LDS_COL) {
+                const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
+                q[0 * LDS_COL] = (i16)v.x; q[1 * LDS_COL] = (i16)(v.x >> 16); q[2 * LDS_COL] = (i16)v.y; q[3 * LDS_COL] = (i16)(v.y >> 16);
+                q[4 * LDS_COL] = (i16)v.z; q[5 * LDS_COL] = (i16)(v.z >> 16); q[6 * LDS_COL] = (i16)v.w; q[7 * LDS_COL] = (i16)(v.w >> 16);
+            }
+        }
+    }
+    CA_STAMP_F(F, 21);
+    // scratch for the leaves: copy of the leaf + pulse counts
+    const int leaf_max = Nband <= LANE_HALF ? LANE_IYN : 32;
+    CA_AS_LDS i16 *const leaf = Nband <= LANE_HALF ? (cur == S ? S + LANE_HALF * LDS_COL : S) : S + 176 * LDS_COL;
+    CA_AS_LDS u16 *const cnt = (CA_AS_LDS u16 *)(Nband <= LANE_HALF ? S + LANE_IY * LDS_COL : S + 208 * LDS_COL);
+
+    int sp = 0;
+    int xoff = 0;
+    for (;;) {
+        // descend: split until the current node is a leaf
+        while (LM != -1 && N > 2 && b > pulse_cache_max(ctx.i, LM) + 12) {
+            const int B0 = B;
+            N >>= 1;
+            LM -= 1;
+            B = (B + 1) >> 1;
+            SplitCtx sc = split_theta_lane(F, ec, ctx, cur + xoff * LDS_COL, cur + (xoff + N) * LDS_COL, N, &b, B0, LM);
+            int delta = sc.delta;
+            const int itheta = sc.itheta;
+            if (B0 > 1 && (itheta & 0x3fff)) {
+                if (itheta > 8192) delta -= delta >> (4 - LM);
+                else delta = imin(0, delta + (N << BITRES >> (5 - LM)));
+            }
+            const int mbits = imax(0, imin(b, (b - delta) / 2));
+            const int sbits = b - mbits;
+            ctx.remaining_bits -= sc.qalloc;
+            const int mid_first = mbits >= sbits;
+            i32 *fr = F.pstack[sp];
+            fr[0] = mid_first ? xoff + N : xoff;
+            fr[1] = mid_first ? sbits : mbits;
+            fr[2] = N;
+            fr[3] = B;
+            fr[4] = LM;
+            fr[5] = ctx.remaining_bits;
+            fr[6] = mid_first ? mbits : sbits;
+            fr[7] = mid_first ? (itheta != 0) : (itheta != 16384);
+            sp++;
+            if (!mid_first) xoff += N;
+            b = mid_first ? mbits : sbits;
+        }
+        // leaf: the basic no-split case (bands.c:983-1039)
+        int q = bits2pulses(ctx.i, LM, b);
+        int curr_bits = pulses2bits(ctx.i, LM, q);
+        ctx.remaining_bits -= curr_bits;
+        while (ctx.remaining_bits < 0 && q > 0) {
+            ctx.remaining_bits += curr_bits;
+            q--;
+            curr_bits = pulses2bits(ctx.i, LM, q);
+            ctx.remaining_bits -= curr_bits;
+        }
+        if (q != 0) {
+            const int K = get_pulses(q);
+            CA_AS_LDS const i16 *src = cur + xoff * LDS_COL;
+            if (N <= leaf_max) {
+                CA_AS_LDS i16 *dst = leaf;
+                for (int k = 0; k < N; k += 8, src += 8 * LDS_COL, dst += 8 * LDS_COL) {
+                    i32 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = src[u * LDS_COL];       // reads up to 7 slots past the leaf: inside the column
+#pragma unroll
+                    for (int u = 0; u < 8; u++) dst[u * LDS_COL] = (i16)v[u];
+                }
+                alg_quant_lane(F, ec, leaf, cnt, N, K, ctx.spread, B);
+            } else {
+                i16 *xb = F.xbig;
+                for (int k = 0; k < N; k++) xb[k] = src[k * LDS_COL];
+                alg_quant_body(F, ec, priv(xb), priv((i16 *)F.s.pvq.y), priv((i16 *)F.s.pvq.xabs), priv((i32 *)F.s.pvq.iy), N, K, ctx.spread, B);
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        const i32 *fr = F.pstack[sp];
+        xoff = fr[0];
+        b = fr[1];
+        N = fr[2];
+        B = fr[3];
+        LM = fr[4];
+        const i32 rebalance = fr[6] - (fr[5] - ctx.remaining_bits);
+        if (rebalance > 3 << BITRES && fr[7]) b += rebalance - (3 << BITRES);
+    }
+}
+#endif
+
 // quant_all_bands(encode = 1, start 0, end 21, LM 3)  (bands.c:1337-1502) with quant_band_stereo
 // (bands.c:1176-1335) folded in: per band up to two quant_band jobs (mid/side or L/R) run through ONE
 // call site, the second with the re-balanced budget.
@@ -1222,7 +1462,11 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
                 i32 rebalance = jb0 - (rebalance0 - ctx.remaining_bits);
                 if (rebalance > 3 << BITRES && allow2) jb += rebalance - (3 << BITRES);
             }
+#if defined(CA_LANE_FRAME)
+            quant_band_lane(F, ec, ctx, jx, N, jb, B, LM);
+#else
             quant_band_wave(F, ec, ctx, jx, N, jb, B, LM);
+#endif
         }
         balance += uni(F.pulses[i]) + tell;
     }

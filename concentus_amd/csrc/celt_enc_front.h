@@ -74,6 +74,7 @@ struct __attribute__((aligned(16))) BackLds {
     CA_AS_LDS i16 *lds_pvq16;      // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
     CA_AS_LDS i32 *lds_pvq32;
     CA_AS_LDS i16 *lds_xs;         // -> this lane's column of the leaf copy of X ([element][lane])
+    i16 xbig[176];                 // a leaf too large for the LDS column (an unsplit wide band), for the generic search
 #else
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
 #endif
