@@ -11,9 +11,13 @@
 
 namespace ca {
 
-struct __align__(16) MdctFwdLds {
-    MdctLds tab;
-    __align__(16) i32 buf[1080];      // input samples; re-used as the 960 output coefficients
+// LDS holds only the FFT scratch of the transform (480 complex points, 3 840 B): the fold reads the input samples and the
+// post-rotation writes the coefficients straight from / to HBM. Both walk their rows with 4-byte accesses at an 8-byte
+// stride from both ends (mdct.c:155-204, :237-257), so a row's cache lines are touched twice a few hundred nanoseconds
+// apart and the second touch hits L2; what that buys is LDS: 3.8 KB instead of 8.2 KB (12 KB backward) per wavefront, i.e.
+// all the wavefronts a CU can hold (limited by registers, not LDS) instead of 16, and the chain of one transform -- fold,
+// five butterfly stages, post-rotation, each an LDS round trip -- is hidden by the others.
+struct __align__(16) MdctFftLds {
     __align__(16) int2 f2[480];
 };
 
@@ -22,52 +26,38 @@ __global__ __launch_bounds__(64) void mdct_forward_kernel(const i32 *__restrict_
                                                           int ntransforms)
 {
     constexpr int B = 1 << SHIFT;
-    __shared__ MdctFwdLds S;
+    __shared__ MdctFftLds S;
     const int lane = threadIdx.x;
-    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
-    wave_sync();
+    const MdctTab T = mdct_global_tab<SHIFT>();   // 5 KB of tables: L1-resident
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
-        const int4 *src = reinterpret_cast<const int4 *>(sig + (size_t)t * 1080);
-        int4 *b4 = reinterpret_cast<int4 *>(S.buf);
-        for (int i = lane; i < 270; i += 64) b4[i] = src[i];
-        wave_sync();
-        mdct_forward_wave<SHIFT, B>(S.buf, S.f2, S.buf, 1, T, lane);
-        int4 *dst = reinterpret_cast<int4 *>(freq + (size_t)t * 960);
-        for (int i = lane; i < 240; i += 64) dst[i] = b4[i];
+        mdct_forward_wave<SHIFT, B>(sig + (size_t)t * 1080, S.f2, freq + (size_t)t * 960, 1, T, lane);
         wave_sync();
     }
 }
 
+template <int SHIFT>
+__global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *sig, int ntransforms)
+{
+    constexpr int B = 1 << SHIFT;
+    __shared__ MdctFftLds S;
+    const int lane = threadIdx.x;
+    const MdctTab T = mdct_global_tab<SHIFT>();
+    for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
+        // out[0, 60) (the previous frame's tail) is live on entry, [60, 1020) is produced, [1020, 1080) untouched (mdct.c:345-361)
+        mdct_backward_wave<SHIFT, B>(freq + (size_t)t * 960, 1, S.f2, sig + (size_t)t * 1080, T, lane);
+        wave_sync();
+    }
+}
+
+struct __align__(16) MdctFwdLds {
+    __align__(16) i32 buf[1080];      // input samples; re-used as the 960 output coefficients
+    __align__(16) int2 f2[480];
+};
 struct __align__(16) MdctBwdLds {
-    MdctLds tab;
     __align__(16) i32 coef[960];
     __align__(16) i32 out[1080];
     __align__(16) int2 f2[480];
 };
-
-template <int SHIFT>
-__global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *__restrict__ sig,
-                                                           int ntransforms)
-{
-    constexpr int B = 1 << SHIFT;
-    __shared__ MdctBwdLds S;
-    const int lane = threadIdx.x;
-    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
-    wave_sync();
-    for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
-        const int4 *src = reinterpret_cast<const int4 *>(freq + (size_t)t * 960);
-        int4 *c4 = reinterpret_cast<int4 *>(S.coef);
-        for (int i = lane; i < 240; i += 64) c4[i] = src[i];
-        // only the first 60 samples (previous tail) are live on entry (mdct.c:345-361)
-        int4 *io = reinterpret_cast<int4 *>(sig + (size_t)t * 1080);
-        int4 *o4 = reinterpret_cast<int4 *>(S.out);
-        if (lane < 15) o4[lane] = io[lane];
-        wave_sync();
-        mdct_backward_wave<SHIFT, B>(S.coef, 1, S.f2, S.out, T, lane);
-        for (int i = lane; i < 255; i += 64) io[i] = o4[i];      // 1020 samples; [1020,1080) untouched
-        wave_sync();
-    }
-}
 
 // Single transform with an arbitrary output/input stride, for the per-call RTCD-style hook.
 template <int SHIFT>
@@ -76,7 +66,7 @@ __global__ __launch_bounds__(64) void mdct_forward_single_kernel(const i32 *in, 
     __shared__ MdctFwdLds S;
     const int lane = threadIdx.x;
     constexpr int N2 = 960 >> SHIFT;
-    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
+    const MdctTab T = mdct_global_tab<SHIFT>();   // 5 KB of tables: L1-resident; a copy per one-wave workgroup in LDS would halve the wavefronts a CU holds
     for (int i = lane; i < N2 + 120; i += 64) S.buf[i] = in[i];
     wave_sync();
     mdct_forward_wave<SHIFT, 1>(S.buf, S.f2, out, stride, T, lane);
@@ -88,7 +78,7 @@ __global__ __launch_bounds__(64) void mdct_backward_single_kernel(const i32 *in,
     __shared__ MdctBwdLds S;
     const int lane = threadIdx.x;
     constexpr int N2 = 960 >> SHIFT;
-    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
+    const MdctTab T = mdct_global_tab<SHIFT>();   // 5 KB of tables: L1-resident; a copy per one-wave workgroup in LDS would halve the wavefronts a CU holds
     for (int i = lane; i < N2; i += 64) S.coef[i] = in[i * stride];
     for (int i = lane; i < 120; i += 64) S.out[i] = out[i];
     wave_sync();
@@ -99,7 +89,6 @@ __global__ __launch_bounds__(64) void mdct_backward_single_kernel(const i32 *in,
 // opus_fft_c (opus-fix/celt/kiss_fft.c:580-599): scaled, bit-reversing, out-of-place forward FFT of 480 >> SHIFT complex
 // points, one wavefront per transform; fin / fout hold [re, im] int32 pairs.
 struct __align__(16) FftLds {
-    MdctLds tab;
     __align__(16) int2 x[480];
 };
 
@@ -109,7 +98,7 @@ __global__ __launch_bounds__(64) void fft_kernel(const int2 *__restrict__ fin, i
     constexpr int NFFT = 480 >> SHIFT, SCALE_SHIFT = (8 - SHIFT) - 1;    // kiss_fft_state.scale = 17476, scale_shift = 8 - shift
     __shared__ FftLds S;
     const int lane = threadIdx.x;
-    const MdctTab T = mdct_stage_tables<SHIFT>(S.tab, lane, 64);
+    const MdctTab T = mdct_global_tab<SHIFT>();   // 5 KB of tables: L1-resident; a copy per one-wave workgroup in LDS would halve the wavefronts a CU holds
     wave_sync();
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
         const int2 *src = fin + (size_t)t * NFFT;
@@ -145,7 +134,7 @@ extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq,
     if (nt == 0) return OPUSGPU_OK;
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int grid = grid_for(nt, 12);
+    int grid = nt;        // one transform per one-wave workgroup: nothing is staged per workgroup, the dispatcher balances
     if (shift == 0) hipLaunchKernelGGL(mdct_forward_kernel<0>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
     else            hipLaunchKernelGGL(mdct_forward_kernel<3>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
     return opusgpu_check_launch();
@@ -161,7 +150,7 @@ extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig
     if (nt == 0) return OPUSGPU_OK;
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
-    int grid = grid_for(nt, 10);
+    int grid = nt;
     if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     else            hipLaunchKernelGGL(mdct_backward_kernel<3>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     return opusgpu_check_launch();
