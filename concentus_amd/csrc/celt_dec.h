@@ -22,8 +22,9 @@ enum { DEC_BUF = 2048, DEC_MEM = DEC_BUF + OVL };           // DECODE_BUFFER_SIZ
 struct __attribute__((aligned(16))) DecWork {
     i16 *X;                        // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
 #if defined(CA_LANE_FRAME)
-    i32 *lds_pvq32;                // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
-    i16 *lds_pvq16;                // -> ... of the 16-bit scratch (LANE_SCRATCH_N bins: (de)interleave, band staging)
+    // (address space in the pointer type, wave.h: a generic pointer reloaded from this private struct makes every access FLAT)
+    CA_AS_LDS i32 *lds_pvq32;      // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
+    CA_AS_LDS i16 *lds_pvq16;      // -> ... of the 16-bit scratch (LANE_SCRATCH_N bins: (de)interleave, band staging)
 #endif
     i16 norm[2 * 624];             // folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel
     i32 iy[176];
@@ -253,14 +254,25 @@ CA_DEV void renormalise_vector_dec(i16 *X, int N, i32 gain)                     
     }
 }
 
+template <class D, class PI>
+CA_DEV unsigned alg_unquant_body(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy);
+
 template <class D>
 CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain)   // vq.c:329-346
 {
 #if defined(CA_LANE_FRAME)
-    LP<i32> iy = N <= 48 ? lp_make(F.lds_pvq32, 64) : lp_make((i32 *)F.iy, 1);
+    // the pulse vector of a leaf of up to 48 bins lives in this lane's LDS column, of a larger one in private memory: two
+    // instantiations, each with the address space in its accessor type
+    if (N <= 48) return alg_unquant_body(F, X, N, K, spread, B, dec, gain, lds_col(F.lds_pvq32));
+    return alg_unquant_body(F, X, N, K, spread, B, dec, gain, priv((i32 *)F.iy));
 #else
-    i32 *iy = F.iy;
+    return alg_unquant_body(F, X, N, K, spread, B, dec, gain, (i32 *)F.iy);
 #endif
+}
+
+template <class D, class PI>
+CA_DEV unsigned alg_unquant_body(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy)
+{
     CA_STAMP_F(F, 8);
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
     u32 idx = ec_dec_uint(dec, V);
@@ -275,7 +287,7 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
         if (N <= LANE_SCRATCH_N) {
             // the leaf is scaled and un-rotated in the per-lane LDS scratch (16-bit part; iy sits in the 32-bit part) and
             // reaches X in HBM once, sixteen bytes at a time where the leaf is aligned
-            LP<i16> T = lp_make(F.lds_pvq16, 64);
+            LdsCol<i16> T = lds_col(F.lds_pvq16);
 #pragma unroll 8
             for (int i = 0; i < N; i++) T[i] = (i16)pshr32(mul16_16(g, iy[i]), k + 1);
             CA_STAMP_F(F, 5);
@@ -510,15 +522,24 @@ CA_DEV void haar1_ref(P X, int N0, int stride)                                  
     }
 }
 
+template <class PT>
+CA_DEV void deinterleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard);
+
 template <class D>
-CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)            // bands.c:524-549
+CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)
+{
+#if defined(CA_LANE_FRAME)
+    if (N0 * stride <= 96) deinterleave_hadamard_ref_via(X, lds_col(F.lds_pvq16), N0, stride, hadamard);
+    else deinterleave_hadamard_ref_via(X, priv((i16 *)F.tmp), N0, stride, hadamard);
+#else
+    deinterleave_hadamard_ref_via(X, (i16 *)F.tmp, N0, stride, hadamard);
+#endif
+}
+
+template <class PT>
+CA_DEV void deinterleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard)
 {
     const int N = N0 * stride;
-#if defined(CA_LANE_FRAME)
-    LP<i16> tmp = N <= 96 ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.tmp, 1);
-#else
-    i16 *tmp = F.tmp;
-#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
         const i16 *__restrict__ x = X;
@@ -535,15 +556,24 @@ CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hada
     }
 }
 
+template <class PT>
+CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard);
+
 template <class D>
-CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)              // bands.c:551-578
+CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)
+{
+#if defined(CA_LANE_FRAME)
+    if (N0 * stride <= 96) interleave_hadamard_ref_via(X, lds_col(F.lds_pvq16), N0, stride, hadamard);
+    else interleave_hadamard_ref_via(X, priv((i16 *)F.tmp), N0, stride, hadamard);
+#else
+    interleave_hadamard_ref_via(X, (i16 *)F.tmp, N0, stride, hadamard);
+#endif
+}
+
+template <class PT>
+CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard)
 {
     const int N = N0 * stride;
-#if defined(CA_LANE_FRAME)
-    LP<i16> tmp = N <= 96 ? lp_make(F.lds_pvq16, 64) : lp_make((i16 *)F.tmp, 1);
-#else
-    i16 *tmp = F.tmp;
-#endif
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
         const i16 *__restrict__ x = X;
@@ -645,7 +675,7 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     // instead pulled into the idle per-lane LDS scratch with 16-byte loads (through the interleave), transformed there,
     // and written back once with 16-byte stores (same scheme as the encoder's band set-up, celt_enc_back.h).
     if (N0 <= LANE_SCRATCH_N && (N0 & 7) == 0 && ((uintptr_t)X & 15) == 0 && (B0 > 1 || time_divide > 0 || recombine > 0)) {
-        LP<i16> T = lp_make(F.lds_pvq16, 64);
+        LdsCol<i16> T = lds_col(F.lds_pvq16);
         {   // interleave_hadamard (bands.c:551-578) on the way in: X[d*Ni + j] -> T[j*stride + i], d = ordery[i] or i
             const int stride = B0 > 1 ? B0 << recombine : 1, Ni = B0 > 1 ? N_B >> recombine : N0;
             const u8 *ordery = CLT_ordery_table + stride - 2;

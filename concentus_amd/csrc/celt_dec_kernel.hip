@@ -29,8 +29,8 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_decode_lane_kernel(opusgpu
     const int k = blockIdx.x * 64 + slot;
     if (k >= n) return;
     DecWork F;
-    F.lds_pvq32 = g_lds_pvq32 + slot;
-    F.lds_pvq16 = g_lds_pvq16 + slot;
+    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
+    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
     const int ln = len[k];
     if (ln > packet_stride) {
         // a length past this stream's row would read the next stream's packet (or, for the last stream, past the slab)
