@@ -15,6 +15,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  silk_lpc        silk_find_LPC_FIX (Burg + silk_A2NLSF, and the NLSF interpolation search at complexity >= 4) over 65 536
+                  distinct records: the SILK analysis step that feeds / consumes silk_burg_modified.
   mixed           BASELINE.json configs[4]: per GPU 131 072 units = 7/8 CELT frames (as celt) + 1/8 SILK records (as
                   silk); with --gpus 8 that is the 1 M-unit corpus sharded over the node.
   decode          the packets of configs[2] through opusgpu_decode_batch (fresh decoder each).
@@ -57,7 +59,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -286,6 +288,24 @@ def cpu_baseline_silk(bi, ni, st0):
                       "%d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
+def cpu_baseline_silk_lpc(lin):
+    """CPU baseline for silk_find_LPC_FIX records: the kernel sources compiled for the host (tests/emu, kind "port"), chunks on
+    a thread pool."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulib
+    emu = emulib.lib()
+    cores = host_threads()
+    n = lin.shape[0]
+    out = np.zeros((n, 40), np.uint8)
+
+    def work(lo, hi):
+        emu.emu_silk_find_lpc(C.c_void_p(lin.ctypes.data + lo * 832), C.c_void_p(out.ctypes.data + lo * 40), C.c_long(hi - lo))
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d silk_find_LPC_FIX records per pass through the host build of concentus_amd/csrc/silk_lpc_dev.h, repeated "
+                      "~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
+
+
 def cpu_baseline_silk_dd(di, st0):
     """CPU baseline for the silk_NSQ_del_dec records: the C restatement (oracle/oracle_silk.c, kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -315,7 +335,7 @@ def silk_records(F, kind, rank):
     import silk_corpus
     if silk_corpus.available():
         c = silk_corpus.corpus(F, kind, seed=20260401 + 1000003 * rank)
-        return {k: np.ascontiguousarray(v) for k, v in c.items()}, \
+        return {k: np.array(v) for k, v in c.items()}, \
             "%d distinct records captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s VOIP, %s)" % (
                 F, "complexity 3" if kind == "nsq" else "complexity 5/7/10 = 2/3/4 delayed-decision states")
     g = np.load(os.path.join(ROOT, "tests", "golden", "silk_golden.npz" if kind == "nsq" else "silk_dd_golden.npz"))
@@ -575,6 +595,44 @@ def main(argv=None):
                 parity = {"checked": F, "note": "every record (pulses, Seed, all of silk_nsq_state) vs the reference's own captured outputs"}
             else:
                 parity["note"] = "capture library absent: tiled golden inputs, outputs not compared here"
+    elif a.workload == "silk_lpc":
+        F = a.frames or 65536
+        steps = a.steps or 10
+        warm = a.warmup if a.warmup is not None else 2
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        if not silk_corpus.available():
+            raise SystemExit("silk_lpc needs oracle/_ref/libopus_ref_silkcap.so (records are captured from the reference encoder)")
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "lpc", seed=20260401 + 1000003 * rank).items()}
+        li = torch.from_numpy(rec["lpc_in"]).to(dev)
+        lo = torch.empty((F, 40), dtype=torch.uint8, device=dev)
+        for _ in range(warm):
+            ca.silk_find_LPC(li, lo)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.silk_find_LPC(li, lo)
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_find_lpc_kernel"
+        kbytes = F * (832 + 40)
+        limiter = "latency / VALU issue (serial recurrences per frame, divergent root search)"
+        metric = "SILK 16kHz mono 20ms frames/sec (silk_find_LPC_FIX records)"
+        workload = ("%d distinct records per GPU captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s VOIP, "
+                    "complexity 3/5/8/10 in turn), silk_find_LPC_FIX, bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {}
+        m_cpu = min(F, 4096)
+        cpu = (lambda: cpu_baseline_silk_lpc(np.ascontiguousarray(rec["lpc_in"][:m_cpu])))
+        if not a.no_parity and rank == 0:
+            if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
+                raise SystemExit("PARITY FAILURE (silk_find_LPC)")
+            parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
     elif a.workload == "silk":
         F = a.frames or 65536
         steps = a.steps or 20

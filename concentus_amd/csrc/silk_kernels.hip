@@ -19,14 +19,13 @@
 // Arithmetic: the reference's x86-64 build uses the 64-bit macro forms (OPUS_FAST_INT64, silk/macros.h:47-102);
 // 16x32 products are evaluated on split halves (full-rate 24-bit multiplier), 32x32 ones as 64-bit.
 #include <string.h>
-#include "silk_math.h"
+#include "silk_burg_dev.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
 #include "silk_validate.h"
 
 namespace ca {
 
-enum { QA = 25, COND_FAC_Q32 = 42950 };                              // SILK_FIX_CONST(FIND_LPC_COND_FAC = 1e-5f, 32)
 
 // ---- silk_burg_modified: one lane per record --------------------------------------------------------
 // A record's samples x[384] are read ~25 times each (16 autocorrelation lags, then both ends of every subframe in
@@ -67,173 +66,7 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
     }
     BurgX x;
     x.p = xs + threadIdx.x;
-    const int subfr_length = in.subfr_length, nb_subfr = in.nb_subfr, D = in.D;
-    const i32 minInvGain_Q30 = in.minInvGain_Q30;
-    i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
-    i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
-    int k, n, s, lz, rshifts, reached_max_gain;
-    i64 C0_64 = 0;
-    for (k = 0; k < subfr_length * nb_subfr; k++) C0_64 += __mul24(x[k], x[k]);
-    {
-        i32 hi = (i32)(C0_64 >> 32);
-        lz = hi == 0 ? 32 + s_clz32((i32)C0_64) : s_clz32(hi);
-    }
-    rshifts = 32 + 1 + 2 - lz;
-    if (rshifts > 32 - QA) rshifts = 32 - QA;
-    if (rshifts < -16) rshifts = -16;
-    C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
-    CAb[0] = CAf[0] = s_addw(s_addw(C0, s_smmul(COND_FAC_Q32, C0)), 1);
-    for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
-    if (rshifts > 0) {
-        for (s = 0; s < nb_subfr; s++) {
-            const BurgX xp = x + s * subfr_length;
-            for (n = 1; n < D + 1; n++) {
-                i64 acc = 0;
-                for (k = 0; k < subfr_length - n; k++) acc += __mul24(xp[k], xp[k + n]);
-                C_first_row[n - 1] = s_addw(C_first_row[n - 1], (i32)(acc >> rshifts));
-            }
-        }
-    } else {
-        for (s = 0; s < nb_subfr; s++) {
-            const BurgX xp = x + s * subfr_length;
-            for (n = 1; n < D + 1; n++) {
-                i32 d = 0;           // celt_pitch_xcorr + tail loop = the full lag-n product, 32-bit wrap-around
-                for (k = n; k < subfr_length; k++) d = s_addw(d, __mul24(xp[k], xp[k - n]));
-                C_first_row[n - 1] = s_addw(C_first_row[n - 1], shl32(d, -rshifts));
-            }
-        }
-    }
-    for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
-    invGain_Q30 = (i32)1 << 30;
-    reached_max_gain = 0;
-    for (n = 0; n < D; n++) {
-        if (rshifts > -2) {
-            for (s = 0; s < nb_subfr; s++) {
-                const BurgX xp = x + s * subfr_length;
-                x1 = (i32)(0u - (u32)shl32(xp[n], 16 - rshifts));
-                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], 16 - rshifts));
-                tmp1 = shl32(xp[n], QA - 16);
-                tmp2 = shl32(xp[subfr_length - n - 1], QA - 16);
-                for (k = 0; k < n; k++) {
-                    C_first_row[k] = s_smlawb(C_first_row[k], x1, xp[n - k - 1]);
-                    C_last_row[k] = s_smlawb(C_last_row[k], x2, xp[subfr_length - n + k]);
-                    Atmp_QA = Af_QA[k];
-                    tmp1 = s_smlawb(tmp1, Atmp_QA, xp[n - k - 1]);
-                    tmp2 = s_smlawb(tmp2, Atmp_QA, xp[subfr_length - n + k]);
-                }
-                tmp1 = shl32((i32)(0u - (u32)tmp1), 32 - QA - rshifts);
-                tmp2 = shl32((i32)(0u - (u32)tmp2), 32 - QA - rshifts);
-                for (k = 0; k <= n; k++) {
-                    CAf[k] = s_smlawb(CAf[k], tmp1, xp[n - k]);
-                    CAb[k] = s_smlawb(CAb[k], tmp2, xp[subfr_length - n + k - 1]);
-                }
-            }
-        } else {
-            for (s = 0; s < nb_subfr; s++) {
-                const BurgX xp = x + s * subfr_length;
-                x1 = (i32)(0u - (u32)shl32(xp[n], -rshifts));
-                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], -rshifts));
-                tmp1 = shl32(xp[n], 17);
-                tmp2 = shl32(xp[subfr_length - n - 1], 17);
-                for (k = 0; k < n; k++) {
-                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)(i32)xp[n - k - 1]);
-                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)(i32)xp[subfr_length - n + k]);
-                    Atmp1 = s_rshift_round(Af_QA[k], QA - 17);
-                    tmp1 = (i32)((u32)tmp1 + (u32)(i32)xp[n - k - 1] * (u32)Atmp1);
-                    tmp2 = (i32)((u32)tmp2 + (u32)(i32)xp[subfr_length - n + k] * (u32)Atmp1);
-                }
-                tmp1 = (i32)(0u - (u32)tmp1);
-                tmp2 = (i32)(0u - (u32)tmp2);
-                for (k = 0; k <= n; k++) {
-                    CAf[k] = s_smlaww(CAf[k], tmp1, shl32(xp[n - k], -rshifts - 1));
-                    CAb[k] = s_smlaww(CAb[k], tmp2, shl32(xp[subfr_length - n + k - 1], -rshifts - 1));
-                }
-            }
-        }
-        tmp1 = C_first_row[n];
-        tmp2 = C_last_row[n];
-        num = 0;
-        nrg = s_addw(CAb[0], CAf[0]);
-        for (k = 0; k < n; k++) {
-            Atmp_QA = Af_QA[k];
-            lz = s_clz32(s_abs(Atmp_QA)) - 1;
-            if (lz > 32 - QA) lz = 32 - QA;
-            Atmp1 = shl32(Atmp_QA, lz);
-            tmp1 = s_addw(tmp1, shl32(s_smmul(C_last_row[n - k - 1], Atmp1), 32 - QA - lz));
-            tmp2 = s_addw(tmp2, shl32(s_smmul(C_first_row[n - k - 1], Atmp1), 32 - QA - lz));
-            num = s_addw(num, shl32(s_smmul(CAb[n - k], Atmp1), 32 - QA - lz));
-            nrg = s_addw(nrg, shl32(s_smmul(s_addw(CAb[k + 1], CAf[k + 1]), Atmp1), 32 - QA - lz));
-        }
-        CAf[n + 1] = tmp1;
-        CAb[n + 1] = tmp2;
-        num = s_addw(num, tmp2);
-        num = shl32((i32)(0u - (u32)num), 1);
-        if (s_abs(num) < nrg) rc_Q31 = s_div32_varq(num, nrg, 31);
-        else rc_Q31 = (num > 0) ? 0x7FFFFFFF : (i32)0x80000000;
-        tmp1 = s_subw((i32)1 << 30, s_smmul(rc_Q31, rc_Q31));
-        tmp1 = shl32(s_smmul(invGain_Q30, tmp1), 2);
-        if (tmp1 <= minInvGain_Q30) {
-            tmp2 = s_subw((i32)1 << 30, s_div32_varq(minInvGain_Q30, invGain_Q30, 30));
-            rc_Q31 = s_sqrt_approx(tmp2);
-            rc_Q31 = s_addw(rc_Q31, tmp2 / rc_Q31) >> 1;
-            rc_Q31 = shl32(rc_Q31, 16);
-            if (num < 0) rc_Q31 = (i32)(0u - (u32)rc_Q31);
-            invGain_Q30 = minInvGain_Q30;
-            reached_max_gain = 1;
-        } else {
-            invGain_Q30 = tmp1;
-        }
-        for (k = 0; k < (n + 1) >> 1; k++) {
-            tmp1 = Af_QA[k];
-            tmp2 = Af_QA[n - k - 1];
-            Af_QA[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
-            Af_QA[n - k - 1] = s_addw(tmp2, shl32(s_smmul(tmp1, rc_Q31), 1));
-        }
-        Af_QA[n] = rc_Q31 >> (31 - QA);
-        if (reached_max_gain) {
-            for (k = n + 1; k < D; k++) Af_QA[k] = 0;
-            break;
-        }
-        for (k = 0; k <= n + 1; k++) {
-            tmp1 = CAf[k];
-            tmp2 = CAb[n - k + 1];
-            CAf[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
-            CAb[n - k + 1] = s_addw(tmp2, shl32(s_smmul(tmp1, rc_Q31), 1));
-        }
-    }
-    opusgpu_burg_out &out = outs[r];
-    if (reached_max_gain) {
-        for (k = 0; k < D; k++) out.A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
-        if (rshifts > 0) {
-            for (s = 0; s < nb_subfr; s++) {
-                const BurgX xp = x + s * subfr_length;
-                i64 acc = 0;
-                for (k = 0; k < D; k++) acc += __mul24(xp[k], xp[k]);
-                C0 = s_subw(C0, (i32)(acc >> rshifts));
-            }
-        } else {
-            for (s = 0; s < nb_subfr; s++) {
-                const BurgX xp = x + s * subfr_length;
-                i32 acc = 0;
-                for (k = 0; k < D; k++) acc = s_addw(acc, __mul24(xp[k], xp[k]));
-                C0 = s_subw(C0, shl32(acc, -rshifts));
-            }
-        }
-        out.res_nrg = shl32(s_smmul(invGain_Q30, C0), 2);
-        out.res_nrg_Q = -rshifts;
-    } else {
-        nrg = CAf[0];
-        tmp1 = (i32)1 << 16;
-        for (k = 0; k < D; k++) {
-            Atmp1 = s_rshift_round(Af_QA[k], QA - 16);
-            nrg = s_smlaww(nrg, CAf[k + 1], Atmp1);
-            tmp1 = s_smlaww(tmp1, Atmp1, Atmp1);
-            out.A_Q16[k] = (i32)(0u - (u32)Atmp1);
-        }
-        out.res_nrg = s_smlaww(nrg, s_smmul(COND_FAC_Q32, C0), (i32)(0u - (u32)tmp1));
-        out.res_nrg_Q = -rshifts;
-    }
-    for (k = D; k < 16; k++) out.A_Q16[k] = 0;
+    silk_burg_modified_dev(x, in.minInvGain_Q30, in.subfr_length, in.nb_subfr, in.D, outs[r].A_Q16, &outs[r].res_nrg, &outs[r].res_nrg_Q);
 }
 
 // ---- silk_NSQ: one lane per record ---------------------------------------------------------------------

@@ -20,6 +20,15 @@ __device__ __forceinline__ bool burg_record_ok(const opusgpu_burg_in &in)
            L * n <= OPUSGPU_SILK_BURG_MAX_X;
 }
 
+__device__ __forceinline__ bool find_lpc_record_ok(const opusgpu_find_lpc_in &in)
+{
+    const int L = in.subfr_length, n = in.nb_subfr, D = in.predictLPCOrder;
+    if (!((n == 2 || n == 4) && (D == 10 || D == 16) && L >= D && L <= 80 && (L + D) * n <= OPUSGPU_SILK_BURG_MAX_X)) return false;
+    for (int k = 0; k < D; k++)
+        if (in.prev_NLSFq_Q15[k] < 0) return false;             // silk_NLSF2A indexes the cosine table with NLSF >> 8
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -36,6 +36,8 @@ SYMBOLS = [
     ("opusgpu_silk_nsq_del_dec_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_silk_nsq_del_dec_batch", _i, [_vp, _vp, _vp, _i, _vp, C.c_size_t, _vp]),
     ("opusgpu_silk_bad_records", _i, [_vp]),
+    ("opusgpu_silk_find_lpc_batch", _i, [_vp, _vp, _i, _vp]),
+    ("opusgpu_silk_find_LPC_FIX", None, [_vp, _vp, _vp, C.c_int32]),
     ("opusgpu_celt_dec_state_size", _i, []),
     ("opusgpu_celt_dec_state_init", _i, [_vp, _i, _vp]),
     ("opusgpu_decode_batch", _i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -121,3 +121,32 @@ def silk_NSQ_del_dec(dd_in, nsq_state, dd_out=None):
                                           _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_nsq_del_dec_batch")
     return dd_out
+
+
+class FindLpcIn(C.Structure):
+    """opusgpu_find_lpc_in: one silk_find_LPC_FIX() call (opus-fix/silk/fixed/find_LPC_FIX.c:37)."""
+    _fields_ = [("x", C.c_int16 * 384), ("minInvGain_Q30", C.c_int32), ("subfr_length", C.c_int32), ("nb_subfr", C.c_int32),
+                ("predictLPCOrder", C.c_int32), ("useInterpolatedNLSFs", C.c_int32), ("first_frame_after_reset", C.c_int32),
+                ("prev_NLSFq_Q15", C.c_int16 * 16), ("reserved", C.c_int32 * 2)]
+
+
+class FindLpcOut(C.Structure):
+    _fields_ = [("NLSF_Q15", C.c_int16 * 16), ("NLSFInterpCoef_Q2", C.c_int32), ("status", C.c_int32)]
+
+
+SIZES["find_lpc_in"] = C.sizeof(FindLpcIn)
+SIZES["find_lpc_out"] = C.sizeof(FindLpcOut)
+
+
+def silk_find_LPC(lpc_in, lpc_out=None):
+    """silk_find_LPC_FIX() over a batch of records: lpc_in uint8 [N][832] (opusgpu_find_lpc_in) -> uint8 [N][40]
+    (NLSF_Q15 int16[16], NLSFInterpCoef_Q2, status)."""
+    import torch
+    _check(lpc_in, SIZES["find_lpc_in"], "lpc_in")
+    n = lpc_in.shape[0]
+    if lpc_out is None:
+        lpc_out = torch.empty((n, SIZES["find_lpc_out"]), dtype=torch.uint8, device=lpc_in.device)
+    _check(lpc_out, SIZES["find_lpc_out"], "lpc_out")
+    rc = _lib.load().opusgpu_silk_find_lpc_batch(lpc_in.data_ptr(), lpc_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_find_lpc_batch")
+    return lpc_out

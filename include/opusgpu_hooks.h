@@ -53,6 +53,10 @@ void opusgpu_renormalise_vector(int16_t *X, int N, int gain, int arch);
 #define OPUSGPU_REF_OFF_SHAPING_LPC_ORDER 4660      /* .shapingLPCOrder */
 #define OPUSGPU_REF_OFF_PREDICT_LPC_ORDER 4664      /* .predictLPCOrder */
 #define OPUSGPU_REF_OFF_WARPING_Q16 4704            /* .warping_Q16 */
+#define OPUSGPU_REF_OFF_PREV_NLSFQ_Q15 4524          /* .prev_NLSFq_Q15[16]                        (opus_int16) */
+#define OPUSGPU_REF_OFF_USE_INTERPOLATED_NLSFS 4656 /* .useInterpolatedNLSFs */
+#define OPUSGPU_REF_OFF_FIRST_FRAME_AFTER_RESET 4696 /* .first_frame_after_reset */
+#define OPUSGPU_REF_OFF_INDICES 4784                /* .indices (SideInfoIndices) */
 #define OPUSGPU_REF_SIZEOF_SIDE_INFO_INDICES 36
 #define OPUSGPU_REF_OFF_SIGNAL_TYPE 29              /* SideInfoIndices.signalType                 (opus_int8) */
 #define OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE 30        /* .quantOffsetType */
@@ -66,6 +70,12 @@ void opusgpu_silk_NSQ_del_dec(const void *psEncC, void *NSQ, void *psIndices, co
                               const int16_t PredCoef_Q12[/*2 * 16*/], const int16_t LTPCoef_Q14[/*5 * 4*/], const int16_t AR2_Q13[/*4 * 16*/],
                               const int HarmShapeGain_Q14[/*4*/], const int Tilt_Q14[/*4*/], const int32_t LF_shp_Q14[/*4*/],
                               const int32_t Gains_Q16[/*4*/], const int pitchL[/*4*/], const int Lambda_Q10, const int LTP_scale_Q14);
+
+/* silk_find_LPC_FIX(psEncC, NLSF_Q15, x, minInvGain_Q30) -- opus-fix/silk/fixed/find_LPC_FIX.c:37-151 (declared in
+ * silk/fixed/main_FIX.h, called at silk/fixed/find_pred_coefs_FIX.c:136): reads psEncC->subfr_length / nb_subfr /
+ * predictLPCOrder / useInterpolatedNLSFs / first_frame_after_reset / prev_NLSFq_Q15, writes NLSF_Q15[predictLPCOrder] and
+ * psEncC->indices.NLSFInterpCoef_Q2. */
+void opusgpu_silk_find_LPC_FIX(void *psEncC, int16_t NLSF_Q15[], const int16_t x[], const int32_t minInvGain_Q30);
 
 #ifdef __cplusplus
 }

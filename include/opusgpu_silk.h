@@ -111,6 +111,34 @@ size_t opusgpu_silk_nsq_del_dec_workspace_bytes(int n);
 int opusgpu_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_dd_out *d_out, int n,
                                    void *d_workspace, size_t workspace_bytes, void *hip_stream);
 
+/* ---- silk_find_LPC_FIX(): the analysis step around silk_burg_modified (first slice) ----------------
+ *   silk_find_LPC_FIX   opus-fix/silk/fixed/find_LPC_FIX.c:37-151, called at silk/fixed/find_pred_coefs_FIX.c:136
+ * Burg analysis of the whole frame; with NLSF interpolation enabled (complexity >= 4, control_codec.c:345-377) a second Burg
+ * analysis of the last 10 ms, silk_A2NLSF, and the search over the four interpolation factors (silk_interpolate ->
+ * silk_NLSF2A -> silk_LPC_analysis_filter -> silk_sum_sqr_shift per factor); finally silk_A2NLSF of the winner. One record =
+ * the arguments of one call plus the psEncC fields it reads; the output is what the call leaves in NLSF_Q15[] and in
+ * psEncC->indices.NLSFInterpCoef_Q2. Records whose header would index out of bounds are skipped (status OPUSGPU_BAD_ARG,
+ * outputs zero) and counted by opusgpu_silk_bad_records(). */
+typedef struct opusgpu_find_lpc_in {
+    int16_t x[OPUSGPU_SILK_BURG_MAX_X];      /* LPC_in_pre: nb_subfr * (subfr_length + predictLPCOrder) samples */
+    int32_t minInvGain_Q30;
+    int32_t subfr_length;                    /* psEncC->subfr_length (WITHOUT the order samples: 80 at 16 kHz) */
+    int32_t nb_subfr;                        /* 2 or 4 */
+    int32_t predictLPCOrder;                 /* 10 or 16 */
+    int32_t useInterpolatedNLSFs;
+    int32_t first_frame_after_reset;
+    int16_t prev_NLSFq_Q15[OPUSGPU_SILK_MAX_ORDER];
+    int32_t reserved[2];
+} opusgpu_find_lpc_in;
+
+typedef struct opusgpu_find_lpc_out {
+    int16_t NLSF_Q15[OPUSGPU_SILK_MAX_ORDER];
+    int32_t NLSFInterpCoef_Q2;               /* 0..4 (4 = no interpolation) */
+    int32_t status;                          /* OPUSGPU_OK, or OPUSGPU_BAD_ARG for a skipped record */
+} opusgpu_find_lpc_out;
+
+int opusgpu_silk_find_lpc_batch(const opusgpu_find_lpc_in *d_in, opusgpu_find_lpc_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

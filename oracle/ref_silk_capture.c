@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -150,5 +150,43 @@ void __wrap_silk_NSQ_del_dec_c(const silk_encoder_state *psEncC, silk_nsq_state 
         memcpy(g_dout[rec].pulses, pulses, psEncC->frame_length);
         g_dout[rec].Seed = psIndices->Seed;
         g_nd++;
+    }
+}
+
+/* ---- silk_find_LPC_FIX (opus-fix/silk/fixed/find_LPC_FIX.c:37): arguments + the psEncC fields it reads -> NLSF_Q15, NLSFInterpCoef_Q2 ---- */
+#include "main_FIX.h"
+static opusgpu_find_lpc_in *g_lin; static opusgpu_find_lpc_out *g_lout; static int g_nl, g_capl;
+void refcap_start_lpc(int max_records)
+{
+    g_capl = max_records; g_nl = 0; g_on = 1;
+    g_lin = (opusgpu_find_lpc_in *)calloc(max_records, sizeof(*g_lin));
+    g_lout = (opusgpu_find_lpc_out *)calloc(max_records, sizeof(*g_lout));
+}
+int refcap_count_lpc(void) { return g_nl; }
+int refcap_sizes_lpc(int which) { return which == 0 ? sizeof(opusgpu_find_lpc_in) : sizeof(opusgpu_find_lpc_out); }
+void refcap_get_lpc(void *lin, void *lout)
+{
+    memcpy(lin, g_lin, (size_t)g_nl * sizeof(*g_lin)); memcpy(lout, g_lout, (size_t)g_nl * sizeof(*g_lout));
+}
+
+void __real_silk_find_LPC_FIX(silk_encoder_state *psEncC, opus_int16 NLSF_Q15[], const opus_int16 x[], const opus_int32 minInvGain_Q30);
+void __wrap_silk_find_LPC_FIX(silk_encoder_state *psEncC, opus_int16 NLSF_Q15[], const opus_int16 x[], const opus_int32 minInvGain_Q30)
+{
+    const int nx = (psEncC->subfr_length + psEncC->predictLPCOrder) * psEncC->nb_subfr;
+    int rec = (g_on && g_lin && g_nl < g_capl && nx <= OPUSGPU_SILK_BURG_MAX_X) ? g_nl : -1;
+    if (rec >= 0) {
+        opusgpu_find_lpc_in *r = &g_lin[rec];
+        memcpy(r->x, x, sizeof(opus_int16) * nx);
+        r->minInvGain_Q30 = minInvGain_Q30; r->subfr_length = psEncC->subfr_length; r->nb_subfr = psEncC->nb_subfr;
+        r->predictLPCOrder = psEncC->predictLPCOrder; r->useInterpolatedNLSFs = psEncC->useInterpolatedNLSFs;
+        r->first_frame_after_reset = psEncC->first_frame_after_reset;
+        memcpy(r->prev_NLSFq_Q15, psEncC->prev_NLSFq_Q15, sizeof(r->prev_NLSFq_Q15));
+    }
+    __real_silk_find_LPC_FIX(psEncC, NLSF_Q15, x, minInvGain_Q30);
+    if (rec >= 0) {
+        memcpy(g_lout[rec].NLSF_Q15, NLSF_Q15, sizeof(opus_int16) * psEncC->predictLPCOrder);
+        g_lout[rec].NLSFInterpCoef_Q2 = psEncC->indices.NLSFInterpCoef_Q2;
+        g_lout[rec].status = 0;
+        g_nl++;
     }
 }

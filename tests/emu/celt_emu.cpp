@@ -157,3 +157,18 @@ extern "C" void emu_mdct_backward(const int32_t *coef, int32_t *out, int shift)
     if (shift == 0) { MdctTab T = mdct_global_tab<0>(); mdct_backward_wave<0, 1>(coef, 1, f2, out, T, 0); }
     else { MdctTab T = mdct_global_tab<3>(); mdct_backward_wave<3, 8>(coef, 1, f2, out, T, 0); }
 }
+
+// ---- silk_find_LPC_FIX, host build of concentus_amd/csrc/silk_lpc_dev.h (CPU tier of tests/test_silk_lpc_cpu.py) ----
+#include "../../concentus_amd/csrc/silk_lpc_dev.h"
+#include "../../include/opusgpu_silk.h"
+extern "C" void emu_silk_find_lpc(const opusgpu_find_lpc_in *in, opusgpu_find_lpc_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        int16_t nlsf[16] = {0};
+        out[r].NLSFInterpCoef_Q2 = ca::silk_find_LPC_dev(in[r].x, in[r].minInvGain_Q30, in[r].subfr_length, in[r].nb_subfr,
+                                                         in[r].predictLPCOrder, in[r].useInterpolatedNLSFs, in[r].first_frame_after_reset,
+                                                         in[r].prev_NLSFq_Q15, nlsf);
+        for (int k = 0; k < 16; k++) out[r].NLSF_Q15[k] = nlsf[k];
+        out[r].status = 0;
+    }
+}

@@ -26,7 +26,8 @@ FRAME = 320
 SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder each)
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
-SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324}
+SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324,
+         "lpc_in": 832, "lpc_out": 40}
 
 
 def available():
@@ -100,6 +101,8 @@ def _capture_segment(args):
     cap = 3 * nfr + 16
     if kind == "dd":
         lib.refcap_start_dd(cap)
+    elif kind == "lpc":
+        lib.refcap_start_lpc(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -112,7 +115,14 @@ def _capture_segment(args):
         fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
         assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
-    if kind == "dd":
+    if kind == "lpc":
+        nl = lib.refcap_count_lpc()
+        assert nl >= nfr, (nl, nfr)
+        bufs = [np.zeros((nl, SIZES["lpc_in"]), np.uint8), np.zeros((nl, SIZES["lpc_out"]), np.uint8)]
+        lib.refcap_get_lpc(*[_p(b) for b in bufs])
+        for name, b in zip(("lpc_in", "lpc_out"), bufs):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    elif kind == "dd":
         nd = lib.refcap_count_dd()
         assert nd >= nfr, (nd, nfr)
         bufs = [np.zeros((nd, SIZES["dd_in"]), np.uint8), np.zeros((nd, SIZES["nsq_state"]), np.uint8),
@@ -142,6 +152,7 @@ _LAYOUT = {
     "nsq": (("burg_in", "burg_in"), ("burg_out", "burg_out"), ("nsq_in", "nsq_in"), ("nsq_state_in", "nsq_state"),
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
     "dd": (("dd_in", "dd_in"), ("dd_state_in", "nsq_state"), ("dd_state_out", "nsq_state"), ("dd_out", "dd_out")),
+    "lpc": (("lpc_in", "lpc_in"), ("lpc_out", "lpc_out")),
 }
 
 
@@ -162,7 +173,8 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
     if not available():
         raise FileNotFoundError(CAPLIB)
-    complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10))
+    # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
+    complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10) if kind == "dd" else (3, 5, 8, 10))
     cache = cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus")
     os.makedirs(cache, exist_ok=True)
     done = os.path.join(cache, "%s_%d_%s.done" % (kind, n, "-".join(map(str, complexities))))
@@ -173,7 +185,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + (0 if kind == "nsq" else 104729), complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709}[kind], complexities[k % len(complexities)],
                          row, take, n))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

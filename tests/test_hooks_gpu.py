@@ -161,3 +161,36 @@ def test_silk_nsq_hooks_with_the_reference_argument_list(L, ref, which):
         assert np.array_equal(out[0][2], out[1][2]), (which, k, "SideInfoIndices (Seed)")
         if which == "nsq":
             assert np.array_equal(out[1][1].view(np.uint8), gold["silk_nsq_out"][k])
+
+
+def test_silk_find_LPC_FIX_hook_with_the_reference_argument_list(L, ref):
+    """opusgpu_silk_find_LPC_FIX(psEncC, NLSF_Q15, x, minInvGain_Q30) against silk_find_LPC_FIX of the compiled reference, both
+    driven through a zeroed silk_encoder_state in which only the fields the function reads are set (offsets of
+    include/opusgpu_hooks.h); compared: NLSF_Q15[] and psEncC->indices.NLSFInterpCoef_Q2."""
+    import silk_corpus
+    r, _ = ref
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    d = header_defines()
+    rec = silk_corpus.corpus(4096, "lpc")
+    lin = np.asarray(rec["lpc_in"])
+    want = np.asarray(rec["lpc_out"])
+    picks = list(range(0, 4096, 293))
+    for k in picks:
+        row = np.ascontiguousarray(lin[k])
+        hdr = row[768:792].view(np.int32)
+        x = np.ascontiguousarray(row[:768].view(np.int16))
+        outs = []
+        for fn in (r.silk_find_LPC_FIX, L.opusgpu_silk_find_LPC_FIX):
+            enc = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE"], np.uint8)
+            for off, v in ((d["OPUSGPU_REF_OFF_SUBFR_LENGTH"], hdr[1]), (d["OPUSGPU_REF_OFF_NB_SUBFR"], hdr[2]),
+                           (d["OPUSGPU_REF_OFF_PREDICT_LPC_ORDER"], hdr[3]), (d["OPUSGPU_REF_OFF_USE_INTERPOLATED_NLSFS"], hdr[4]),
+                           (d["OPUSGPU_REF_OFF_FIRST_FRAME_AFTER_RESET"], hdr[5])):
+                enc[off:off + 4].view(np.int32)[0] = v
+            enc[d["OPUSGPU_REF_OFF_PREV_NLSFQ_Q15"]:][:32] = row[792:824]
+            nlsf = np.zeros(16, np.int16)
+            fn(p(enc), p(nlsf), p(x), C.c_int32(int(hdr[0])))
+            outs.append((nlsf, int(enc[d["OPUSGPU_REF_OFF_INDICES"] + d["OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2"]].view(np.int8))))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], k
+        assert np.array_equal(outs[1][0], want[k, :32].view(np.int16)) and outs[1][1] == want[k, 32:36].view(np.int32)[0]

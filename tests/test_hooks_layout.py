@@ -20,6 +20,10 @@ PAIRS = {
     "OPUSGPU_REF_OFF_SHAPING_LPC_ORDER": "silk_encoder_state.shapingLPCOrder",
     "OPUSGPU_REF_OFF_PREDICT_LPC_ORDER": "silk_encoder_state.predictLPCOrder",
     "OPUSGPU_REF_OFF_WARPING_Q16": "silk_encoder_state.warping_Q16",
+    "OPUSGPU_REF_OFF_PREV_NLSFQ_Q15": "silk_encoder_state.prev_NLSFq_Q15",
+    "OPUSGPU_REF_OFF_USE_INTERPOLATED_NLSFS": "silk_encoder_state.useInterpolatedNLSFs",
+    "OPUSGPU_REF_OFF_FIRST_FRAME_AFTER_RESET": "silk_encoder_state.first_frame_after_reset",
+    "OPUSGPU_REF_OFF_INDICES": "silk_encoder_state.indices",
     "OPUSGPU_REF_SIZEOF_SIDE_INFO_INDICES": "sizeof.SideInfoIndices",
     "OPUSGPU_REF_OFF_SIGNAL_TYPE": "SideInfoIndices.signalType",
     "OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE": "SideInfoIndices.quantOffsetType",

@@ -258,3 +258,32 @@ def test_corrupted_record_headers_are_skipped_not_executed(ca):
     assert np.array_equal(st.cpu().numpy()[good], dd["dd_state_out"][good])
     assert np.array_equal(st.cpu().numpy()[[1, 3]], dd["dd_state_in"][[1, 3]])
     assert ca.silk.bad_records() == 0
+
+
+# ---- silk_find_LPC_FIX (first slice): one lane per frame ----
+def test_find_lpc_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_find_LPC_FIX on the GPU against the outputs the unmodified reference produced when the records were captured
+    (tests/silk_corpus.py kind "lpc": complexity 3 / 5 / 8 / 10 in turn, i.e. with and without the NLSF interpolation search)."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "lpc")
+    out = ca.silk_find_LPC(_dev(rec["lpc_in"]))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.asarray(rec["lpc_out"])
+    assert (out[:, 36:40].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :36] != want[:, :36]).any(1))[0]
+    assert bad.size == 0, (bad[:8], out[bad[:2], :36].view(np.int16), want[bad[:2], :36].view(np.int16))
+    interp = want[:, 32:36].view(np.int32)[:, 0]
+    assert (interp < 4).sum() > 500 and (interp == 4).sum() > 500
+    # a corrupted header is skipped and counted, its neighbours are unaffected
+    ca.silk.bad_records()
+    lin = np.array(rec["lpc_in"][:256])
+    lin[7, 768 + 12:768 + 16].view(np.int32)[0] = 40          # predictLPCOrder
+    lin[9, 768 + 4:768 + 8].view(np.int32)[0] = 500           # subfr_length
+    out2 = ca.silk_find_LPC(_dev(lin)).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [7, 9])
+    assert np.array_equal(out2[good, :36], want[:256][good, :36]) and (out2[[7, 9], 36:40].view(np.int32) == -1).all()
