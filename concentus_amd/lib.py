@@ -53,6 +53,7 @@ SYMBOLS = [
     ("opusgpu_comb_filter_const", None, [_vp, _vp, _i, _i, _i, _i, _i]),
     ("opusgpu_exp_rotation1", None, [_vp, _i, _i, _i, _i]),
     ("opusgpu_renormalise_vector", None, [_vp, _i, _i, _i]),
+    ("opusgpu_quant_all_bands", None, [_i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int32, C.c_int32, _vp, _i, _i, _vp, _i]),
     ("opusgpu_silk_NSQ", None, [_vp] * 13 + [_i, _i]),
     ("opusgpu_silk_NSQ_del_dec", None, [_vp] * 13 + [_i, _i]),
     ("opusgpu_decode_lane_diag", _i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),

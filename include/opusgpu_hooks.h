@@ -71,6 +71,19 @@ void opusgpu_silk_NSQ_del_dec(const void *psEncC, void *NSQ, void *psIndices, co
                               const int HarmShapeGain_Q14[/*4*/], const int Tilt_Q14[/*4*/], const int32_t LF_shp_Q14[/*4*/],
                               const int32_t Gains_Q16[/*4*/], const int pitchL[/*4*/], const int Lambda_Q10, const int LTP_scale_Q14);
 
+/* quant_all_bands(...) -- opus-fix/celt/bands.c:1337-1502, the PVQ band quantiser with the tree's own 21-argument list. The
+ * reference has no RTCD slot for it (plain extern, celt/bands.h): a build that wants the GPU version renames / --wraps the
+ * symbol to this one. `ec` is the tree's ec_ctx INCLUDING its trailing EC_DIFF field (celt/entcode.h:63-94,
+ * 56 bytes on x86-64): buf[0 .. storage) is copied to the device, the range coder runs there, and every field plus the
+ * buffer come back. Supported: encode == 1, the static 48 kHz mode (m->Fs 48000, overlap 120, nbEBands 21), start 0, end 21,
+ * LM 3, stereo (Y != NULL), storage <= 1275; anything else -> OPUSGPU_UNIMPLEMENTED in opusgpu_get_last_error() and nothing
+ * is touched. As in the reference's non-RESYNTH build the caller's X, Y, collapse_masks and *seed carry no information the
+ * encoder reads afterwards (celt_encoder.c:2130-2160); they are left as they were. */
+void opusgpu_quant_all_bands(int encode, const void *m, int start, int end, int16_t *X, int16_t *Y, unsigned char *collapse_masks,
+                             const int32_t *bandE, int *pulses, int shortBlocks, int spread, int dual_stereo, int intensity,
+                             int *tf_res, int32_t total_bits, int32_t balance, void *ec, int LM, int codedBands, uint32_t *seed,
+                             int arch);
+
 /* silk_find_LPC_FIX(psEncC, NLSF_Q15, x, minInvGain_Q30) -- opus-fix/silk/fixed/find_LPC_FIX.c:37-151 (declared in
  * silk/fixed/main_FIX.h, called at silk/fixed/find_pred_coefs_FIX.c:136): reads psEncC->subfr_length / nb_subfr /
  * predictLPCOrder / useInterpolatedNLSFs / first_frame_after_reset / prev_NLSFq_Q15, writes NLSF_Q15[predictLPCOrder] and

@@ -194,3 +194,75 @@ def test_silk_find_LPC_FIX_hook_with_the_reference_argument_list(L, ref):
         assert L.opusgpu_get_last_error() == 0
         assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], k
         assert np.array_equal(outs[1][0], want[k, :32].view(np.int16)) and outs[1][1] == want[k, 32:36].view(np.int32)[0]
+
+
+def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
+    """opusgpu_quant_all_bands with the tree's 21-argument list and its ec_ctx (EC_DIFF included) against quant_all_bands of the
+    compiled reference ON THE CALLS THE REFERENCE ENCODER ITSELF MAKES: oracle/_ref/libopus_ref_celtcap.so (--wrap=quant_all_bands,
+    oracle/ref_celt_capture.c) records the arguments before each call and the range coder after it while opus_encode() runs over
+    noise, music and the reference's own test signal at several rates; compared: every ec_ctx field and every byte of the
+    coder's buffer."""
+    import encode_cases as ec
+    cap_path = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_celtcap.so")
+    if not os.path.exists(cap_path):
+        pytest.skip("oracle/_ref/libopus_ref_celtcap.so did not travel")
+    cap = C.CDLL(cap_path)
+    cap.opus_encoder_create.restype = C.c_void_p
+    cap.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    gm = ec.golden_module()
+    cap.refcap_start_qab(4096)
+    for kind, br, vbr, cx, seed in (("noise", 96000, 1, 10, 71), ("music", 64000, 1, 10, 72), ("gmusic", 128000, 0, 5, 13371337),
+                                    ("music", 40000, 1, 8, 73)):
+        pcm = gm.synth_pcm(kind, 12, seed)
+        err = C.c_int()
+        enc = C.c_void_p(cap.opus_encoder_create(48000, 2, 2051, C.byref(err)))
+        for req, v in ((4002, br), (4006, vbr), (4020, 0), (4010, cx), (4036, 16)):
+            cap.opus_encoder_ctl(enc, req, v)
+        out = (C.c_ubyte * 1500)()
+        for f in range(pcm.shape[0]):
+            fr = np.ascontiguousarray(pcm[f])
+            assert cap.opus_encode(enc, p(fr), 960, out, 1500) > 0
+    n = cap.refcap_count_qab()
+    assert n == 48
+    sz = cap.refcap_sizeof_qab()
+    raw = np.zeros((n, sz), np.uint8)
+    cap.refcap_get_qab(p(raw))
+    mode = reflib.lib().opus_custom_mode_create(48000, 960, C.byref(C.c_int()))
+    o = 0
+    fields = {}
+    for name, nbytes in (("X", 1920), ("Y", 1920), ("bandE", 168), ("pulses", 84), ("tf_res", 84), ("ints", 40), ("tb", 8), ("seed", 4),
+                         ("ec_in", 44), ("ec_out", 44), ("buf_in", 1280), ("buf_out", 1280)):
+        fields[name] = (o, nbytes)
+        o += nbytes
+    assert o <= sz
+    get = lambda r, k, dt: np.ascontiguousarray(raw[r, fields[k][0]:fields[k][0] + fields[k][1]]).view(dt).copy()
+    seen_short = set()
+    for r in range(n):
+        X, Y = get(r, "X", np.int16), get(r, "Y", np.int16)
+        bandE, pulses, tf_res = get(r, "bandE", np.int32), get(r, "pulses", np.int32), get(r, "tf_res", np.int32)
+        encode, start, end, _st, shortBlocks, spread, dual, intensity, LM, coded = [int(v) for v in get(r, "ints", np.int32)]
+        total_bits, balance = [int(v) for v in get(r, "tb", np.int32)]
+        seed = C.c_uint32(int(get(r, "seed", np.uint32)[0]))
+        ein, eout = get(r, "ec_in", np.int32), get(r, "ec_out", np.int32)
+        buf = get(r, "buf_in", np.uint8)
+        want_buf = get(r, "buf_out", np.uint8)
+        seen_short.add(shortBlocks)
+        e = reflib.EcCtx()
+        e.buf = buf.ctypes.data_as(C.POINTER(C.c_ubyte))
+        (e.storage, e.end_offs, e.end_window, e.nend_bits, e.nbits_total, e.offs, e.rng, e.val, e.ext, e.rem, e.error) = \
+            [int(v) & 0xffffffff if i in (0, 1, 2, 5, 6, 7, 8) else int(v) for i, v in enumerate(ein)]
+        e.EC_DIFF = 0
+        cm = np.zeros(42, np.uint8)
+        L.opusgpu_quant_all_bands(encode, mode, start, end, p(X), p(Y), p(cm), p(bandE), p(pulses), shortBlocks, spread, dual, intensity,
+                                  p(tf_res), total_bits, balance, C.byref(e), LM, coded, C.byref(seed), 0)
+        assert L.opusgpu_get_last_error() == 0, r
+        got = np.array([e.storage, e.end_offs, e.end_window, e.nend_bits, e.nbits_total, e.offs, e.rng, e.val, e.ext, e.rem, e.error],
+                       dtype=np.int64) & 0xffffffff
+        assert np.array_equal(got, eout.astype(np.int64) & 0xffffffff), (r, got, eout)
+        st = int(e.storage)
+        assert np.array_equal(buf[:st], want_buf[:st]), (r, np.nonzero(buf[:st] != want_buf[:st])[0][:8])
+    assert seen_short == {0, 8}
+    e2 = reflib.EcCtx()
+    L.opusgpu_quant_all_bands(0, mode, 0, 21, p(X), p(Y), p(cm), p(bandE), p(pulses), 0, 2, 0, 0, p(tf_res), 100, 0, C.byref(e2), 3, 21,
+                              C.byref(seed), 0)
+    assert L.opusgpu_get_last_error() == -5                      # decode side: not through this hook
