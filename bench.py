@@ -400,12 +400,23 @@ def main(argv=None):
 
     import torch
     import torch.distributed as dist
+    # CONCENTUS_BENCH_BACKEND=gloo + CONCENTUS_BENCH_ONE_DEVICE=1: a rehearsal of the N-rank path on a ONE-GPU box -- every rank
+    # runs the real kernels on cuda:0 and the gather goes through gloo on host copies (RCCL needs one device per rank). Not a
+    # measurement: the line then carries "rehearsal": true.
+    backend = os.environ.get("CONCENTUS_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("CONCENTUS_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        assert dist.get_world_size() == a.gpus and dist.get_backend() == "nccl"
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+        assert dist.get_world_size() == a.gpus and dist.get_backend() == backend
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    host_gather = world > 1 and backend != "nccl"
     import concentus_amd as ca
     L = ca.lib.load()
 
@@ -803,9 +814,10 @@ def main(argv=None):
                     torch.cuda.current_stream().wait_stream(side[k % len(side)])
                 for pg in pending:
                     pg.wait()
-                pending = [gather_packets(out, lens, _r, world, sizes=[F] * world, trim=True, async_op=True)]
+                hc = (lambda t: t.cpu()) if host_gather else (lambda t: t)
+                pending = [gather_packets(hc(out), hc(lens), hc(_r), world, sizes=[F] * world, trim=True, async_op=True)]
                 if mixed:
-                    pending.append(gather_packets(s_pulses, s_bo, s_bo[:, :4], world, sizes=[NS] * world, async_op=True))
+                    pending.append(gather_packets(hc(s_pulses), hc(s_bo), hc(s_bo[:, :4]).contiguous(), world, sizes=[NS] * world, async_op=True))
         for pg in pending:
             pg.wait()
         torch.cuda.synchronize()
@@ -856,7 +868,7 @@ def main(argv=None):
             extra.pop("realtime_factor", None)
             F = FT
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -895,6 +907,7 @@ def main(argv=None):
             "data": "synthetic",
             "config": {"workload": workload, "frames_per_gpu": F, "channels": 2,
                        "sharding": "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0"},
+            **({"rehearsal": True} if (host_gather or one_device) else {}),
             "parity_checked": parity["checked"],
             "parity_note": parity["note"],
             "roofline": dict(roof, **extra),

@@ -159,7 +159,7 @@ _LAYOUT = {
 def _files(cache, kind, n, mode):
     out = {}
     for name, sz in _LAYOUT[kind]:
-        path = os.path.join(cache, "%s_%s_%d.npy" % (kind, name, n))
+        path = os.path.join(cache, "%s_%d.npy" % (name, n))
         if mode == "w+":
             out[name] = np.lib.format.open_memmap(path, mode="w+", dtype=np.uint8, shape=(n, SIZES[sz]))
         else:
@@ -175,9 +175,11 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         raise FileNotFoundError(CAPLIB)
     # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
     complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10) if kind == "dd" else (3, 5, 8, 10))
-    cache = cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus")
+    # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
+    cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
+                         "%s_%d_%s_%d" % (kind, n, "-".join(map(str, complexities)), seed))
     os.makedirs(cache, exist_ok=True)
-    done = os.path.join(cache, "%s_%d_%s.done" % (kind, n, "-".join(map(str, complexities))))
+    done = os.path.join(cache, "done")
     if not os.path.exists(done):
         for f in _files(cache, kind, n, "w+").values():
             f.flush()
