@@ -1,4 +1,10 @@
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02_v; mkdir -p $O
-CONCENTUS_BENCH_BACKEND=gloo CONCENTUS_BENCH_ONE_DEVICE=1 timeout -k 10 280 python3 bench.py --gpus 2 --frames 16384 --steps 3 --no-cpu-baseline > $O/bench_2r.json 2>$O/bench_2r.err; echo "rc=$?"; tail -3 $O/bench_2r.err | cut -c1-300; cut -c1-500 $O/bench_2r.json
-CONCENTUS_BENCH_BACKEND=gloo CONCENTUS_BENCH_ONE_DEVICE=1 timeout -k 10 280 python3 bench.py --gpus 2 --workload mixed --frames 32768 --steps 2 --no-cpu-baseline > $O/bench_2r_mixed.json 2>$O/bench_2r_mixed.err; echo "rc=$?"; tail -3 $O/bench_2r_mixed.err | cut -c1-300; cut -c1-400 $O/bench_2r_mixed.json
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_w; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for a in 32 64; do
+export OPUSGPU_LANE_FRAMES=$a
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f$a -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w$a -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof.err
+python3 $R/tools/pmc_traffic.py $O/f$a $O/w$a $O/traffic_$a.json | grep back_lane
+python3 $R/bench.py --steps 10 --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
+import json,sys;d=json.loads(sys.stdin.read());print($a, d['value'], d['ms_per_step'], [(k['kernel'][5:],k['avg_launch_ms']) for k in d['roofline']['kernels']][:2])"
+done
