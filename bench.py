@@ -15,6 +15,7 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  silk_nlsf       silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX) over 65 536 distinct records
   silk_lpc        silk_find_LPC_FIX (Burg + silk_A2NLSF, and the NLSF interpolation search at complexity >= 4) over 65 536
                   distinct records: the SILK analysis step that feeds / consumes silk_burg_modified.
   mixed           BASELINE.json configs[4]: per GPU 131 072 units = 7/8 CELT frames (as celt) + 1/8 SILK records (as
@@ -59,7 +60,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -304,6 +305,26 @@ def cpu_baseline_silk_lpc(lin):
     return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "%d silk_find_LPC_FIX records per pass through the host build of concentus_amd/csrc/silk_lpc_dev.h, repeated "
                       "~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
+
+
+def cpu_baseline_silk_nlsf(nin, ein):
+    """CPU baseline for silk_process_NLSFs + silk_residual_energy_FIX records: the kernel sources compiled for the host
+    (tests/emu, kind "port"), chunks on a thread pool."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulib
+    emu = emulib.lib()
+    cores = host_threads()
+    n = nin.shape[0]
+    out = np.zeros((n, 120), np.uint8)
+    eout = np.zeros((n, 40), np.uint8)
+
+    def work(lo, hi):
+        emu.emu_silk_process_nlsfs(C.c_void_p(nin.ctypes.data + lo * 96), C.c_void_p(out.ctypes.data + lo * 120), C.c_long(hi - lo))
+        emu.emu_silk_residual_energy(C.c_void_p(ein.ctypes.data + lo * 864), C.c_void_p(eout.ctypes.data + lo * 40), C.c_long(hi - lo))
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d (silk_process_NLSFs + silk_residual_energy_FIX) record pairs per pass through the host build of "
+                      "concentus_amd/csrc/silk_nlsf_dev.h, repeated ~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
 def cpu_baseline_silk_dd(di, st0):
@@ -644,6 +665,50 @@ def main(argv=None):
             if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
                 raise SystemExit("PARITY FAILURE (silk_find_LPC)")
             parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
+    elif a.workload == "silk_nlsf":
+        F = a.frames or 65536
+        steps = a.steps or 10
+        warm = a.warmup if a.warmup is not None else 2
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        if not silk_corpus.available():
+            raise SystemExit("silk_nlsf needs oracle/_ref/libopus_ref_silkcap.so (records are captured from the reference encoder)")
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "pred", seed=20260401 + 1000003 * rank).items()}
+        ni, ei = torch.from_numpy(rec["nlsf_in"]).to(dev), torch.from_numpy(rec["resnrg_in"]).to(dev)
+        no = torch.empty((F, 120), dtype=torch.uint8, device=dev)
+        eo = torch.empty((F, 40), dtype=torch.uint8, device=dev)
+        for _ in range(warm):
+            ca.silk_process_NLSFs(ni, no)
+            ca.silk_residual_energy(ei, eo)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.silk_process_NLSFs(ni, no)
+            ev[k][1].record()
+            ca.silk_residual_energy(ei, eo)
+            ev[k][2].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_process_nlsfs_kernel"
+        kbytes = F * (96 + 120)
+        limiter = "latency / VALU issue (32-entry insertion sort and a 16-step 4-state trellis per survivor, one lane per record)"
+        metric = "SILK 16kHz mono 20ms frames/sec (silk_process_NLSFs + silk_residual_energy_FIX records)"
+        workload = ("%d distinct records per GPU captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s VOIP, "
+                    "complexity 3/5/8/10 in turn), silk_process_NLSFs then silk_residual_energy_FIX (the tail of "
+                    "silk_find_pred_coefs_FIX), bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {"residual_energy_kernel_ms": round(float(np.mean([e[1].elapsed_time(e[2]) for e in ev])), 4)}
+        m_cpu = min(F, 4096)
+        cpu = (lambda: cpu_baseline_silk_nlsf(np.ascontiguousarray(rec["nlsf_in"][:m_cpu]), np.ascontiguousarray(rec["resnrg_in"][:m_cpu])))
+        if not a.no_parity and rank == 0:
+            if not (np.array_equal(no.cpu().numpy()[:, :116], rec["nlsf_out"][:, :116])
+                    and np.array_equal(eo.cpu().numpy()[:, :32], rec["resnrg_out"][:, :32])):
+                raise SystemExit("PARITY FAILURE (silk_process_NLSFs / silk_residual_energy_FIX)")
+            parity = {"checked": F, "note": "every record (NLSFIndices, quantised NLSFs, PredCoef_Q12; nrgs, nrgsQ) vs the reference's own captured outputs"}
     elif a.workload == "silk":
         F = a.frames or 65536
         steps = a.steps or 20

@@ -29,6 +29,26 @@ __device__ __forceinline__ bool find_lpc_record_ok(const opusgpu_find_lpc_in &in
     return true;
 }
 
+__device__ __forceinline__ bool process_nlsf_record_ok(const opusgpu_process_nlsf_in &in)
+{
+    const int D = in.predictLPCOrder;
+    if (!((in.nb_subfr == 2 || in.nb_subfr == 4) && (D == 10 || D == 16))) return false;
+    if ((unsigned)in.speech_activity_Q8 > 256u || (unsigned)in.useInterpolatedNLSFs > 1u || (unsigned)in.NLSFInterpCoef_Q2 > 4u) return false;
+    if (in.NLSF_MSVQ_Survivors < 1 || in.NLSF_MSVQ_Survivors > 32 || (unsigned)in.signalType > 2u) return false;
+    for (int k = 0; k < D; k++)
+        if (in.NLSF_Q15[k] < 0 || in.prev_NLSFq_Q15[k] < 0) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool res_nrg_record_ok(const opusgpu_res_nrg_in &in)
+{
+    const int L = in.subfr_length, n = in.nb_subfr, D = in.LPC_order;
+    if (!((n == 2 || n == 4) && D >= 2 && D <= 16 && !(D & 1) && L >= 1 && L <= 80 && (L + D) * n <= OPUSGPU_SILK_BURG_MAX_X)) return false;
+    for (int k = 0; k < n; k++)
+        if (in.gains[k] <= 0) return false;                      // quantisation gains are positive (silk_CLZ32(gain) - 1 is a shift count)
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -150,3 +150,56 @@ def silk_find_LPC(lpc_in, lpc_out=None):
     rc = _lib.load().opusgpu_silk_find_lpc_batch(lpc_in.data_ptr(), lpc_out.data_ptr(), n, _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_find_lpc_batch")
     return lpc_out
+
+
+class ProcessNlsfIn(C.Structure):
+    """opusgpu_process_nlsf_in: one silk_process_NLSFs() call (opus-fix/silk/process_NLSFs.c:35)."""
+    _fields_ = [("NLSF_Q15", C.c_int16 * 16), ("prev_NLSFq_Q15", C.c_int16 * 16), ("speech_activity_Q8", C.c_int32),
+                ("nb_subfr", C.c_int32), ("predictLPCOrder", C.c_int32), ("useInterpolatedNLSFs", C.c_int32),
+                ("NLSFInterpCoef_Q2", C.c_int32), ("NLSF_MSVQ_Survivors", C.c_int32), ("signalType", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ProcessNlsfOut(C.Structure):
+    _fields_ = [("PredCoef_Q12", C.c_int16 * 32), ("NLSF_Q15", C.c_int16 * 16), ("NLSFIndices", C.c_int8 * 17), ("pad", C.c_int8 * 3),
+                ("status", C.c_int32)]
+
+
+class ResNrgIn(C.Structure):
+    """opusgpu_res_nrg_in: one silk_residual_energy_FIX() call (opus-fix/silk/fixed/residual_energy_FIX.c:37)."""
+    _fields_ = [("x", C.c_int16 * 384), ("a_Q12", C.c_int16 * 32), ("gains", C.c_int32 * 4), ("subfr_length", C.c_int32),
+                ("nb_subfr", C.c_int32), ("LPC_order", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ResNrgOut(C.Structure):
+    _fields_ = [("nrgs", C.c_int32 * 4), ("nrgsQ", C.c_int32 * 4), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+SIZES["process_nlsf_in"] = C.sizeof(ProcessNlsfIn)
+SIZES["process_nlsf_out"] = C.sizeof(ProcessNlsfOut)
+SIZES["res_nrg_in"] = C.sizeof(ResNrgIn)
+SIZES["res_nrg_out"] = C.sizeof(ResNrgOut)
+
+
+def _record_op(symbol, rec_in, rec_out, size_in, size_out, name):
+    import torch
+    _check(rec_in, size_in, name + "_in")
+    n = rec_in.shape[0]
+    if rec_out is None:
+        rec_out = torch.empty((n, size_out), dtype=torch.uint8, device=rec_in.device)
+    _check(rec_out, size_out, name + "_out")
+    rc = getattr(_lib.load(), symbol)(rec_in.data_ptr(), rec_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, symbol)
+    return rec_out
+
+
+def silk_process_NLSFs(nlsf_in, nlsf_out=None):
+    """silk_process_NLSFs() over a batch of records: nlsf_in uint8 [N][96] (opusgpu_process_nlsf_in) -> uint8 [N][120]
+    (PredCoef_Q12 int16[2][16], quantised NLSF_Q15 int16[16], NLSFIndices int8[17], status)."""
+    return _record_op("opusgpu_silk_process_nlsfs_batch", nlsf_in, nlsf_out, SIZES["process_nlsf_in"], SIZES["process_nlsf_out"],
+                      "nlsf")
+
+
+def silk_residual_energy(nrg_in, nrg_out=None):
+    """silk_residual_energy_FIX() over a batch of records: nrg_in uint8 [N][864] (opusgpu_res_nrg_in) -> uint8 [N][40]
+    (nrgs int32[4], nrgsQ int32[4], status)."""
+    return _record_op("opusgpu_silk_residual_energy_batch", nrg_in, nrg_out, SIZES["res_nrg_in"], SIZES["res_nrg_out"], "res_nrg")

@@ -62,6 +62,7 @@ void opusgpu_renormalise_vector(int16_t *X, int N, int gain, int arch);
 #define OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE 30        /* .quantOffsetType */
 #define OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2 31      /* .NLSFInterpCoef_Q2 */
 #define OPUSGPU_REF_OFF_SEED 34                     /* .Seed */
+#define OPUSGPU_REF_OFF_NLSF_INDICES 8              /* .NLSFIndices[17]                           (opus_int8) */
 void opusgpu_silk_NSQ(const void *psEncC, void *NSQ, void *psIndices, const int32_t x_Q3[], int8_t pulses[],
                       const int16_t PredCoef_Q12[/*2 * 16*/], const int16_t LTPCoef_Q14[/*5 * 4*/], const int16_t AR2_Q13[/*4 * 16*/],
                       const int HarmShapeGain_Q14[/*4*/], const int Tilt_Q14[/*4*/], const int32_t LF_shp_Q14[/*4*/],
@@ -89,6 +90,21 @@ void opusgpu_quant_all_bands(int encode, const void *m, int start, int end, int1
  * predictLPCOrder / useInterpolatedNLSFs / first_frame_after_reset / prev_NLSFq_Q15, writes NLSF_Q15[predictLPCOrder] and
  * psEncC->indices.NLSFInterpCoef_Q2. */
 void opusgpu_silk_find_LPC_FIX(void *psEncC, int16_t NLSF_Q15[], const int16_t x[], const int32_t minInvGain_Q30);
+
+/* silk_process_NLSFs(psEncC, PredCoef_Q12, pNLSF_Q15, prev_NLSFq_Q15) -- opus-fix/silk/process_NLSFs.c:35-106 (declared in
+ * silk/main.h, called at silk/fixed/find_pred_coefs_FIX.c:139): reads psEncC->speech_activity_Q8 / nb_subfr / predictLPCOrder /
+ * useInterpolatedNLSFs / NLSF_MSVQ_Survivors / indices.signalType / indices.NLSFInterpCoef_Q2 (the codebook follows
+ * predictLPCOrder, as psEncC->psNLSF_CB does), quantises pNLSF_Q15 in place, writes PredCoef_Q12[2][16] and
+ * psEncC->indices.NLSFIndices[predictLPCOrder + 1]. */
+#define OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8 4556     /* silk_encoder_state.speech_activity_Q8      (opus_int) */
+#define OPUSGPU_REF_OFF_NLSF_MSVQ_SURVIVORS 4692    /* .NLSF_MSVQ_Survivors */
+void opusgpu_silk_process_NLSFs(void *psEncC, int16_t PredCoef_Q12[/*2 * 16*/], int16_t pNLSF_Q15[], const int16_t prev_NLSFq_Q15[]);
+
+/* silk_residual_energy_FIX(nrgs, nrgsQ, x, a_Q12, gains, subfr_length, nb_subfr, LPC_order, arch) --
+ * opus-fix/silk/fixed/residual_energy_FIX.c:37-98 (declared in silk/fixed/main_FIX.h, called at
+ * silk/fixed/find_pred_coefs_FIX.c:142). a_Q12 is the reference's opus_int16[2][MAX_LPC_ORDER]. */
+void opusgpu_silk_residual_energy_FIX(int32_t nrgs[], int nrgsQ[], const int16_t x[], int16_t a_Q12[/*2 * 16*/], const int32_t gains[],
+                                      const int subfr_length, const int nb_subfr, const int LPC_order, int arch);
 
 #ifdef __cplusplus
 }

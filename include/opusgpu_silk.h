@@ -139,6 +139,56 @@ typedef struct opusgpu_find_lpc_out {
 
 int opusgpu_silk_find_lpc_batch(const opusgpu_find_lpc_in *d_in, opusgpu_find_lpc_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_process_NLSFs, batched (second slice) -------------------------------------------------------
+ * Replaces silk_process_NLSFs(psEncC, PredCoef_Q12, pNLSF_Q15, prev_NLSFq_Q15) (opus-fix/silk/process_NLSFs.c:35-106, called
+ * at silk/fixed/find_pred_coefs_FIX.c:139): NLSF weights, first-stage VQ, survivor trellis (silk_NLSF_encode /
+ * silk_NLSF_del_dec_quant), decode, silk_NLSF2A for both frame halves. A record is the arguments of one call plus the
+ * psEncC fields it reads; the codebook follows predictLPCOrder (16: silk_NLSF_CB_WB, 10: silk_NLSF_CB_NB_MB). */
+typedef struct opusgpu_process_nlsf_in {
+    int16_t NLSF_Q15[OPUSGPU_SILK_MAX_ORDER];        /* pNLSF_Q15 on entry (from silk_find_LPC_FIX) */
+    int16_t prev_NLSFq_Q15[OPUSGPU_SILK_MAX_ORDER];
+    int32_t speech_activity_Q8;                      /* 0..256 */
+    int32_t nb_subfr;                                /* 2 or 4 */
+    int32_t predictLPCOrder;                         /* 10 or 16 */
+    int32_t useInterpolatedNLSFs;
+    int32_t NLSFInterpCoef_Q2;                       /* psEncC->indices.NLSFInterpCoef_Q2, 0..4 */
+    int32_t NLSF_MSVQ_Survivors;                     /* 1..32 */
+    int32_t signalType;                              /* 0..2 */
+    int32_t reserved;
+} opusgpu_process_nlsf_in;
+
+typedef struct opusgpu_process_nlsf_out {
+    int16_t PredCoef_Q12[2][OPUSGPU_SILK_MAX_ORDER];
+    int16_t NLSF_Q15[OPUSGPU_SILK_MAX_ORDER];        /* the quantised NLSFs (pNLSF_Q15 on return) */
+    int8_t NLSFIndices[OPUSGPU_SILK_MAX_ORDER + 1];  /* psEncC->indices.NLSFIndices */
+    int8_t pad[3];
+    int32_t status;
+} opusgpu_process_nlsf_out;
+
+int opusgpu_silk_process_nlsfs_batch(const opusgpu_process_nlsf_in *d_in, opusgpu_process_nlsf_out *d_out, int n, void *hip_stream);
+
+/* ---- silk_residual_energy_FIX, batched ---------------------------------------------------------------------------------
+ * Replaces silk_residual_energy_FIX(nrgs, nrgsQ, x, a_Q12, gains, subfr_length, nb_subfr, LPC_order, arch)
+ * (opus-fix/silk/fixed/residual_energy_FIX.c:37-98, called at silk/fixed/find_pred_coefs_FIX.c:142). */
+typedef struct opusgpu_res_nrg_in {
+    int16_t x[OPUSGPU_SILK_BURG_MAX_X];              /* LPC_in_pre: nb_subfr * (subfr_length + LPC_order) samples */
+    int16_t a_Q12[2][OPUSGPU_SILK_MAX_ORDER];
+    int32_t gains[4];
+    int32_t subfr_length;
+    int32_t nb_subfr;                                /* 2 or 4 */
+    int32_t LPC_order;
+    int32_t reserved;
+} opusgpu_res_nrg_in;
+
+typedef struct opusgpu_res_nrg_out {
+    int32_t nrgs[4];
+    int32_t nrgsQ[4];
+    int32_t status;
+    int32_t reserved;
+} opusgpu_res_nrg_out;
+
+int opusgpu_silk_residual_energy_batch(const opusgpu_res_nrg_in *d_in, opusgpu_res_nrg_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

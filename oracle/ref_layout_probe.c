@@ -16,9 +16,10 @@ int main(void)
     F(silk_encoder_state, ltp_mem_length); F(silk_encoder_state, predictLPCOrder); F(silk_encoder_state, shapingLPCOrder);
     F(silk_encoder_state, nStatesDelayedDecision); F(silk_encoder_state, warping_Q16); F(silk_encoder_state, arch);
     F(silk_encoder_state, useInterpolatedNLSFs); F(silk_encoder_state, first_frame_after_reset); F(silk_encoder_state, prev_NLSFq_Q15);
-    F(silk_encoder_state, indices);
+    F(silk_encoder_state, indices); F(silk_encoder_state, speech_activity_Q8); F(silk_encoder_state, NLSF_MSVQ_Survivors);
+    F(silk_encoder_state, psNLSF_CB);
     F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
-    F(SideInfoIndices, Seed);
+    F(SideInfoIndices, Seed); F(SideInfoIndices, NLSFIndices);
     printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu\n}\n",
            sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state));
     return 0;

@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -188,5 +188,80 @@ void __wrap_silk_find_LPC_FIX(silk_encoder_state *psEncC, opus_int16 NLSF_Q15[],
         g_lout[rec].NLSFInterpCoef_Q2 = psEncC->indices.NLSFInterpCoef_Q2;
         g_lout[rec].status = 0;
         g_nl++;
+    }
+}
+
+/* ---- silk_process_NLSFs (opus-fix/silk/process_NLSFs.c:35) and silk_residual_energy_FIX (opus-fix/silk/fixed/residual_energy_FIX.c:37):
+ * the two calls silk_find_pred_coefs_FIX makes after silk_find_LPC_FIX (find_pred_coefs_FIX.c:139-143) ---- */
+static opusgpu_process_nlsf_in *g_pin; static opusgpu_process_nlsf_out *g_pout; static int g_np;
+static opusgpu_res_nrg_in *g_ein; static opusgpu_res_nrg_out *g_eout; static int g_ne, g_capp;
+void refcap_start_pred(int max_records)
+{
+    g_capp = max_records; g_np = g_ne = 0; g_on = 1;
+    g_pin = (opusgpu_process_nlsf_in *)calloc(max_records, sizeof(*g_pin));
+    g_pout = (opusgpu_process_nlsf_out *)calloc(max_records, sizeof(*g_pout));
+    g_ein = (opusgpu_res_nrg_in *)calloc(max_records, sizeof(*g_ein));
+    g_eout = (opusgpu_res_nrg_out *)calloc(max_records, sizeof(*g_eout));
+}
+int refcap_count_pred(int which) { return which == 0 ? g_np : g_ne; }
+int refcap_sizes_pred(int which)
+{
+    return which == 0 ? sizeof(opusgpu_process_nlsf_in) : which == 1 ? sizeof(opusgpu_process_nlsf_out)
+         : which == 2 ? sizeof(opusgpu_res_nrg_in) : sizeof(opusgpu_res_nrg_out);
+}
+void refcap_get_pred(void *pin, void *pout, void *ein, void *eout)
+{
+    memcpy(pin, g_pin, (size_t)g_np * sizeof(*g_pin)); memcpy(pout, g_pout, (size_t)g_np * sizeof(*g_pout));
+    memcpy(ein, g_ein, (size_t)g_ne * sizeof(*g_ein)); memcpy(eout, g_eout, (size_t)g_ne * sizeof(*g_eout));
+}
+
+void __real_silk_process_NLSFs(silk_encoder_state *psEncC, opus_int16 PredCoef_Q12[2][MAX_LPC_ORDER], opus_int16 pNLSF_Q15[MAX_LPC_ORDER],
+                               const opus_int16 prev_NLSFq_Q15[MAX_LPC_ORDER]);
+void __wrap_silk_process_NLSFs(silk_encoder_state *psEncC, opus_int16 PredCoef_Q12[2][MAX_LPC_ORDER], opus_int16 pNLSF_Q15[MAX_LPC_ORDER],
+                               const opus_int16 prev_NLSFq_Q15[MAX_LPC_ORDER])
+{
+    int rec = (g_on && g_pin && g_np < g_capp) ? g_np : -1;
+    if (rec >= 0) {
+        opusgpu_process_nlsf_in *r = &g_pin[rec];
+        memcpy(r->NLSF_Q15, pNLSF_Q15, sizeof(opus_int16) * psEncC->predictLPCOrder);
+        memcpy(r->prev_NLSFq_Q15, prev_NLSFq_Q15, sizeof(opus_int16) * psEncC->predictLPCOrder);
+        r->speech_activity_Q8 = psEncC->speech_activity_Q8; r->nb_subfr = psEncC->nb_subfr; r->predictLPCOrder = psEncC->predictLPCOrder;
+        r->useInterpolatedNLSFs = psEncC->useInterpolatedNLSFs; r->NLSFInterpCoef_Q2 = psEncC->indices.NLSFInterpCoef_Q2;
+        r->NLSF_MSVQ_Survivors = psEncC->NLSF_MSVQ_Survivors; r->signalType = psEncC->indices.signalType;
+    }
+    __real_silk_process_NLSFs(psEncC, PredCoef_Q12, pNLSF_Q15, prev_NLSFq_Q15);
+    if (rec >= 0) {
+        opusgpu_process_nlsf_out *o = &g_pout[rec];
+        memcpy(o->PredCoef_Q12[0], PredCoef_Q12[0], sizeof(opus_int16) * psEncC->predictLPCOrder);
+        memcpy(o->PredCoef_Q12[1], PredCoef_Q12[1], sizeof(opus_int16) * psEncC->predictLPCOrder);
+        memcpy(o->NLSF_Q15, pNLSF_Q15, sizeof(opus_int16) * psEncC->predictLPCOrder);
+        memcpy(o->NLSFIndices, psEncC->indices.NLSFIndices, psEncC->predictLPCOrder + 1);
+        o->status = 0;
+        g_np++;
+    }
+}
+
+void __real_silk_residual_energy_FIX(opus_int32 nrgs[MAX_NB_SUBFR], opus_int nrgsQ[MAX_NB_SUBFR], const opus_int16 x[],
+                                     opus_int16 a_Q12[2][MAX_LPC_ORDER], const opus_int32 gains[MAX_NB_SUBFR], const opus_int subfr_length,
+                                     const opus_int nb_subfr, const opus_int LPC_order, int arch);
+void __wrap_silk_residual_energy_FIX(opus_int32 nrgs[MAX_NB_SUBFR], opus_int nrgsQ[MAX_NB_SUBFR], const opus_int16 x[],
+                                     opus_int16 a_Q12[2][MAX_LPC_ORDER], const opus_int32 gains[MAX_NB_SUBFR], const opus_int subfr_length,
+                                     const opus_int nb_subfr, const opus_int LPC_order, int arch)
+{
+    const int nx = (subfr_length + LPC_order) * nb_subfr;
+    int rec = (g_on && g_ein && g_ne < g_capp && nx <= OPUSGPU_SILK_BURG_MAX_X) ? g_ne : -1;
+    if (rec >= 0) {
+        opusgpu_res_nrg_in *r = &g_ein[rec];
+        memcpy(r->x, x, sizeof(opus_int16) * nx);
+        memcpy(r->a_Q12[0], a_Q12[0], sizeof(opus_int16) * LPC_order); memcpy(r->a_Q12[1], a_Q12[1], sizeof(opus_int16) * LPC_order);
+        memcpy(r->gains, gains, sizeof(opus_int32) * nb_subfr);
+        r->subfr_length = subfr_length; r->nb_subfr = nb_subfr; r->LPC_order = LPC_order;
+    }
+    __real_silk_residual_energy_FIX(nrgs, nrgsQ, x, a_Q12, gains, subfr_length, nb_subfr, LPC_order, arch);
+    if (rec >= 0) {
+        memcpy(g_eout[rec].nrgs, nrgs, sizeof(opus_int32) * nb_subfr);
+        for (int k = 0; k < nb_subfr; k++) g_eout[rec].nrgsQ[k] = nrgsQ[k];
+        g_eout[rec].status = 0;
+        g_ne++;
     }
 }

@@ -172,3 +172,32 @@ extern "C" void emu_silk_find_lpc(const opusgpu_find_lpc_in *in, opusgpu_find_lp
         out[r].status = 0;
     }
 }
+
+// ---- silk_process_NLSFs / silk_residual_energy_FIX, host build of concentus_amd/csrc/silk_nlsf_dev.h (tests/test_silk_nlsf_cpu.py) ----
+#include "../../concentus_amd/csrc/silk_nlsf_dev.h"
+extern "C" void emu_silk_process_nlsfs(const opusgpu_process_nlsf_in *in, opusgpu_process_nlsf_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        int16_t nlsf[16], pc[2][16];
+        int8_t idx[17];
+        memset(pc, 0, sizeof(pc));
+        memset(idx, 0, sizeof(idx));
+        for (int k = 0; k < 16; k++) nlsf[k] = in[r].NLSF_Q15[k];
+        ca::silk_process_NLSFs_dev(pc, idx, nlsf, in[r].prev_NLSFq_Q15, in[r].speech_activity_Q8, in[r].nb_subfr, in[r].predictLPCOrder,
+                                   in[r].useInterpolatedNLSFs, in[r].NLSFInterpCoef_Q2, in[r].NLSF_MSVQ_Survivors, in[r].signalType);
+        memset(&out[r], 0, sizeof(out[r]));
+        for (int k = 0; k < in[r].predictLPCOrder; k++) {
+            out[r].PredCoef_Q12[0][k] = pc[0][k]; out[r].PredCoef_Q12[1][k] = pc[1][k]; out[r].NLSF_Q15[k] = nlsf[k];
+        }
+        for (int k = 0; k <= in[r].predictLPCOrder; k++) out[r].NLSFIndices[k] = idx[k];
+    }
+}
+extern "C" void emu_silk_residual_energy(const opusgpu_res_nrg_in *in, opusgpu_res_nrg_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        int32_t nrgs[4] = {0, 0, 0, 0}, nrgsQ[4] = {0, 0, 0, 0};
+        ca::silk_residual_energy_dev(nrgs, nrgsQ, in[r].x, in[r].a_Q12, in[r].gains, in[r].subfr_length, in[r].nb_subfr, in[r].LPC_order);
+        memset(&out[r], 0, sizeof(out[r]));
+        for (int k = 0; k < in[r].nb_subfr; k++) { out[r].nrgs[k] = nrgs[k]; out[r].nrgsQ[k] = nrgsQ[k]; }
+    }
+}

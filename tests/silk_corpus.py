@@ -27,7 +27,7 @@ SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder eac
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
 SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324,
-         "lpc_in": 832, "lpc_out": 40}
+         "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40}
 
 
 def available():
@@ -103,6 +103,8 @@ def _capture_segment(args):
         lib.refcap_start_dd(cap)
     elif kind == "lpc":
         lib.refcap_start_lpc(cap)
+    elif kind == "pred":
+        lib.refcap_start_pred(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -115,7 +117,15 @@ def _capture_segment(args):
         fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
         assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
-    if kind == "lpc":
+    if kind == "pred":
+        npr, ne = lib.refcap_count_pred(0), lib.refcap_count_pred(1)
+        assert npr >= nfr and ne >= nfr, (npr, ne, nfr)
+        bufs = [np.zeros((npr, SIZES["nlsf_in"]), np.uint8), np.zeros((npr, SIZES["nlsf_out"]), np.uint8),
+                np.zeros((ne, SIZES["resnrg_in"]), np.uint8), np.zeros((ne, SIZES["resnrg_out"]), np.uint8)]
+        lib.refcap_get_pred(*[_p(b) for b in bufs])
+        for name, b in zip(("nlsf_in", "nlsf_out", "resnrg_in", "resnrg_out"), bufs):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    elif kind == "lpc":
         nl = lib.refcap_count_lpc()
         assert nl >= nfr, (nl, nfr)
         bufs = [np.zeros((nl, SIZES["lpc_in"]), np.uint8), np.zeros((nl, SIZES["lpc_out"]), np.uint8)]
@@ -153,6 +163,7 @@ _LAYOUT = {
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
     "dd": (("dd_in", "dd_in"), ("dd_state_in", "nsq_state"), ("dd_state_out", "nsq_state"), ("dd_out", "dd_out")),
     "lpc": (("lpc_in", "lpc_in"), ("lpc_out", "lpc_out")),
+    "pred": (("nlsf_in", "nlsf_in"), ("nlsf_out", "nlsf_out"), ("resnrg_in", "resnrg_in"), ("resnrg_out", "resnrg_out")),
 }
 
 
@@ -173,6 +184,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
     if not available():
         raise FileNotFoundError(CAPLIB)
+    # kind "pred": silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX), complexities as "lpc"
     # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
     complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10) if kind == "dd" else (3, 5, 8, 10))
     # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
@@ -187,7 +199,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863}[kind], complexities[k % len(complexities)],
                          row, take, n))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

@@ -196,6 +196,65 @@ def test_silk_find_LPC_FIX_hook_with_the_reference_argument_list(L, ref):
         assert np.array_equal(outs[1][0], want[k, :32].view(np.int16)) and outs[1][1] == want[k, 32:36].view(np.int32)[0]
 
 
+def test_silk_process_NLSFs_and_residual_energy_hooks_with_the_reference_argument_lists(L, ref):
+    """opusgpu_silk_process_NLSFs(psEncC, PredCoef_Q12, pNLSF_Q15, prev_NLSFq_Q15) and opusgpu_silk_residual_energy_FIX(nrgs, nrgsQ,
+    x, a_Q12, gains, subfr_length, nb_subfr, LPC_order, arch) against the same functions of the compiled reference. The first
+    is driven through a zeroed silk_encoder_state in which only the fields it reads are set (offsets of
+    include/opusgpu_hooks.h) -- except psNLSF_CB, a pointer into the reference's own tables, which the reference run needs and
+    takes from a silk_encoder_state the reference initialised itself."""
+    import silk_corpus
+    r, _ = ref
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    d = header_defines()
+    rec = silk_corpus.corpus(4096, "pred")
+    nin, nwant = np.asarray(rec["nlsf_in"]), np.asarray(rec["nlsf_out"])
+    ein, ewant = np.asarray(rec["resnrg_in"]), np.asarray(rec["resnrg_out"])
+    # psNLSF_CB: offset from oracle/_ref/layout.json (offsetof() compiled against the reference's headers); the GPU hook never reads it
+    import json
+    off_cb = json.load(open(os.path.join(ROOT, "oracle", "_ref", "layout.json")))["silk_encoder_state.psNLSF_CB"]
+    cb_wb = C.addressof(C.c_char.in_dll(r, "silk_NLSF_CB_WB"))
+    cb_nb = C.addressof(C.c_char.in_dll(r, "silk_NLSF_CB_NB_MB"))
+    for k in range(0, 4096, 293):
+        row = np.ascontiguousarray(nin[k])
+        hdr = row[64:96].view(np.int32)
+        outs = []
+        for which, fn in (("ref", r.silk_process_NLSFs), ("gpu", L.opusgpu_silk_process_NLSFs)):
+            enc = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE"] + 64, np.uint8)
+            for off, v in ((d["OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8"], hdr[0]), (d["OPUSGPU_REF_OFF_NB_SUBFR"], hdr[1]),
+                           (d["OPUSGPU_REF_OFF_PREDICT_LPC_ORDER"], hdr[2]), (d["OPUSGPU_REF_OFF_USE_INTERPOLATED_NLSFS"], hdr[3]),
+                           (d["OPUSGPU_REF_OFF_NLSF_MSVQ_SURVIVORS"], hdr[5])):
+                enc[off:off + 4].view(np.int32)[0] = v
+            ind = d["OPUSGPU_REF_OFF_INDICES"]
+            enc[ind + d["OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2"]] = np.uint8(hdr[4])
+            enc[ind + d["OPUSGPU_REF_OFF_SIGNAL_TYPE"]] = np.uint8(hdr[6])
+            if which == "ref":
+                enc[off_cb:off_cb + 8].view(np.uint64)[0] = cb_wb if hdr[2] == 16 else cb_nb
+            pc = np.zeros(32, np.int16)
+            nlsf = np.ascontiguousarray(row[:32].view(np.int16)).copy()
+            prev = np.ascontiguousarray(row[32:64].view(np.int16)).copy()
+            fn(p(enc), p(pc), p(nlsf), p(prev))
+            outs.append((pc, nlsf, enc[ind + d["OPUSGPU_REF_OFF_NLSF_INDICES"]:][:17].copy()))
+        assert L.opusgpu_get_last_error() == 0
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), k
+        assert np.array_equal(outs[1][0].view(np.uint8), nwant[k, :64]) and np.array_equal(outs[1][2], nwant[k, 96:113])
+
+        row = np.ascontiguousarray(ein[k])
+        eh = row[848:864].view(np.int32)
+        outs = []
+        for fn in (r.silk_residual_energy_FIX, L.opusgpu_silk_residual_energy_FIX):
+            nrgs, nrgsQ = np.zeros(4, np.int32), np.zeros(4, np.int32)
+            x = np.ascontiguousarray(row[:768].view(np.int16)).copy()
+            a = np.ascontiguousarray(row[768:832].view(np.int16)).copy()
+            g = np.ascontiguousarray(row[832:848].view(np.int32)).copy()
+            fn(p(nrgs), p(nrgsQ), p(x), p(a), p(g), C.c_int(int(eh[0])), C.c_int(int(eh[1])), C.c_int(int(eh[2])), C.c_int(0))
+            outs.append((nrgs, nrgsQ))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), k
+        assert np.array_equal(outs[1][0].view(np.uint8), ewant[k, :16]) and np.array_equal(outs[1][1].view(np.uint8), ewant[k, 16:32])
+
+
 def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
     """opusgpu_quant_all_bands with the tree's 21-argument list and its ec_ctx (EC_DIFF included) against quant_all_bands of the
     compiled reference ON THE CALLS THE REFERENCE ENCODER ITSELF MAKES: oracle/_ref/libopus_ref_celtcap.so (--wrap=quant_all_bands,

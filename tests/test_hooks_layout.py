@@ -29,6 +29,9 @@ PAIRS = {
     "OPUSGPU_REF_OFF_QUANT_OFFSET_TYPE": "SideInfoIndices.quantOffsetType",
     "OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2": "SideInfoIndices.NLSFInterpCoef_Q2",
     "OPUSGPU_REF_OFF_SEED": "SideInfoIndices.Seed",
+    "OPUSGPU_REF_OFF_NLSF_INDICES": "SideInfoIndices.NLSFIndices",
+    "OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8": "silk_encoder_state.speech_activity_Q8",
+    "OPUSGPU_REF_OFF_NLSF_MSVQ_SURVIVORS": "silk_encoder_state.NLSF_MSVQ_Survivors",
 }
 
 

@@ -287,3 +287,42 @@ def test_find_lpc_32768_distinct_records_vs_reference_outputs(ca):
     assert ca.silk.bad_records() == 2
     good = np.setdiff1d(np.arange(256), [7, 9])
     assert np.array_equal(out2[good, :36], want[:256][good, :36]) and (out2[[7, 9], 36:40].view(np.int32) == -1).all()
+
+
+# ---- silk_process_NLSFs + silk_residual_energy_FIX (second slice): one lane per record ----
+def test_process_nlsfs_and_residual_energy_32768_distinct_records_vs_reference_outputs(ca):
+    """The tail of silk_find_pred_coefs_FIX on the GPU against the outputs the unmodified reference produced when the records
+    were captured (tests/silk_corpus.py kind "pred": complexity 3 / 5 / 8 / 10 in turn -> different survivor counts, with and
+    without NLSF interpolation, voiced and unvoiced): NLSFIndices, quantised NLSFs, both PredCoef_Q12 rows; the four residual
+    energies and their Q values."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "pred")
+    out = ca.silk_process_NLSFs(_dev(rec["nlsf_in"]))
+    eout = ca.silk_residual_energy(_dev(rec["resnrg_in"]))
+    torch.cuda.synchronize()
+    out, eout = out.cpu().numpy(), eout.cpu().numpy()
+    want, ewant = np.asarray(rec["nlsf_out"]), np.asarray(rec["resnrg_out"])
+    assert (out[:, 116:120].view(np.int32) == 0).all() and (eout[:, 32:36].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :116] != want[:, :116]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], out[bad[:1], 96:113].view(np.int8), want[bad[:1], 96:113].view(np.int8))
+    bad = np.nonzero((eout[:, :32] != ewant[:, :32]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], eout[bad[:1], :32].view(np.int32), ewant[bad[:1], :32].view(np.int32))
+    hdr = np.asarray(rec["nlsf_in"])[:, 64:96].view(np.int32)
+    assert len(np.unique(hdr[:, 5])) >= 3 and (hdr[:, 4] < 4).sum() > 500 and (hdr[:, 6] == 2).sum() > 500
+    # corrupted headers are skipped and counted, their neighbours are unaffected
+    ca.silk.bad_records()
+    nin = np.array(rec["nlsf_in"][:256])
+    nin[5, 64 + 20:64 + 24].view(np.int32)[0] = 99            # NLSF_MSVQ_Survivors
+    nin[11, 64 + 8:64 + 12].view(np.int32)[0] = 12            # predictLPCOrder
+    ein = np.array(rec["resnrg_in"][:256])
+    ein[3, 848:852].view(np.int32)[0] = 500                   # subfr_length
+    o2 = ca.silk_process_NLSFs(_dev(nin)).cpu().numpy()
+    e2 = ca.silk_residual_energy(_dev(ein)).cpu().numpy()
+    assert ca.silk.bad_records() == 3
+    good = np.setdiff1d(np.arange(256), [5, 11])
+    assert np.array_equal(o2[good, :116], want[:256][good, :116]) and (o2[[5, 11], 116:120].view(np.int32) == -1).all()
+    good = np.setdiff1d(np.arange(256), [3])
+    assert np.array_equal(e2[good, :32], ewant[:256][good, :32]) and e2[3, 32:36].view(np.int32)[0] == -1

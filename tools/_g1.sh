@@ -1,10 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_w; mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
-for a in 32 64; do
-export OPUSGPU_LANE_FRAMES=$a
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/f$a -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/w$a -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof.err
-python3 $R/tools/pmc_traffic.py $O/f$a $O/w$a $O/traffic_$a.json | grep back_lane
-python3 $R/bench.py --steps 10 --no-cpu-baseline --no-parity 2>/dev/null | python3 -c "
-import json,sys;d=json.loads(sys.stdin.read());print($a, d['value'], d['ms_per_step'], [(k['kernel'][5:],k['avg_launch_ms']) for k in d['roofline']['kernels']][:2])"
-done
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02_z; mkdir -p $O
+cd $R
+timeout -k 10 900 python3 -m pytest tests/test_silk_gpu.py tests/test_hooks_gpu.py -x -q -m gpu > $O/tests.log 2>&1; tail -15 $O/tests.log
+timeout -k 10 600 python3 bench.py --workload silk_nlsf > $O/nlsf.json 2> $O/nlsf.err; tail -c 1500 $O/nlsf.json; tail -3 $O/nlsf.err
