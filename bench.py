@@ -15,6 +15,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  silk_pred       silk_find_pred_coefs_FIX whole (LTP analysis + quantisation, silk_find_LPC_FIX, silk_process_NLSFs,
+                  silk_residual_energy_FIX) over 65 536 distinct records (voiced and unvoiced frames).
   silk_nlsf       silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX) over 65 536 distinct records
   silk_lpc        silk_find_LPC_FIX (Burg + silk_A2NLSF, and the NLSF interpolation search at complexity >= 4) over 65 536
                   distinct records: the SILK analysis step that feeds / consumes silk_burg_modified.
@@ -60,7 +62,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -325,6 +327,23 @@ def cpu_baseline_silk_nlsf(nin, ein):
     return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "%d (silk_process_NLSFs + silk_residual_energy_FIX) record pairs per pass through the host build of "
                       "concentus_amd/csrc/silk_nlsf_dev.h, repeated ~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
+
+
+def cpu_baseline_silk_pred(fin):
+    """CPU baseline for silk_find_pred_coefs_FIX records: the kernel sources compiled for the host (tests/emu, kind "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulib
+    emu = emulib.lib()
+    cores = host_threads()
+    n = fin.shape[0]
+    out = np.zeros((n, 208), np.uint8)
+
+    def work(lo, hi):
+        emu.emu_silk_find_pred_coefs(C.c_void_p(fin.ctypes.data + lo * 2688), C.c_void_p(out.ctypes.data + lo * 208), C.c_long(hi - lo))
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d silk_find_pred_coefs_FIX records per pass through the host build of concentus_amd/csrc/silk_pred_dev.h, "
+                      "repeated ~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
 
 
 def cpu_baseline_silk_dd(di, st0):
@@ -665,6 +684,45 @@ def main(argv=None):
             if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
                 raise SystemExit("PARITY FAILURE (silk_find_LPC)")
             parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
+    elif a.workload == "silk_pred":
+        F = a.frames or 65536
+        steps = a.steps or 10
+        warm = a.warmup if a.warmup is not None else 2
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        if not silk_corpus.available():
+            raise SystemExit("silk_pred needs oracle/_ref/libopus_ref_silkcap.so (records are captured from the reference encoder)")
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "fpc", seed=20260401 + 1000003 * rank).items()}
+        fi = torch.from_numpy(rec["fpc_in"]).to(dev)
+        fo = torch.empty((F, 208), dtype=torch.uint8, device=dev)
+        for _ in range(warm):
+            ca.silk_find_pred_coefs(fi, fo)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            ca.silk_find_pred_coefs(fi, fo)
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_find_pred_coefs_kernel"
+        kbytes = F * (2688 + 208)
+        limiter = "latency / VALU issue (serial recurrences per frame: LDL solve, codebook searches, Burg, NLSF trellis)"
+        metric = "SILK 16kHz mono 20ms frames/sec (silk_find_pred_coefs_FIX records)"
+        workload = ("%d distinct records per GPU captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s VOIP, "
+                    "complexity 3/5/8/10 in turn, voiced and unvoiced frames), silk_find_pred_coefs_FIX whole, bit-exact vs "
+                    "FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {}
+        m_cpu = min(F, 4096)
+        cpu = (lambda: cpu_baseline_silk_pred(np.ascontiguousarray(rec["fpc_in"][:m_cpu])))
+        if not a.no_parity and rank == 0:
+            if not np.array_equal(fo.cpu().numpy()[:, :204], rec["fpc_out"][:, :204]):
+                raise SystemExit("PARITY FAILURE (silk_find_pred_coefs)")
+            parity = {"checked": F, "note": "every record, every field silk_find_pred_coefs_FIX writes, vs the reference's own captured outputs"}
     elif a.workload == "silk_nlsf":
         F = a.frames or 65536
         steps = a.steps or 10

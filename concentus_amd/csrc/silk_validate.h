@@ -49,6 +49,23 @@ __device__ __forceinline__ bool res_nrg_record_ok(const opusgpu_res_nrg_in &in)
     return true;
 }
 
+__device__ __forceinline__ bool find_pred_coefs_record_ok(const opusgpu_find_pred_coefs_in &in)
+{
+    const int L = in.subfr_length, n = in.nb_subfr, D = in.predictLPCOrder, ltp = in.ltp_mem_length;
+    if (!((n == 2 || n == 4) && (D == 10 || D == 16) && L >= D && L <= 80 && (L + D) * n <= OPUSGPU_SILK_BURG_MAX_X)) return false;
+    if (!(ltp >= D && ltp <= OPUSGPU_SILK_MAX_LTP_MEM && n * L <= OPUSGPU_SILK_MAX_FRAME)) return false;
+    if ((unsigned)in.signalType > 2u || (unsigned)in.useInterpolatedNLSFs > 1u || (unsigned)in.speech_activity_Q8 > 256u) return false;
+    if (in.NLSF_MSVQ_Survivors < 1 || in.NLSF_MSVQ_Survivors > 32) return false;
+    for (int k = 0; k < D; k++)
+        if (in.prev_NLSFq_Q15[k] < 0) return false;
+    for (int k = 0; k < n; k++) {
+        if (in.Gains_Q16[k] <= 0) return false;
+        // voiced: the lagged windows of find_LTP_FIX / LTP_analysis_filter_FIX must stay inside res_pitch[] / x[]
+        if (in.signalType == 2 && !(in.pitchL[k] >= 2 && in.pitchL[k] + 2 + D <= ltp)) return false;
+    }
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -203,3 +203,30 @@ def silk_residual_energy(nrg_in, nrg_out=None):
     """silk_residual_energy_FIX() over a batch of records: nrg_in uint8 [N][864] (opusgpu_res_nrg_in) -> uint8 [N][40]
     (nrgs int32[4], nrgsQ int32[4], status)."""
     return _record_op("opusgpu_silk_residual_energy_batch", nrg_in, nrg_out, SIZES["res_nrg_in"], SIZES["res_nrg_out"], "res_nrg")
+
+
+class FindPredCoefsIn(C.Structure):
+    """opusgpu_find_pred_coefs_in: one silk_find_pred_coefs_FIX() call (opus-fix/silk/fixed/find_pred_coefs_FIX.c:35)."""
+    _fields_ = [("res_pitch", C.c_int16 * 640), ("x", C.c_int16 * 640), ("Gains_Q16", C.c_int32 * 4), ("pitchL", C.c_int32 * 4),
+                ("prev_NLSFq_Q15", C.c_int16 * 16)] + [(k, C.c_int32) for k in (
+                    "nb_subfr", "subfr_length", "predictLPCOrder", "ltp_mem_length", "signalType", "condCoding",
+                    "first_frame_after_reset", "useInterpolatedNLSFs", "speech_activity_Q8", "NLSF_MSVQ_Survivors", "mu_LTP_Q9",
+                    "LTPQuantLowComplexity", "sum_log_gain_Q7", "coding_quality_Q14", "PacketLoss_perc", "nFramesPerPacket")]
+
+
+class FindPredCoefsOut(C.Structure):
+    _fields_ = [("PredCoef_Q12", C.c_int16 * 32), ("LTPCoef_Q14", C.c_int16 * 20), ("NLSF_Q15", C.c_int16 * 16), ("ResNrg", C.c_int32 * 4),
+                ("ResNrgQ", C.c_int32 * 4), ("LTPredCodGain_Q7", C.c_int32), ("LTP_scale_Q14", C.c_int32), ("sum_log_gain_Q7", C.c_int32),
+                ("NLSFIndices", C.c_int8 * 17), ("NLSFInterpCoef_Q2", C.c_int8), ("LTPIndex", C.c_int8 * 4), ("PERIndex", C.c_int8),
+                ("LTP_scaleIndex", C.c_int8), ("status", C.c_int32)]
+
+
+SIZES["find_pred_coefs_in"] = C.sizeof(FindPredCoefsIn)
+SIZES["find_pred_coefs_out"] = C.sizeof(FindPredCoefsOut)
+
+
+def silk_find_pred_coefs(fpc_in, fpc_out=None):
+    """silk_find_pred_coefs_FIX() over a batch of records: fpc_in uint8 [N][2688] (opusgpu_find_pred_coefs_in) -> uint8 [N][208]
+    (opusgpu_find_pred_coefs_out: every field the call writes in psEnc / psEncCtrl, then status)."""
+    return _record_op("opusgpu_silk_find_pred_coefs_batch", fpc_in, fpc_out, SIZES["find_pred_coefs_in"], SIZES["find_pred_coefs_out"],
+                      "fpc")

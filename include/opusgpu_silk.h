@@ -189,6 +189,43 @@ typedef struct opusgpu_res_nrg_out {
 
 int opusgpu_silk_residual_energy_batch(const opusgpu_res_nrg_in *d_in, opusgpu_res_nrg_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_find_pred_coefs_FIX, batched (third slice) ----------------------------------------------------
+ * Replaces silk_find_pred_coefs_FIX(psEnc, psEncCtrl, res_pitch, x, condCoding) (opus-fix/silk/fixed/find_pred_coefs_FIX.c:35-148,
+ * called at silk/fixed/encode_frame_FIX.c) WHOLE: the voiced branch (silk_find_LTP_FIX, silk_quant_LTP_gains,
+ * silk_LTP_scale_ctrl_FIX, silk_LTP_analysis_filter_FIX) or the unvoiced one, then silk_find_LPC_FIX, silk_process_NLSFs and
+ * silk_residual_energy_FIX. A record is the arguments of one call plus the psEnc / psEncCtrl fields it reads; the output is
+ * every field it writes. For an unvoiced frame the call does not touch LTP_scale_Q14 / indices.LTP_scaleIndex: reported as
+ * 0 / -1. */
+#define OPUSGPU_SILK_MAX_LTP_MEM 320             /* LTP_MEM_LENGTH_MS * MAX_FS_KHZ */
+typedef struct opusgpu_find_pred_coefs_in {
+    int16_t res_pitch[OPUSGPU_SILK_MAX_LTP_MEM + OPUSGPU_SILK_MAX_FRAME]; /* res_pitch[0 .. ltp_mem_length + frame_length) */
+    int16_t x[OPUSGPU_SILK_MAX_LTP_MEM + OPUSGPU_SILK_MAX_FRAME];         /* x[-ltp_mem_length .. frame_length): x_buf up to the end of the frame */
+    int32_t Gains_Q16[4];                    /* psEncCtrl->Gains_Q16 */
+    int32_t pitchL[4];                       /* psEncCtrl->pitchL */
+    int16_t prev_NLSFq_Q15[OPUSGPU_SILK_MAX_ORDER];
+    int32_t nb_subfr, subfr_length, predictLPCOrder, ltp_mem_length;
+    int32_t signalType, condCoding, first_frame_after_reset, useInterpolatedNLSFs;
+    int32_t speech_activity_Q8, NLSF_MSVQ_Survivors, mu_LTP_Q9, LTPQuantLowComplexity;
+    int32_t sum_log_gain_Q7, coding_quality_Q14, PacketLoss_perc, nFramesPerPacket;
+} opusgpu_find_pred_coefs_in;
+
+typedef struct opusgpu_find_pred_coefs_out {
+    int16_t PredCoef_Q12[2][OPUSGPU_SILK_MAX_ORDER];
+    int16_t LTPCoef_Q14[20];
+    int16_t NLSF_Q15[OPUSGPU_SILK_MAX_ORDER];    /* -> psEnc->sCmn.prev_NLSFq_Q15 */
+    int32_t ResNrg[4];
+    int32_t ResNrgQ[4];
+    int32_t LTPredCodGain_Q7, LTP_scale_Q14, sum_log_gain_Q7;
+    int8_t NLSFIndices[OPUSGPU_SILK_MAX_ORDER + 1];
+    int8_t NLSFInterpCoef_Q2;
+    int8_t LTPIndex[4];
+    int8_t PERIndex;
+    int8_t LTP_scaleIndex;
+    int32_t status;
+} opusgpu_find_pred_coefs_out;
+
+int opusgpu_silk_find_pred_coefs_batch(const opusgpu_find_pred_coefs_in *d_in, opusgpu_find_pred_coefs_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -263,5 +263,62 @@ void __wrap_silk_residual_energy_FIX(opus_int32 nrgs[MAX_NB_SUBFR], opus_int nrg
         for (int k = 0; k < nb_subfr; k++) g_eout[rec].nrgsQ[k] = nrgsQ[k];
         g_eout[rec].status = 0;
         g_ne++;
+    }
+}
+
+/* ---- silk_find_pred_coefs_FIX (opus-fix/silk/fixed/find_pred_coefs_FIX.c:35), whole: arguments + the psEnc / psEncCtrl fields it
+ * reads -> every field it writes ---- */
+static opusgpu_find_pred_coefs_in *g_fin; static opusgpu_find_pred_coefs_out *g_fout; static int g_nf, g_capf;
+void refcap_start_fpc(int max_records)
+{
+    g_capf = max_records; g_nf = 0; g_on = 1;
+    g_fin = (opusgpu_find_pred_coefs_in *)calloc(max_records, sizeof(*g_fin));
+    g_fout = (opusgpu_find_pred_coefs_out *)calloc(max_records, sizeof(*g_fout));
+}
+int refcap_count_fpc(void) { return g_nf; }
+int refcap_sizes_fpc(int which) { return which == 0 ? sizeof(opusgpu_find_pred_coefs_in) : sizeof(opusgpu_find_pred_coefs_out); }
+void refcap_get_fpc(void *fin, void *fout)
+{
+    memcpy(fin, g_fin, (size_t)g_nf * sizeof(*g_fin)); memcpy(fout, g_fout, (size_t)g_nf * sizeof(*g_fout));
+}
+
+void __real_silk_find_pred_coefs_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, const opus_int16 res_pitch[],
+                                     const opus_int16 x[], opus_int condCoding);
+void __wrap_silk_find_pred_coefs_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, const opus_int16 res_pitch[],
+                                     const opus_int16 x[], opus_int condCoding)
+{
+    const silk_encoder_state *c = &psEnc->sCmn;
+    int rec = (g_on && g_fin && g_nf < g_capf && c->ltp_mem_length <= OPUSGPU_SILK_MAX_LTP_MEM && c->frame_length <= OPUSGPU_SILK_MAX_FRAME)
+                  ? g_nf : -1;
+    if (rec >= 0) {
+        opusgpu_find_pred_coefs_in *r = &g_fin[rec];
+        memcpy(r->res_pitch, res_pitch, sizeof(opus_int16) * (c->ltp_mem_length + c->frame_length));
+        memcpy(r->x, x - c->ltp_mem_length, sizeof(opus_int16) * (c->ltp_mem_length + c->frame_length));
+        for (int k = 0; k < MAX_NB_SUBFR; k++) { r->Gains_Q16[k] = psEncCtrl->Gains_Q16[k]; r->pitchL[k] = psEncCtrl->pitchL[k]; }
+        memcpy(r->prev_NLSFq_Q15, c->prev_NLSFq_Q15, sizeof(r->prev_NLSFq_Q15));
+        r->nb_subfr = c->nb_subfr; r->subfr_length = c->subfr_length; r->predictLPCOrder = c->predictLPCOrder; r->ltp_mem_length = c->ltp_mem_length;
+        r->signalType = c->indices.signalType; r->condCoding = condCoding; r->first_frame_after_reset = c->first_frame_after_reset;
+        r->useInterpolatedNLSFs = c->useInterpolatedNLSFs; r->speech_activity_Q8 = c->speech_activity_Q8;
+        r->NLSF_MSVQ_Survivors = c->NLSF_MSVQ_Survivors; r->mu_LTP_Q9 = c->mu_LTP_Q9; r->LTPQuantLowComplexity = c->LTPQuantLowComplexity;
+        r->sum_log_gain_Q7 = c->sum_log_gain_Q7; r->coding_quality_Q14 = psEncCtrl->coding_quality_Q14;
+        r->PacketLoss_perc = c->PacketLoss_perc; r->nFramesPerPacket = c->nFramesPerPacket;
+    }
+    __real_silk_find_pred_coefs_FIX(psEnc, psEncCtrl, res_pitch, x, condCoding);
+    if (rec >= 0) {
+        opusgpu_find_pred_coefs_out *o = &g_fout[rec];
+        const int voiced = c->indices.signalType == TYPE_VOICED;
+        memcpy(o->PredCoef_Q12[0], psEncCtrl->PredCoef_Q12[0], sizeof(opus_int16) * c->predictLPCOrder);
+        memcpy(o->PredCoef_Q12[1], psEncCtrl->PredCoef_Q12[1], sizeof(opus_int16) * c->predictLPCOrder);
+        memcpy(o->LTPCoef_Q14, psEncCtrl->LTPCoef_Q14, sizeof(opus_int16) * c->nb_subfr * LTP_ORDER);
+        memcpy(o->NLSF_Q15, c->prev_NLSFq_Q15, sizeof(opus_int16) * c->predictLPCOrder);
+        for (int k = 0; k < c->nb_subfr; k++) { o->ResNrg[k] = psEncCtrl->ResNrg[k]; o->ResNrgQ[k] = psEncCtrl->ResNrgQ[k]; }
+        o->LTPredCodGain_Q7 = psEncCtrl->LTPredCodGain_Q7; o->sum_log_gain_Q7 = c->sum_log_gain_Q7;
+        o->LTP_scale_Q14 = voiced ? psEncCtrl->LTP_scale_Q14 : 0;
+        memcpy(o->NLSFIndices, c->indices.NLSFIndices, c->predictLPCOrder + 1);
+        o->NLSFInterpCoef_Q2 = c->indices.NLSFInterpCoef_Q2;
+        if (voiced) { memcpy(o->LTPIndex, c->indices.LTPIndex, c->nb_subfr); o->PERIndex = c->indices.PERIndex; }
+        o->LTP_scaleIndex = voiced ? c->indices.LTP_scaleIndex : -1;
+        o->status = 0;
+        g_nf++;
     }
 }

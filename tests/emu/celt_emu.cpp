@@ -201,3 +201,40 @@ extern "C" void emu_silk_residual_energy(const opusgpu_res_nrg_in *in, opusgpu_r
         for (int k = 0; k < in[r].nb_subfr; k++) { out[r].nrgs[k] = nrgs[k]; out[r].nrgsQ[k] = nrgsQ[k]; }
     }
 }
+
+// ---- silk_find_pred_coefs_FIX, host build of concentus_amd/csrc/silk_pred_dev.h (tests/test_silk_pred_cpu.py) ----
+#include "../../concentus_amd/csrc/silk_pred_dev.h"
+static void pred_cfg_from_record(const opusgpu_find_pred_coefs_in &in, ca::PredCoefsCfg &c)
+{
+    for (int k = 0; k < 4; k++) { c.Gains_Q16[k] = in.Gains_Q16[k]; c.pitchL[k] = in.pitchL[k]; }
+    for (int k = 0; k < 16; k++) c.prev_NLSFq_Q15[k] = in.prev_NLSFq_Q15[k];
+    c.nb_subfr = in.nb_subfr; c.subfr_length = in.subfr_length; c.predictLPCOrder = in.predictLPCOrder; c.ltp_mem_length = in.ltp_mem_length;
+    c.signalType = in.signalType; c.condCoding = in.condCoding; c.first_frame_after_reset = in.first_frame_after_reset;
+    c.useInterpolatedNLSFs = in.useInterpolatedNLSFs; c.speech_activity_Q8 = in.speech_activity_Q8;
+    c.NLSF_MSVQ_Survivors = in.NLSF_MSVQ_Survivors; c.mu_LTP_Q9 = in.mu_LTP_Q9; c.LTPQuantLowComplexity = in.LTPQuantLowComplexity;
+    c.sum_log_gain_Q7 = in.sum_log_gain_Q7; c.coding_quality_Q14 = in.coding_quality_Q14; c.PacketLoss_perc = in.PacketLoss_perc;
+    c.nFramesPerPacket = in.nFramesPerPacket;
+}
+static void pred_out_to_record(const ca::PredCoefsOut &o, int order, int nb, opusgpu_find_pred_coefs_out &r)
+{
+    memset(&r, 0, sizeof(r));
+    for (int k = 0; k < order; k++) { r.PredCoef_Q12[0][k] = o.PredCoef_Q12[0][k]; r.PredCoef_Q12[1][k] = o.PredCoef_Q12[1][k]; r.NLSF_Q15[k] = o.NLSF_Q15[k]; }
+    for (int k = 0; k < nb * 5; k++) r.LTPCoef_Q14[k] = o.LTPCoef_Q14[k];
+    for (int k = 0; k < nb; k++) { r.ResNrg[k] = o.ResNrg[k]; r.ResNrgQ[k] = o.ResNrgQ[k]; r.LTPIndex[k] = o.LTPIndex[k]; }
+    r.LTPredCodGain_Q7 = o.LTPredCodGain_Q7; r.LTP_scale_Q14 = o.LTP_scale_Q14; r.sum_log_gain_Q7 = o.sum_log_gain_Q7;
+    for (int k = 0; k <= order; k++) r.NLSFIndices[k] = o.NLSFIndices[k];
+    r.NLSFInterpCoef_Q2 = (int8_t)o.NLSFInterpCoef_Q2; r.PERIndex = (int8_t)o.PERIndex; r.LTP_scaleIndex = (int8_t)o.LTP_scaleIndex;
+}
+extern "C" void emu_silk_find_pred_coefs(const opusgpu_find_pred_coefs_in *in, opusgpu_find_pred_coefs_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        ca::PredCoefsCfg c;
+        ca::PredCoefsOut o;
+        memset(&o, 0, sizeof(o));
+        pred_cfg_from_record(in[r], c);
+        int16_t pre[OPUSGPU_SILK_BURG_MAX_X];
+        memset(pre, 0, sizeof(pre));
+        ca::silk_find_pred_coefs_dev(c, (const int16_t *)in[r].res_pitch, (const int16_t *)in[r].x + in[r].ltp_mem_length, (int16_t *)pre, o);
+        pred_out_to_record(o, in[r].predictLPCOrder, in[r].nb_subfr, out[r]);
+    }
+}

@@ -27,7 +27,8 @@ SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder eac
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
 SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324,
-         "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40}
+         "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40,
+         "fpc_in": 2688, "fpc_out": 208}
 
 
 def available():
@@ -105,6 +106,8 @@ def _capture_segment(args):
         lib.refcap_start_lpc(cap)
     elif kind == "pred":
         lib.refcap_start_pred(cap)
+    elif kind == "fpc":
+        lib.refcap_start_fpc(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -117,7 +120,15 @@ def _capture_segment(args):
         fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
         assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
-    if kind == "pred":
+    if kind == "fpc":
+        nf = lib.refcap_count_fpc()
+        assert nf >= nfr, (nf, nfr)
+        assert (lib.refcap_sizes_fpc(0), lib.refcap_sizes_fpc(1)) == (SIZES["fpc_in"], SIZES["fpc_out"])
+        bufs = [np.zeros((nf, SIZES["fpc_in"]), np.uint8), np.zeros((nf, SIZES["fpc_out"]), np.uint8)]
+        lib.refcap_get_fpc(*[_p(b) for b in bufs])
+        for name, b in zip(("fpc_in", "fpc_out"), bufs):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    elif kind == "pred":
         npr, ne = lib.refcap_count_pred(0), lib.refcap_count_pred(1)
         assert npr >= nfr and ne >= nfr, (npr, ne, nfr)
         bufs = [np.zeros((npr, SIZES["nlsf_in"]), np.uint8), np.zeros((npr, SIZES["nlsf_out"]), np.uint8),
@@ -163,6 +174,7 @@ _LAYOUT = {
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
     "dd": (("dd_in", "dd_in"), ("dd_state_in", "nsq_state"), ("dd_state_out", "nsq_state"), ("dd_out", "dd_out")),
     "lpc": (("lpc_in", "lpc_in"), ("lpc_out", "lpc_out")),
+    "fpc": (("fpc_in", "fpc_in"), ("fpc_out", "fpc_out")),
     "pred": (("nlsf_in", "nlsf_in"), ("nlsf_out", "nlsf_out"), ("resnrg_in", "resnrg_in"), ("resnrg_out", "resnrg_out")),
 }
 
@@ -184,6 +196,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
     if not available():
         raise FileNotFoundError(CAPLIB)
+    # kind "fpc": silk_find_pred_coefs_FIX whole (voiced and unvoiced frames), complexities as "lpc"
     # kind "pred": silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX), complexities as "lpc"
     # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
     complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10) if kind == "dd" else (3, 5, 8, 10))
@@ -199,7 +212,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843}[kind], complexities[k % len(complexities)],
                          row, take, n))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

@@ -326,3 +326,35 @@ def test_process_nlsfs_and_residual_energy_32768_distinct_records_vs_reference_o
     assert np.array_equal(o2[good, :116], want[:256][good, :116]) and (o2[[5, 11], 116:120].view(np.int32) == -1).all()
     good = np.setdiff1d(np.arange(256), [3])
     assert np.array_equal(e2[good, :32], ewant[:256][good, :32]) and e2[3, 32:36].view(np.int32)[0] == -1
+
+
+# ---- silk_find_pred_coefs_FIX, whole (third slice): one lane per frame ----
+def test_find_pred_coefs_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_find_pred_coefs_FIX on the GPU against everything the unmodified reference wrote when the records were captured
+    (tests/silk_corpus.py kind "fpc"; complexity 3 / 5 / 8 / 10 in turn): voiced frames run the LTP analysis, the LTP gain
+    codebook search and the LTP residual filter, unvoiced ones the gain-scaled copy; all of them silk_find_LPC_FIX,
+    silk_process_NLSFs and silk_residual_energy_FIX."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "fpc")
+    out = ca.silk_find_pred_coefs(_dev(rec["fpc_in"]))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.asarray(rec["fpc_out"])
+    assert (out[:, 204:208].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :204] != want[:, :204]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], np.nonzero(out[bad[0], :204] != want[bad[0], :204])[0][:12])
+    st = np.asarray(rec["fpc_in"])[:, 2624 + 16:2624 + 20].view(np.int32)[:, 0]
+    assert (st == 2).sum() > 5000 and (st != 2).sum() > 1000
+    # corrupted headers are skipped and counted, their neighbours are unaffected
+    ca.silk.bad_records()
+    fin = np.array(rec["fpc_in"][:256])
+    voiced = np.nonzero(st[:256] == 2)[0]
+    fin[voiced[0], 2576:2580].view(np.int32)[0] = 5000        # pitchL[0] of a voiced frame: lag window outside res_pitch
+    fin[9, 2624 + 8:2624 + 12].view(np.int32)[0] = 12         # predictLPCOrder
+    o2 = ca.silk_find_pred_coefs(_dev(fin)).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [voiced[0], 9])
+    assert np.array_equal(o2[good, :204], want[:256][good, :204]) and (o2[[voiced[0], 9], 204:208].view(np.int32) == -1).all()

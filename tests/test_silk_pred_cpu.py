@@ -1,0 +1,36 @@
+"""CPU tier for silk_find_pred_coefs_FIX, whole (third slice): the device sources
+(concentus_amd/csrc/silk_pred_dev.h: silk_ltp_dev.h + silk_nlsf_dev.h + silk_lpc_dev.h + silk_burg_dev.h) compiled for the host
+(tests/emu) against records freshly captured from the UNMODIFIED reference encoder (oracle/_ref/libopus_ref_silkcap.so wraps
+silk_find_pred_coefs_FIX, oracle/ref_silk_capture.c): every field the call writes -- PredCoef_Q12, LTPCoef_Q14, the quantised
+NLSFs, ResNrg / ResNrgQ, LTPredCodGain_Q7, LTP_scale_Q14, sum_log_gain_Q7, NLSFIndices, NLSFInterpCoef_Q2, LTPIndex, PERIndex,
+LTP_scaleIndex -- on voiced and unvoiced frames at complexities 3 / 5 / 8 / 10."""
+import ctypes as C
+import tempfile
+
+import numpy as np
+import pytest
+
+import emulib
+import silk_corpus
+
+
+@pytest.mark.ref
+def test_find_pred_coefs_sources_match_the_reference_on_fresh_records():
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    emu = emulib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4 * silk_corpus.SEG_FRAMES, "fpc", cache=tmp, workers=4)
+        fin = np.ascontiguousarray(c["fpc_in"])
+        want = np.asarray(c["fpc_out"])
+        n = fin.shape[0]
+        got = np.zeros((n, silk_corpus.SIZES["fpc_out"]), np.uint8)
+        emu.emu_silk_find_pred_coefs(fin.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_long(n))
+        hdr = fin[:, 2624:2688].view(np.int32)     # nb_subfr, subfr_length, order, ltp_mem, signalType, condCoding, ...
+        assert (hdr[:, 4] == 2).sum() > 1000 and (hdr[:, 4] != 2).sum() > 200, "voiced and unvoiced frames"
+        bad = np.nonzero((got[:, :204] != want[:, :204]).any(1))[0]
+        if bad.size:
+            k = bad[0]
+            cols = np.nonzero(got[k, :204] != want[k, :204])[0]
+            raise AssertionError((bad.size, bad[:8], "signalType", hdr[k, 4], "first differing bytes", cols[:12]))
+        del c
