@@ -6,6 +6,7 @@
 #include "silk_pred_dev.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
+#include "../../include/opusgpu_hooks.h"
 #include "silk_validate.h"
 
 namespace ca {
@@ -69,4 +70,84 @@ extern "C" int opusgpu_silk_find_pred_coefs_batch(const opusgpu_find_pred_coefs_
     if (!bad) return OPUSGPU_ALLOC_FAIL;
     hipLaunchKernelGGL(silk_find_pred_coefs_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
     return opusgpu_check_launch();
+}
+
+// Per-call hook with the reference's own argument list: silk_find_pred_coefs_FIX(psEnc, psEncCtrl, res_pitch, x, condCoding)
+// (silk/fixed/main_FIX.h; called from silk_encode_frame_FIX). psEnc / psEncCtrl are the reference's silk_encoder_state_FIX /
+// silk_encoder_control_FIX (x86-64 layout): the fields read and written are reached at the offsets of include/opusgpu_hooks.h.
+// x must be preceded by ltp_mem_length samples (it points into psEnc->x_buf, encode_frame_FIX.c), res_pitch holds
+// ltp_mem_length + frame_length samples.
+static int rd_int(const void *base, int off) { int v; memcpy(&v, (const char *)base + off, sizeof(v)); return v; }
+static void wr_int(void *base, int off, int v) { memcpy((char *)base + off, &v, sizeof(v)); }
+
+extern "C" void opusgpu_silk_find_pred_coefs_FIX(void *psEnc, void *psEncCtrl, const int16_t res_pitch[], const int16_t x[], int condCoding)
+{
+    if (!psEnc || !psEncCtrl || !res_pitch || !x) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+    static opusgpu_find_pred_coefs_in h_in_zero;
+    opusgpu_find_pred_coefs_in *h_in = (opusgpu_find_pred_coefs_in *)malloc(sizeof(*h_in));
+    opusgpu_find_pred_coefs_out h_out;
+    if (!h_in) { opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL); return; }
+    *h_in = h_in_zero;
+    char *sCmn = (char *)psEnc + OPUSGPU_REF_OFF_FIX_SCMN;
+    char *ind = sCmn + OPUSGPU_REF_OFF_INDICES;
+    h_in->nb_subfr = rd_int(sCmn, OPUSGPU_REF_OFF_NB_SUBFR);
+    h_in->subfr_length = rd_int(sCmn, OPUSGPU_REF_OFF_SUBFR_LENGTH);
+    h_in->predictLPCOrder = rd_int(sCmn, OPUSGPU_REF_OFF_PREDICT_LPC_ORDER);
+    h_in->ltp_mem_length = rd_int(sCmn, OPUSGPU_REF_OFF_LTP_MEM_LENGTH);
+    h_in->signalType = (int8_t)ind[OPUSGPU_REF_OFF_SIGNAL_TYPE];
+    h_in->condCoding = condCoding;
+    h_in->first_frame_after_reset = rd_int(sCmn, OPUSGPU_REF_OFF_FIRST_FRAME_AFTER_RESET);
+    h_in->useInterpolatedNLSFs = rd_int(sCmn, OPUSGPU_REF_OFF_USE_INTERPOLATED_NLSFS);
+    h_in->speech_activity_Q8 = rd_int(sCmn, OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8);
+    h_in->NLSF_MSVQ_Survivors = rd_int(sCmn, OPUSGPU_REF_OFF_NLSF_MSVQ_SURVIVORS);
+    h_in->mu_LTP_Q9 = rd_int(sCmn, OPUSGPU_REF_OFF_MU_LTP_Q9);
+    h_in->LTPQuantLowComplexity = rd_int(sCmn, OPUSGPU_REF_OFF_LTP_QUANT_LOW_COMPLEXITY);
+    h_in->sum_log_gain_Q7 = rd_int(sCmn, OPUSGPU_REF_OFF_SUM_LOG_GAIN_Q7);
+    h_in->PacketLoss_perc = rd_int(sCmn, OPUSGPU_REF_OFF_PACKET_LOSS_PERC);
+    h_in->nFramesPerPacket = rd_int(sCmn, OPUSGPU_REF_OFF_N_FRAMES_PER_PACKET);
+    h_in->coding_quality_Q14 = rd_int(psEncCtrl, OPUSGPU_REF_OFF_CTRL_CODING_QUALITY_Q14);
+    memcpy(h_in->Gains_Q16, (char *)psEncCtrl + OPUSGPU_REF_OFF_CTRL_GAINS_Q16, sizeof(h_in->Gains_Q16));
+    memcpy(h_in->pitchL, (char *)psEncCtrl + OPUSGPU_REF_OFF_CTRL_PITCHL, sizeof(h_in->pitchL));
+    memcpy(h_in->prev_NLSFq_Q15, sCmn + OPUSGPU_REF_OFF_PREV_NLSFQ_Q15, sizeof(h_in->prev_NLSFq_Q15));
+    const int nb = h_in->nb_subfr, L = h_in->subfr_length, D = h_in->predictLPCOrder, ltp = h_in->ltp_mem_length;
+    if ((nb != 2 && nb != 4) || L < 1 || L > 80 || (D != 10 && D != 16) || ltp < D || ltp > OPUSGPU_SILK_MAX_LTP_MEM) {
+        free(h_in);
+        opusgpu_set_last_error(OPUSGPU_BAD_ARG);
+        return;
+    }
+    memcpy(h_in->res_pitch, res_pitch, sizeof(int16_t) * (size_t)(ltp + nb * L));
+    memcpy(h_in->x, x - ltp, sizeof(int16_t) * (size_t)(ltp + nb * L));
+    opusgpu_find_pred_coefs_in *d_in = nullptr;
+    opusgpu_find_pred_coefs_out *d_out = nullptr;
+    int rc = OPUSGPU_OK;
+    if (hipMalloc(&d_in, sizeof(*h_in)) != hipSuccess || hipMalloc(&d_out, sizeof(h_out)) != hipSuccess) rc = OPUSGPU_ALLOC_FAIL;
+    if (rc == OPUSGPU_OK && hipMemcpy(d_in, h_in, sizeof(*h_in), hipMemcpyHostToDevice) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    if (rc == OPUSGPU_OK) rc = opusgpu_silk_find_pred_coefs_batch(d_in, d_out, 1, nullptr);
+    if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    if (d_in) (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    const int voiced = h_in->signalType == 2;
+    free(h_in);
+    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) { rc = h_out.status; (void)opusgpu_silk_bad_records(nullptr); }
+    opusgpu_set_last_error(rc);
+    if (rc != OPUSGPU_OK) return;
+    char *ctl = (char *)psEncCtrl;
+    memcpy(ctl + OPUSGPU_REF_OFF_CTRL_PRED_COEF_Q12, h_out.PredCoef_Q12[0], sizeof(int16_t) * (size_t)D);
+    memcpy(ctl + OPUSGPU_REF_OFF_CTRL_PRED_COEF_Q12 + 2 * OPUSGPU_SILK_MAX_ORDER, h_out.PredCoef_Q12[1], sizeof(int16_t) * (size_t)D);
+    memcpy(ctl + OPUSGPU_REF_OFF_CTRL_LTP_COEF_Q14, h_out.LTPCoef_Q14, sizeof(int16_t) * (size_t)(nb * 5));
+    wr_int(ctl, OPUSGPU_REF_OFF_CTRL_LTP_RED_COD_GAIN_Q7, h_out.LTPredCodGain_Q7);
+    for (int k = 0; k < nb; k++) {
+        wr_int(ctl, OPUSGPU_REF_OFF_CTRL_RES_NRG + 4 * k, h_out.ResNrg[k]);
+        wr_int(ctl, OPUSGPU_REF_OFF_CTRL_RES_NRG_Q + 4 * k, h_out.ResNrgQ[k]);
+    }
+    wr_int(sCmn, OPUSGPU_REF_OFF_SUM_LOG_GAIN_Q7, h_out.sum_log_gain_Q7);
+    memcpy(sCmn + OPUSGPU_REF_OFF_PREV_NLSFQ_Q15, h_out.NLSF_Q15, sizeof(int16_t) * OPUSGPU_SILK_MAX_ORDER);
+    memcpy(ind + OPUSGPU_REF_OFF_NLSF_INDICES, h_out.NLSFIndices, (size_t)D + 1);
+    ind[OPUSGPU_REF_OFF_NLSF_INTERP_COEF_Q2] = h_out.NLSFInterpCoef_Q2;
+    if (voiced) {
+        wr_int(ctl, OPUSGPU_REF_OFF_CTRL_LTP_SCALE_Q14, h_out.LTP_scale_Q14);
+        memcpy(ind + OPUSGPU_REF_OFF_LTP_INDEX, h_out.LTPIndex, (size_t)nb);
+        ind[OPUSGPU_REF_OFF_PER_INDEX] = h_out.PERIndex;
+        ind[OPUSGPU_REF_OFF_LTP_SCALE_INDEX] = h_out.LTP_scaleIndex;
+    }
 }

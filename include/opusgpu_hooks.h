@@ -106,6 +106,36 @@ void opusgpu_silk_process_NLSFs(void *psEncC, int16_t PredCoef_Q12[/*2 * 16*/], 
 void opusgpu_silk_residual_energy_FIX(int32_t nrgs[], int nrgsQ[], const int16_t x[], int16_t a_Q12[/*2 * 16*/], const int32_t gains[],
                                       const int subfr_length, const int nb_subfr, const int LPC_order, int arch);
 
+/* silk_find_pred_coefs_FIX(psEnc, psEncCtrl, res_pitch, x, condCoding) -- opus-fix/silk/fixed/find_pred_coefs_FIX.c:35-148 (declared
+ * in silk/fixed/main_FIX.h, called from silk_encode_frame_FIX, silk/fixed/encode_frame_FIX.c). psEnc / psEncCtrl are the
+ * reference's silk_encoder_state_FIX / silk_encoder_control_FIX. Reads: sCmn.nb_subfr / subfr_length / predictLPCOrder /
+ * ltp_mem_length / first_frame_after_reset / useInterpolatedNLSFs / speech_activity_Q8 / NLSF_MSVQ_Survivors / mu_LTP_Q9 /
+ * LTPQuantLowComplexity / sum_log_gain_Q7 / PacketLoss_perc / nFramesPerPacket / prev_NLSFq_Q15 / indices.signalType;
+ * psEncCtrl->Gains_Q16 / pitchL / coding_quality_Q14; res_pitch[0 .. ltp_mem_length + frame_length); x[-ltp_mem_length ..
+ * frame_length). Writes: psEncCtrl->PredCoef_Q12 / LTPCoef_Q14 / LTPredCodGain_Q7 / ResNrg / ResNrgQ (and LTP_scale_Q14 for a
+ * voiced frame); sCmn.sum_log_gain_Q7 / prev_NLSFq_Q15 / indices.NLSFIndices / NLSFInterpCoef_Q2 (and LTPIndex, PERIndex,
+ * LTP_scaleIndex for a voiced frame). */
+#define OPUSGPU_REF_OFF_FIX_SCMN 0                  /* silk_encoder_state_FIX.sCmn */
+#define OPUSGPU_REF_OFF_MU_LTP_Q9 4684              /* silk_encoder_state.mu_LTP_Q9 */
+#define OPUSGPU_REF_OFF_LTP_QUANT_LOW_COMPLEXITY 4680 /* .LTPQuantLowComplexity */
+#define OPUSGPU_REF_OFF_SUM_LOG_GAIN_Q7 4688        /* .sum_log_gain_Q7 */
+#define OPUSGPU_REF_OFF_PACKET_LOSS_PERC 4640       /* .PacketLoss_perc */
+#define OPUSGPU_REF_OFF_N_FRAMES_PER_PACKET 5792    /* .nFramesPerPacket */
+#define OPUSGPU_REF_OFF_LTP_INDEX 4                 /* SideInfoIndices.LTPIndex[4]                (opus_int8) */
+#define OPUSGPU_REF_OFF_PER_INDEX 32                /* .PERIndex */
+#define OPUSGPU_REF_OFF_LTP_SCALE_INDEX 33          /* .LTP_scaleIndex */
+#define OPUSGPU_REF_SIZEOF_SILK_ENCODER_CONTROL_FIX 552
+#define OPUSGPU_REF_OFF_CTRL_GAINS_Q16 0            /* silk_encoder_control_FIX.Gains_Q16[4]      (opus_int32) */
+#define OPUSGPU_REF_OFF_CTRL_PRED_COEF_Q12 16       /* .PredCoef_Q12[2][16]                       (opus_int16) */
+#define OPUSGPU_REF_OFF_CTRL_LTP_COEF_Q14 80        /* .LTPCoef_Q14[20]                           (opus_int16) */
+#define OPUSGPU_REF_OFF_CTRL_LTP_SCALE_Q14 120      /* .LTP_scale_Q14                             (opus_int) */
+#define OPUSGPU_REF_OFF_CTRL_PITCHL 124             /* .pitchL[4] */
+#define OPUSGPU_REF_OFF_CTRL_CODING_QUALITY_Q14 484 /* .coding_quality_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_LTP_RED_COD_GAIN_Q7 496 /* .LTPredCodGain_Q7 */
+#define OPUSGPU_REF_OFF_CTRL_RES_NRG 500            /* .ResNrg[4]                                 (opus_int32) */
+#define OPUSGPU_REF_OFF_CTRL_RES_NRG_Q 516          /* .ResNrgQ[4]                                (opus_int) */
+void opusgpu_silk_find_pred_coefs_FIX(void *psEnc, void *psEncCtrl, const int16_t res_pitch[], const int16_t x[], int condCoding);
+
 #ifdef __cplusplus
 }
 #endif

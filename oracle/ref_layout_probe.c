@@ -5,7 +5,7 @@
  * reference's headers where they lie (oracle/Makefile -> oracle/_ref/layout_probe). */
 #include <stddef.h>
 #include <stdio.h>
-#include "main.h"
+#include "main_FIX.h"
 
 #define F(T, f) printf("  \"%s.%s\": %zu,\n", #T, #f, offsetof(T, f))
 
@@ -18,9 +18,16 @@ int main(void)
     F(silk_encoder_state, useInterpolatedNLSFs); F(silk_encoder_state, first_frame_after_reset); F(silk_encoder_state, prev_NLSFq_Q15);
     F(silk_encoder_state, indices); F(silk_encoder_state, speech_activity_Q8); F(silk_encoder_state, NLSF_MSVQ_Survivors);
     F(silk_encoder_state, psNLSF_CB);
+    F(silk_encoder_state, mu_LTP_Q9); F(silk_encoder_state, LTPQuantLowComplexity); F(silk_encoder_state, sum_log_gain_Q7);
+    F(silk_encoder_state, PacketLoss_perc); F(silk_encoder_state, nFramesPerPacket);
+    F(silk_encoder_state_FIX, sCmn);
+    F(silk_encoder_control_FIX, Gains_Q16); F(silk_encoder_control_FIX, PredCoef_Q12); F(silk_encoder_control_FIX, LTPCoef_Q14);
+    F(silk_encoder_control_FIX, LTP_scale_Q14); F(silk_encoder_control_FIX, pitchL); F(silk_encoder_control_FIX, LTPredCodGain_Q7);
+    F(silk_encoder_control_FIX, ResNrg); F(silk_encoder_control_FIX, ResNrgQ); F(silk_encoder_control_FIX, coding_quality_Q14);
     F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
     F(SideInfoIndices, Seed); F(SideInfoIndices, NLSFIndices);
-    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu\n}\n",
-           sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state));
+    F(SideInfoIndices, LTPIndex); F(SideInfoIndices, PERIndex); F(SideInfoIndices, LTP_scaleIndex);
+    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu\n}\n",
+           sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state), sizeof(silk_encoder_control_FIX));
     return 0;
 }

@@ -255,6 +255,66 @@ def test_silk_process_NLSFs_and_residual_energy_hooks_with_the_reference_argumen
         assert np.array_equal(outs[1][0].view(np.uint8), ewant[k, :16]) and np.array_equal(outs[1][1].view(np.uint8), ewant[k, 16:32])
 
 
+def test_silk_find_pred_coefs_FIX_hook_with_the_reference_argument_list(L, ref):
+    """opusgpu_silk_find_pred_coefs_FIX(psEnc, psEncCtrl, res_pitch, x, condCoding) against silk_find_pred_coefs_FIX of the compiled
+    reference: both are handed the same silk_encoder_state_FIX / silk_encoder_control_FIX images (zero except the fields the
+    function reads, at the offsets of include/opusgpu_hooks.h, plus psNLSF_CB for the reference) and the same res_pitch / x
+    buffers; compared: EVERY byte of both structures after the call, i.e. all the fields written and nothing else touched."""
+    import json
+    import silk_corpus
+    r, _ = ref
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    d = header_defines()
+    off_cb = json.load(open(os.path.join(ROOT, "oracle", "_ref", "layout.json")))["silk_encoder_state.psNLSF_CB"]
+    cb_wb = C.addressof(C.c_char.in_dll(r, "silk_NLSF_CB_WB"))
+    rec = silk_corpus.corpus(4096, "fpc")
+    fin, want = np.asarray(rec["fpc_in"]), np.asarray(rec["fpc_out"])
+    names = ("nb_subfr", "subfr_length", "predictLPCOrder", "ltp_mem_length", "signalType", "condCoding", "first_frame_after_reset",
+             "useInterpolatedNLSFs", "speech_activity_Q8", "NLSF_MSVQ_Survivors", "mu_LTP_Q9", "LTPQuantLowComplexity",
+             "sum_log_gain_Q7", "coding_quality_Q14", "PacketLoss_perc", "nFramesPerPacket")
+    state_off = {"nb_subfr": "NB_SUBFR", "subfr_length": "SUBFR_LENGTH", "predictLPCOrder": "PREDICT_LPC_ORDER",
+                 "ltp_mem_length": "LTP_MEM_LENGTH", "first_frame_after_reset": "FIRST_FRAME_AFTER_RESET",
+                 "useInterpolatedNLSFs": "USE_INTERPOLATED_NLSFS", "speech_activity_Q8": "SPEECH_ACTIVITY_Q8",
+                 "NLSF_MSVQ_Survivors": "NLSF_MSVQ_SURVIVORS", "mu_LTP_Q9": "MU_LTP_Q9", "LTPQuantLowComplexity": "LTP_QUANT_LOW_COMPLEXITY",
+                 "sum_log_gain_Q7": "SUM_LOG_GAIN_Q7", "PacketLoss_perc": "PACKET_LOSS_PERC", "nFramesPerPacket": "N_FRAMES_PER_PACKET"}
+    seen = set()
+    for k in range(0, 4096, 157):
+        row = np.ascontiguousarray(fin[k])
+        hdr = dict(zip(names, row[2624:2688].view(np.int32).tolist()))
+        seen.add(hdr["signalType"] == 2)
+        images = []
+        for fn in (r.silk_find_pred_coefs_FIX, L.opusgpu_silk_find_pred_coefs_FIX):
+            enc = np.zeros(32768, np.uint8)                   # silk_encoder_state_FIX starts with sCmn; the rest is never touched
+            ctl = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_CONTROL_FIX"], np.uint8)
+            for name, macro in state_off.items():
+                o = d["OPUSGPU_REF_OFF_" + macro]
+                enc[o:o + 4].view(np.int32)[0] = hdr[name]
+            # frame_length is nb_subfr * subfr_length (silk/control_codec.c); the reference reads it for its stack buffer
+            o = d["OPUSGPU_REF_OFF_FRAME_LENGTH"]
+            enc[o:o + 4].view(np.int32)[0] = hdr["nb_subfr"] * hdr["subfr_length"]
+            enc[d["OPUSGPU_REF_OFF_INDICES"] + d["OPUSGPU_REF_OFF_SIGNAL_TYPE"]] = np.uint8(hdr["signalType"])
+            enc[d["OPUSGPU_REF_OFF_PREV_NLSFQ_Q15"]:][:32] = row[2592:2624]
+            enc[off_cb:off_cb + 8].view(np.uint64)[0] = cb_wb
+            ctl[d["OPUSGPU_REF_OFF_CTRL_GAINS_Q16"]:][:16] = row[2560:2576]
+            ctl[d["OPUSGPU_REF_OFF_CTRL_PITCHL"]:][:16] = row[2576:2592]
+            o = d["OPUSGPU_REF_OFF_CTRL_CODING_QUALITY_Q14"]
+            ctl[o:o + 4].view(np.int32)[0] = hdr["coding_quality_Q14"]
+            res_pitch = np.zeros(1024, np.int16)
+            res_pitch[:640] = row[:1280].view(np.int16)
+            xbuf = np.zeros(1024, np.int16)
+            xbuf[:640] = row[1280:2560].view(np.int16)
+            xptr = C.c_void_p(xbuf.ctypes.data + 2 * hdr["ltp_mem_length"])
+            fn(p(enc), p(ctl), p(res_pitch), xptr, C.c_int(hdr["condCoding"]))
+            images.append((enc, ctl))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(images[0][1], images[1][1]), (k, "silk_encoder_control_FIX", np.nonzero(images[0][1] != images[1][1])[0][:8])
+        assert np.array_equal(images[0][0], images[1][0]), (k, "silk_encoder_state_FIX", np.nonzero(images[0][0] != images[1][0])[0][:8])
+        ctl = images[1][1]
+        assert np.array_equal(ctl[d["OPUSGPU_REF_OFF_CTRL_PRED_COEF_Q12"]:][:64], want[k, :64])
+    assert seen == {True, False}, "voiced and unvoiced frames among the picks"
+
+
 def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
     """opusgpu_quant_all_bands with the tree's 21-argument list and its ec_ctx (EC_DIFF included) against quant_all_bands of the
     compiled reference ON THE CALLS THE REFERENCE ENCODER ITSELF MAKES: oracle/_ref/libopus_ref_celtcap.so (--wrap=quant_all_bands,

@@ -32,6 +32,25 @@ PAIRS = {
     "OPUSGPU_REF_OFF_NLSF_INDICES": "SideInfoIndices.NLSFIndices",
     "OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8": "silk_encoder_state.speech_activity_Q8",
     "OPUSGPU_REF_OFF_NLSF_MSVQ_SURVIVORS": "silk_encoder_state.NLSF_MSVQ_Survivors",
+    "OPUSGPU_REF_OFF_FIX_SCMN": "silk_encoder_state_FIX.sCmn",
+    "OPUSGPU_REF_OFF_MU_LTP_Q9": "silk_encoder_state.mu_LTP_Q9",
+    "OPUSGPU_REF_OFF_LTP_QUANT_LOW_COMPLEXITY": "silk_encoder_state.LTPQuantLowComplexity",
+    "OPUSGPU_REF_OFF_SUM_LOG_GAIN_Q7": "silk_encoder_state.sum_log_gain_Q7",
+    "OPUSGPU_REF_OFF_PACKET_LOSS_PERC": "silk_encoder_state.PacketLoss_perc",
+    "OPUSGPU_REF_OFF_N_FRAMES_PER_PACKET": "silk_encoder_state.nFramesPerPacket",
+    "OPUSGPU_REF_OFF_LTP_INDEX": "SideInfoIndices.LTPIndex",
+    "OPUSGPU_REF_OFF_PER_INDEX": "SideInfoIndices.PERIndex",
+    "OPUSGPU_REF_OFF_LTP_SCALE_INDEX": "SideInfoIndices.LTP_scaleIndex",
+    "OPUSGPU_REF_SIZEOF_SILK_ENCODER_CONTROL_FIX": "sizeof.silk_encoder_control_FIX",
+    "OPUSGPU_REF_OFF_CTRL_GAINS_Q16": "silk_encoder_control_FIX.Gains_Q16",
+    "OPUSGPU_REF_OFF_CTRL_PRED_COEF_Q12": "silk_encoder_control_FIX.PredCoef_Q12",
+    "OPUSGPU_REF_OFF_CTRL_LTP_COEF_Q14": "silk_encoder_control_FIX.LTPCoef_Q14",
+    "OPUSGPU_REF_OFF_CTRL_LTP_SCALE_Q14": "silk_encoder_control_FIX.LTP_scale_Q14",
+    "OPUSGPU_REF_OFF_CTRL_PITCHL": "silk_encoder_control_FIX.pitchL",
+    "OPUSGPU_REF_OFF_CTRL_CODING_QUALITY_Q14": "silk_encoder_control_FIX.coding_quality_Q14",
+    "OPUSGPU_REF_OFF_CTRL_LTP_RED_COD_GAIN_Q7": "silk_encoder_control_FIX.LTPredCodGain_Q7",
+    "OPUSGPU_REF_OFF_CTRL_RES_NRG": "silk_encoder_control_FIX.ResNrg",
+    "OPUSGPU_REF_OFF_CTRL_RES_NRG_Q": "silk_encoder_control_FIX.ResNrgQ",
 }
 
 
