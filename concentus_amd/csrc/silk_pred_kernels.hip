@@ -4,6 +4,7 @@
 // times); res_pitch and x are read from the records where they lie.
 #include <string.h>
 #include "silk_pred_dev.h"
+#include "silk_gains_dev.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
 #include "../../include/opusgpu_hooks.h"
@@ -57,9 +58,46 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     out.status = OPUSGPU_OK;
 }
 
+__global__ __launch_bounds__(64) void silk_process_gains_kernel(const opusgpu_process_gains_in *__restrict__ recs,
+                                                                opusgpu_process_gains_out *__restrict__ outs, int n_rec,
+                                                                int *__restrict__ bad_records)
+{
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_process_gains_in in = recs[r];
+    opusgpu_process_gains_out o;
+    memset(&o, 0, sizeof(o));
+    if (!process_gains_record_ok(in)) {
+        o.status = OPUSGPU_BAD_ARG;
+        outs[r] = o;
+        atomicAdd(bad_records, 1);
+        return;
+    }
+    ProcessGainsIO g;
+    for (int k = 0; k < 4; k++) { g.Gains_Q16[k] = in.Gains_Q16[k]; g.GainsUnq_Q16[k] = 0; g.ResNrg[k] = in.ResNrg[k]; g.ResNrgQ[k] = in.ResNrgQ[k]; g.GainsIndices[k] = 0; }
+    g.LastGainIndex = in.LastGainIndex; g.lastGainIndexPrev = 0; g.quantOffsetType = in.quantOffsetType; g.Lambda_Q10 = 0;
+    silk_process_gains_dev(g, in.signalType, in.nb_subfr, in.subfr_length, in.LTPredCodGain_Q7, in.SNR_dB_Q7, in.condCoding,
+                           in.input_tilt_Q15, in.nStatesDelayedDecision, in.speech_activity_Q8, in.input_quality_Q14, in.coding_quality_Q14);
+    for (int k = 0; k < in.nb_subfr; k++) { o.Gains_Q16[k] = g.Gains_Q16[k]; o.GainsUnq_Q16[k] = g.GainsUnq_Q16[k]; o.GainsIndices[k] = g.GainsIndices[k]; }
+    o.Lambda_Q10 = g.Lambda_Q10; o.LastGainIndex = g.LastGainIndex; o.lastGainIndexPrev = g.lastGainIndexPrev; o.quantOffsetType = g.quantOffsetType;
+    o.status = OPUSGPU_OK;
+    outs[r] = o;
+}
+
 }  // namespace ca
 
 using namespace ca;
+
+extern "C" int opusgpu_silk_process_gains_batch(const opusgpu_process_gains_in *d_in, opusgpu_process_gains_out *d_out, int n, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_process_gains_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
+    return opusgpu_check_launch();
+}
 
 extern "C" int opusgpu_silk_find_pred_coefs_batch(const opusgpu_find_pred_coefs_in *d_in, opusgpu_find_pred_coefs_out *d_out, int n, void *stream)
 {

@@ -66,6 +66,15 @@ __device__ __forceinline__ bool find_pred_coefs_record_ok(const opusgpu_find_pre
     return true;
 }
 
+__device__ __forceinline__ bool process_gains_record_ok(const opusgpu_process_gains_in &in)
+{
+    if (!((in.nb_subfr == 2 || in.nb_subfr == 4) && in.subfr_length >= 1 && in.subfr_length <= 80)) return false;
+    if ((unsigned)in.signalType > 2u || (unsigned)in.quantOffsetType > 1u || (unsigned)in.LastGainIndex > 63u) return false;
+    for (int k = 0; k < in.nb_subfr; k++)
+        if (in.Gains_Q16[k] <= 0 || in.ResNrg[k] < 0 || in.ResNrgQ[k] < -31 || in.ResNrgQ[k] > 31) return false;   // shift counts
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -230,3 +230,27 @@ def silk_find_pred_coefs(fpc_in, fpc_out=None):
     (opusgpu_find_pred_coefs_out: every field the call writes in psEnc / psEncCtrl, then status)."""
     return _record_op("opusgpu_silk_find_pred_coefs_batch", fpc_in, fpc_out, SIZES["find_pred_coefs_in"], SIZES["find_pred_coefs_out"],
                       "fpc")
+
+
+class ProcessGainsIn(C.Structure):
+    """opusgpu_process_gains_in: one silk_process_gains_FIX() call (opus-fix/silk/fixed/process_gains_FIX.c:37)."""
+    _fields_ = [("Gains_Q16", C.c_int32 * 4), ("ResNrg", C.c_int32 * 4), ("ResNrgQ", C.c_int32 * 4)] + [(k, C.c_int32) for k in (
+        "LTPredCodGain_Q7", "signalType", "nb_subfr", "subfr_length", "SNR_dB_Q7", "LastGainIndex", "condCoding", "input_tilt_Q15",
+        "quantOffsetType", "nStatesDelayedDecision", "speech_activity_Q8", "input_quality_Q14", "coding_quality_Q14")] + [
+        ("reserved", C.c_int32 * 3)]
+
+
+class ProcessGainsOut(C.Structure):
+    _fields_ = [("Gains_Q16", C.c_int32 * 4), ("GainsUnq_Q16", C.c_int32 * 4), ("Lambda_Q10", C.c_int32), ("LastGainIndex", C.c_int32),
+                ("lastGainIndexPrev", C.c_int32), ("quantOffsetType", C.c_int32), ("GainsIndices", C.c_int8 * 4), ("status", C.c_int32)]
+
+
+SIZES["process_gains_in"] = C.sizeof(ProcessGainsIn)
+SIZES["process_gains_out"] = C.sizeof(ProcessGainsOut)
+
+
+def silk_process_gains(gains_in, gains_out=None):
+    """silk_process_gains_FIX() over a batch of records: gains_in uint8 [N][112] (opusgpu_process_gains_in) -> uint8 [N][56]
+    (opusgpu_process_gains_out)."""
+    return _record_op("opusgpu_silk_process_gains_batch", gains_in, gains_out, SIZES["process_gains_in"], SIZES["process_gains_out"],
+                      "gains")

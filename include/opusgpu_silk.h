@@ -226,6 +226,30 @@ typedef struct opusgpu_find_pred_coefs_out {
 
 int opusgpu_silk_find_pred_coefs_batch(const opusgpu_find_pred_coefs_in *d_in, opusgpu_find_pred_coefs_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_process_gains_FIX, batched (fourth slice) -----------------------------------------------------
+ * Replaces silk_process_gains_FIX(psEnc, psEncCtrl, condCoding) (opus-fix/silk/fixed/process_gains_FIX.c:37-125, called from
+ * silk_encode_frame_FIX between silk_find_pred_coefs_FIX and the noise-shaping quantiser): LTP-gain dependent gain
+ * reduction, the soft limit against the residual energies, silk_gains_quant, quantOffsetType for voiced frames, Lambda_Q10. */
+typedef struct opusgpu_process_gains_in {
+    int32_t Gains_Q16[4];                    /* psEncCtrl->Gains_Q16 */
+    int32_t ResNrg[4];                       /* psEncCtrl->ResNrg (from silk_find_pred_coefs_FIX) */
+    int32_t ResNrgQ[4];
+    int32_t LTPredCodGain_Q7, signalType, nb_subfr, subfr_length;
+    int32_t SNR_dB_Q7, LastGainIndex /* psEnc->sShape.LastGainIndex */, condCoding, input_tilt_Q15;
+    int32_t quantOffsetType, nStatesDelayedDecision, speech_activity_Q8, input_quality_Q14;
+    int32_t coding_quality_Q14, reserved[3];
+} opusgpu_process_gains_in;
+
+typedef struct opusgpu_process_gains_out {
+    int32_t Gains_Q16[4];                    /* quantised */
+    int32_t GainsUnq_Q16[4];
+    int32_t Lambda_Q10, LastGainIndex, lastGainIndexPrev, quantOffsetType;
+    int8_t GainsIndices[4];
+    int32_t status;
+} opusgpu_process_gains_out;
+
+int opusgpu_silk_process_gains_batch(const opusgpu_process_gains_in *d_in, opusgpu_process_gains_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

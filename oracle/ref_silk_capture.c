@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -320,5 +320,46 @@ void __wrap_silk_find_pred_coefs_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
         o->LTP_scaleIndex = voiced ? c->indices.LTP_scaleIndex : -1;
         o->status = 0;
         g_nf++;
+    }
+}
+
+/* ---- silk_process_gains_FIX (opus-fix/silk/fixed/process_gains_FIX.c:37): the psEnc / psEncCtrl fields it reads -> the ones it writes ---- */
+static opusgpu_process_gains_in *g_gin; static opusgpu_process_gains_out *g_gout; static int g_ng, g_capg;
+void refcap_start_gains(int max_records)
+{
+    g_capg = max_records; g_ng = 0; g_on = 1;
+    g_gin = (opusgpu_process_gains_in *)calloc(max_records, sizeof(*g_gin));
+    g_gout = (opusgpu_process_gains_out *)calloc(max_records, sizeof(*g_gout));
+}
+int refcap_count_gains(void) { return g_ng; }
+int refcap_sizes_gains(int which) { return which == 0 ? sizeof(opusgpu_process_gains_in) : sizeof(opusgpu_process_gains_out); }
+void refcap_get_gains(void *gin, void *gout)
+{
+    memcpy(gin, g_gin, (size_t)g_ng * sizeof(*g_gin)); memcpy(gout, g_gout, (size_t)g_ng * sizeof(*g_gout));
+}
+
+void __real_silk_process_gains_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, opus_int condCoding);
+void __wrap_silk_process_gains_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, opus_int condCoding)
+{
+    const silk_encoder_state *c = &psEnc->sCmn;
+    int rec = (g_on && g_gin && g_ng < g_capg) ? g_ng : -1;
+    if (rec >= 0) {
+        opusgpu_process_gains_in *r = &g_gin[rec];
+        for (int k = 0; k < MAX_NB_SUBFR; k++) { r->Gains_Q16[k] = psEncCtrl->Gains_Q16[k]; r->ResNrg[k] = psEncCtrl->ResNrg[k]; r->ResNrgQ[k] = psEncCtrl->ResNrgQ[k]; }
+        r->LTPredCodGain_Q7 = psEncCtrl->LTPredCodGain_Q7; r->signalType = c->indices.signalType; r->nb_subfr = c->nb_subfr;
+        r->subfr_length = c->subfr_length; r->SNR_dB_Q7 = c->SNR_dB_Q7; r->LastGainIndex = psEnc->sShape.LastGainIndex;
+        r->condCoding = condCoding; r->input_tilt_Q15 = c->input_tilt_Q15; r->quantOffsetType = c->indices.quantOffsetType;
+        r->nStatesDelayedDecision = c->nStatesDelayedDecision; r->speech_activity_Q8 = c->speech_activity_Q8;
+        r->input_quality_Q14 = psEncCtrl->input_quality_Q14; r->coding_quality_Q14 = psEncCtrl->coding_quality_Q14;
+    }
+    __real_silk_process_gains_FIX(psEnc, psEncCtrl, condCoding);
+    if (rec >= 0) {
+        opusgpu_process_gains_out *o = &g_gout[rec];
+        for (int k = 0; k < c->nb_subfr; k++) {
+            o->Gains_Q16[k] = psEncCtrl->Gains_Q16[k]; o->GainsUnq_Q16[k] = psEncCtrl->GainsUnq_Q16[k]; o->GainsIndices[k] = c->indices.GainsIndices[k];
+        }
+        o->Lambda_Q10 = psEncCtrl->Lambda_Q10; o->LastGainIndex = psEnc->sShape.LastGainIndex; o->lastGainIndexPrev = psEncCtrl->lastGainIndexPrev;
+        o->quantOffsetType = c->indices.quantOffsetType; o->status = 0;
+        g_ng++;
     }
 }

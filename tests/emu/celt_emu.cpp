@@ -238,3 +238,22 @@ extern "C" void emu_silk_find_pred_coefs(const opusgpu_find_pred_coefs_in *in, o
         pred_out_to_record(o, in[r].predictLPCOrder, in[r].nb_subfr, out[r]);
     }
 }
+
+// ---- silk_process_gains_FIX, host build of concentus_amd/csrc/silk_gains_dev.h ----
+#include "../../concentus_amd/csrc/silk_gains_dev.h"
+extern "C" void emu_silk_process_gains(const opusgpu_process_gains_in *in, opusgpu_process_gains_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        const opusgpu_process_gains_in &i = in[r];
+        ca::ProcessGainsIO g;
+        memset(&g, 0, sizeof(g));
+        for (int k = 0; k < 4; k++) { g.Gains_Q16[k] = i.Gains_Q16[k]; g.ResNrg[k] = i.ResNrg[k]; g.ResNrgQ[k] = i.ResNrgQ[k]; }
+        g.LastGainIndex = i.LastGainIndex; g.quantOffsetType = i.quantOffsetType;
+        ca::silk_process_gains_dev(g, i.signalType, i.nb_subfr, i.subfr_length, i.LTPredCodGain_Q7, i.SNR_dB_Q7, i.condCoding, i.input_tilt_Q15,
+                                   i.nStatesDelayedDecision, i.speech_activity_Q8, i.input_quality_Q14, i.coding_quality_Q14);
+        memset(&out[r], 0, sizeof(out[r]));
+        for (int k = 0; k < i.nb_subfr; k++) { out[r].Gains_Q16[k] = g.Gains_Q16[k]; out[r].GainsUnq_Q16[k] = g.GainsUnq_Q16[k]; out[r].GainsIndices[k] = g.GainsIndices[k]; }
+        out[r].Lambda_Q10 = g.Lambda_Q10; out[r].LastGainIndex = g.LastGainIndex; out[r].lastGainIndexPrev = g.lastGainIndexPrev;
+        out[r].quantOffsetType = g.quantOffsetType;
+    }
+}

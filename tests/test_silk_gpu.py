@@ -358,3 +358,29 @@ def test_find_pred_coefs_32768_distinct_records_vs_reference_outputs(ca):
     assert ca.silk.bad_records() == 2
     good = np.setdiff1d(np.arange(256), [voiced[0], 9])
     assert np.array_equal(o2[good, :204], want[:256][good, :204]) and (o2[[voiced[0], 9], 204:208].view(np.int32) == -1).all()
+
+
+def test_process_gains_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_process_gains_FIX on the GPU against what the unmodified reference wrote when the records were captured
+    (tests/silk_corpus.py kind "gains"): quantised and unquantised gains, GainsIndices, LastGainIndex, lastGainIndexPrev,
+    quantOffsetType, Lambda_Q10."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "gains")
+    out = ca.silk_process_gains(_dev(rec["gains_in"]))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.asarray(rec["gains_out"])
+    assert (out[:, 52:56].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :52] != want[:, :52]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], out[bad[:1], :52].view(np.int32), want[bad[:1], :52].view(np.int32))
+    ca.silk.bad_records()
+    gin = np.array(rec["gains_in"][:256])
+    gin[4, 0:4].view(np.int32)[0] = 0                          # Gains_Q16[0]
+    gin[8, 48 + 20:48 + 24].view(np.int32)[0] = 200            # LastGainIndex
+    o2 = ca.silk_process_gains(_dev(gin)).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [4, 8])
+    assert np.array_equal(o2[good, :52], want[:256][good, :52]) and (o2[[4, 8], 52:56].view(np.int32) == -1).all()

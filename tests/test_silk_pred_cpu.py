@@ -34,3 +34,26 @@ def test_find_pred_coefs_sources_match_the_reference_on_fresh_records():
             cols = np.nonzero(got[k, :204] != want[k, :204])[0]
             raise AssertionError((bad.size, bad[:8], "signalType", hdr[k, 4], "first differing bytes", cols[:12]))
         del c
+
+
+@pytest.mark.ref
+def test_process_gains_sources_match_the_reference_on_fresh_records():
+    """silk_process_gains_FIX (fourth slice; concentus_amd/csrc/silk_gains_dev.h): quantised and unquantised gains,
+    GainsIndices, LastGainIndex, lastGainIndexPrev, quantOffsetType, Lambda_Q10 of every captured call. Several frames of one
+    packet are coded conditionally (the reference's bitrate loop calls the function again after changing the gains): both kinds
+    must be in the corpus."""
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    emu = emulib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4 * silk_corpus.SEG_FRAMES, "gains", cache=tmp, workers=4)
+        gin = np.ascontiguousarray(c["gains_in"])
+        want = np.asarray(c["gains_out"])
+        n = gin.shape[0]
+        got = np.zeros((n, silk_corpus.SIZES["gains_out"]), np.uint8)
+        emu.emu_silk_process_gains(gin.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_long(n))
+        hdr = gin[:, 48:112].view(np.int32)
+        assert (hdr[:, 1] == 2).sum() > 1000 and (hdr[:, 1] != 2).sum() > 200, "voiced and unvoiced frames"
+        bad = np.nonzero((got[:, :52] != want[:, :52]).any(1))[0]
+        assert bad.size == 0, (bad.size, bad[:8], got[bad[:1], :52].view(np.int32), want[bad[:1], :52].view(np.int32))
+        del c
