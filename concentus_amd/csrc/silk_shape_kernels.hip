@@ -1,0 +1,69 @@
+// silk_shape_kernels.hip -- batched silk_noise_shape_analysis_FIX (opus-fix/silk/fixed/noise_shape_analysis_FIX.c:146-466), one lane
+// per frame. The arithmetic lives in silk_shape_dev.h; the windowed analysis block (and its down-shifted copy for the plain
+// autocorrelation) of each of the wavefront's 64 frames lives in LDS laid out [sample][lane].
+#include <string.h>
+#include "silk_shape_dev.h"
+#include "opusgpu_internal.h"
+#include "../../include/opusgpu_silk.h"
+#include "silk_validate.h"
+
+namespace ca {
+
+struct ShapeCol {                                              // this lane's column of a [sample][lane] block
+    i16 *p;
+    __device__ __forceinline__ i16 &operator[](int k) const { return p[k * 64]; }
+    __device__ __forceinline__ ShapeCol operator+(int o) const { ShapeCol r; r.p = p + o * 64; return r; }
+};
+
+__global__ __launch_bounds__(64) void silk_noise_shape_kernel(const opusgpu_noise_shape_in *__restrict__ recs,
+                                                              opusgpu_noise_shape_out *__restrict__ outs, int n_rec,
+                                                              int *__restrict__ bad_records)
+{
+    __shared__ i16 xw_s[240 * 64], xs_s[240 * 64];
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_noise_shape_in &in = recs[r];
+    opusgpu_noise_shape_out &out = outs[r];
+    if (!noise_shape_record_ok(in)) {
+        memset(&out, 0, sizeof(out));
+        out.status = OPUSGPU_BAD_ARG;
+        atomicAdd(bad_records, 1);
+        return;
+    }
+    ShapeCfg c;
+    c.fs_kHz = in.fs_kHz; c.nb_subfr = in.nb_subfr; c.subfr_length = in.subfr_length; c.la_shape = in.la_shape; c.shapeWinLength = in.shapeWinLength;
+    c.shapingLPCOrder = in.shapingLPCOrder; c.warping_Q16 = in.warping_Q16; c.SNR_dB_Q7 = in.SNR_dB_Q7; c.useCBR = in.useCBR;
+    c.speech_activity_Q8 = in.speech_activity_Q8; c.signalType = in.signalType; c.input_quality_bands_Q15[0] = in.input_quality_bands_Q15[0];
+    c.input_quality_bands_Q15[1] = in.input_quality_bands_Q15[1]; c.LTPCorr_Q15 = in.LTPCorr_Q15; c.predGain_Q16 = in.predGain_Q16;
+    for (int k = 0; k < 4; k++) c.pitchL[k] = in.pitchL[k];
+    ShapeOut o;
+    memset(&o, 0, sizeof(o));
+    o.HarmBoost_smth_Q16 = in.HarmBoost_smth_Q16; o.HarmShapeGain_smth_Q16 = in.HarmShapeGain_smth_Q16; o.Tilt_smth_Q16 = in.Tilt_smth_Q16;
+    ShapeCol xw, xs;
+    xw.p = xw_s + threadIdx.x;
+    xs.p = xs_s + threadIdx.x;
+    silk_noise_shape_analysis_dev(c, (const i16 *)in.pitch_res, (const i16 *)in.x + in.la_shape, xw, xs, o);
+    memset(&out, 0, sizeof(out));
+    for (int k = 0; k < in.nb_subfr; k++) { out.Gains_Q16[k] = o.Gains_Q16[k]; out.GainsPre_Q14[k] = o.GainsPre_Q14[k]; out.LF_shp_Q14[k] = o.LF_shp_Q14[k]; }
+    for (int k = 0; k < 4 * MAX_SHAPE_LPC_ORDER; k++) { out.AR1_Q13[k] = o.AR1_Q13[k]; out.AR2_Q13[k] = o.AR2_Q13[k]; }
+    for (int k = 0; k < 4; k++) { out.HarmBoost_Q14[k] = o.HarmBoost_Q14[k]; out.HarmShapeGain_Q14[k] = o.HarmShapeGain_Q14[k]; out.Tilt_Q14[k] = o.Tilt_Q14[k]; }
+    out.HarmBoost_smth_Q16 = o.HarmBoost_smth_Q16; out.HarmShapeGain_smth_Q16 = o.HarmShapeGain_smth_Q16; out.Tilt_smth_Q16 = o.Tilt_smth_Q16;
+    out.input_quality_Q14 = o.input_quality_Q14; out.coding_quality_Q14 = o.coding_quality_Q14; out.sparseness_Q8 = o.sparseness_Q8;
+    out.quantOffsetType = o.quantOffsetType;
+    out.status = OPUSGPU_OK;
+}
+
+}  // namespace ca
+
+using namespace ca;
+
+extern "C" int opusgpu_silk_noise_shape_analysis_batch(const opusgpu_noise_shape_in *d_in, opusgpu_noise_shape_out *d_out, int n, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_noise_shape_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
+    return opusgpu_check_launch();
+}

@@ -75,6 +75,21 @@ __device__ __forceinline__ bool process_gains_record_ok(const opusgpu_process_ga
     return true;
 }
 
+__device__ __forceinline__ bool noise_shape_record_ok(const opusgpu_noise_shape_in &in)
+{
+    const int n = in.nb_subfr, L = in.subfr_length, la = in.la_shape, W = in.shapeWinLength, D = in.shapingLPCOrder, fs = in.fs_kHz;
+    if (!((n == 2 || n == 4) && (fs == 8 || fs == 12 || fs == 16) && L == 5 * fs && la >= 0 && la <= OPUSGPU_SILK_MAX_LA_SHAPE)) return false;
+    if (!(W == L + 2 * la && W <= 240 && D >= 2 && D <= 16 && !(D & 1))) return false;
+    // the two sine slopes: length a multiple of 4 in 16..120 (apply_sine_window_FIX.c:61-62)
+    const int slope = (W - 3 * fs) >> 1;
+    if (!(slope >= 16 && slope <= 120 && !(slope & 3) && 2 * slope + 3 * fs == W)) return false;
+    if ((unsigned)in.signalType > 2u || (unsigned)in.speech_activity_Q8 > 256u || in.warping_Q16 < 0 || in.warping_Q16 > 32767) return false;
+    if (in.signalType == 2)
+        for (int k = 0; k < n; k++)
+            if (in.pitchL[k] < 1) return false;                  // 3.0 / pitchL
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -254,3 +254,31 @@ def silk_process_gains(gains_in, gains_out=None):
     (opusgpu_process_gains_out)."""
     return _record_op("opusgpu_silk_process_gains_batch", gains_in, gains_out, SIZES["process_gains_in"], SIZES["process_gains_out"],
                       "gains")
+
+
+class NoiseShapeIn(C.Structure):
+    """opusgpu_noise_shape_in: one silk_noise_shape_analysis_FIX() call (opus-fix/silk/fixed/noise_shape_analysis_FIX.c:146)."""
+    _fields_ = [("x", C.c_int16 * 480), ("pitch_res", C.c_int16 * 320)] + [(k, C.c_int32) for k in (
+        "fs_kHz", "nb_subfr", "subfr_length", "la_shape", "shapeWinLength", "shapingLPCOrder", "warping_Q16", "SNR_dB_Q7", "useCBR",
+        "speech_activity_Q8", "signalType", "LTPCorr_Q15")] + [("input_quality_bands_Q15", C.c_int32 * 2), ("predGain_Q16", C.c_int32),
+        ("reserved", C.c_int32), ("pitchL", C.c_int32 * 4), ("HarmBoost_smth_Q16", C.c_int32), ("HarmShapeGain_smth_Q16", C.c_int32),
+        ("Tilt_smth_Q16", C.c_int32), ("reserved2", C.c_int32)]
+
+
+class NoiseShapeOut(C.Structure):
+    _fields_ = [("Gains_Q16", C.c_int32 * 4), ("GainsPre_Q14", C.c_int32 * 4), ("AR1_Q13", C.c_int16 * 64), ("AR2_Q13", C.c_int16 * 64),
+                ("LF_shp_Q14", C.c_int32 * 4), ("HarmBoost_Q14", C.c_int32 * 4), ("HarmShapeGain_Q14", C.c_int32 * 4),
+                ("Tilt_Q14", C.c_int32 * 4), ("HarmBoost_smth_Q16", C.c_int32), ("HarmShapeGain_smth_Q16", C.c_int32),
+                ("Tilt_smth_Q16", C.c_int32), ("input_quality_Q14", C.c_int32), ("coding_quality_Q14", C.c_int32),
+                ("sparseness_Q8", C.c_int32), ("quantOffsetType", C.c_int32), ("status", C.c_int32)]
+
+
+SIZES["noise_shape_in"] = C.sizeof(NoiseShapeIn)
+SIZES["noise_shape_out"] = C.sizeof(NoiseShapeOut)
+
+
+def silk_noise_shape_analysis(shape_in, shape_out=None):
+    """silk_noise_shape_analysis_FIX() over a batch of records: shape_in uint8 [N][1696] (opusgpu_noise_shape_in) -> uint8 [N][384]
+    (opusgpu_noise_shape_out)."""
+    return _record_op("opusgpu_silk_noise_shape_analysis_batch", shape_in, shape_out, SIZES["noise_shape_in"], SIZES["noise_shape_out"],
+                      "shape")

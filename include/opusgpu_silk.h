@@ -250,6 +250,40 @@ typedef struct opusgpu_process_gains_out {
 
 int opusgpu_silk_process_gains_batch(const opusgpu_process_gains_in *d_in, opusgpu_process_gains_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_noise_shape_analysis_FIX, batched (fifth slice) -----------------------------------------------
+ * Replaces silk_noise_shape_analysis_FIX(psEnc, psEncCtrl, pitch_res, x, arch) (opus-fix/silk/fixed/noise_shape_analysis_FIX.c:146-466,
+ * called from silk_encode_frame_FIX before silk_find_pred_coefs_FIX): windowing, (warped) autocorrelation, Schur recursion, the
+ * two bandwidth-expanded shaping filters per subframe, the initial gains, low-frequency / tilt / harmonic shaping controls and
+ * their smoothing state. A record is the two signal arguments plus the psEnc / psEncCtrl fields read; the output is every
+ * field written. AR1_Q13 / AR2_Q13 rows hold shapingLPCOrder entries each (stride 16, the rest zero). */
+#define OPUSGPU_SILK_MAX_LA_SHAPE 80             /* LA_SHAPE_MS * MAX_FS_KHZ */
+typedef struct opusgpu_noise_shape_in {
+    int16_t x[OPUSGPU_SILK_MAX_FRAME + 2 * OPUSGPU_SILK_MAX_LA_SHAPE]; /* x[-la_shape .. frame_length + la_shape) */
+    int16_t pitch_res[OPUSGPU_SILK_MAX_FRAME];                          /* the frame's pitch-analysis residual */
+    int32_t fs_kHz, nb_subfr, subfr_length, la_shape;
+    int32_t shapeWinLength, shapingLPCOrder, warping_Q16, SNR_dB_Q7;
+    int32_t useCBR, speech_activity_Q8, signalType, LTPCorr_Q15;       /* LTPCorr_Q15: psEnc->LTPCorr_Q15 */
+    int32_t input_quality_bands_Q15[2], predGain_Q16, reserved;        /* predGain_Q16: psEncCtrl->predGain_Q16 */
+    int32_t pitchL[4];
+    int32_t HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16, reserved2;   /* psEnc->sShape */
+} opusgpu_noise_shape_in;
+
+typedef struct opusgpu_noise_shape_out {
+    int32_t Gains_Q16[4];
+    int32_t GainsPre_Q14[4];
+    int16_t AR1_Q13[4 * 16];
+    int16_t AR2_Q13[4 * 16];
+    int32_t LF_shp_Q14[4];
+    int32_t HarmBoost_Q14[4];
+    int32_t HarmShapeGain_Q14[4];
+    int32_t Tilt_Q14[4];
+    int32_t HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16;
+    int32_t input_quality_Q14, coding_quality_Q14, sparseness_Q8, quantOffsetType;
+    int32_t status;
+} opusgpu_noise_shape_out;
+
+int opusgpu_silk_noise_shape_analysis_batch(const opusgpu_noise_shape_in *d_in, opusgpu_noise_shape_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -361,5 +361,61 @@ void __wrap_silk_process_gains_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_c
         o->Lambda_Q10 = psEncCtrl->Lambda_Q10; o->LastGainIndex = psEnc->sShape.LastGainIndex; o->lastGainIndexPrev = psEncCtrl->lastGainIndexPrev;
         o->quantOffsetType = c->indices.quantOffsetType; o->status = 0;
         g_ng++;
+    }
+}
+
+/* ---- silk_noise_shape_analysis_FIX (opus-fix/silk/fixed/noise_shape_analysis_FIX.c:146): arguments + the psEnc / psEncCtrl fields it
+ * reads -> every field it writes ---- */
+static opusgpu_noise_shape_in *g_sin; static opusgpu_noise_shape_out *g_sout; static int g_ns, g_caps;
+void refcap_start_shape(int max_records)
+{
+    g_caps = max_records; g_ns = 0; g_on = 1;
+    g_sin = (opusgpu_noise_shape_in *)calloc(max_records, sizeof(*g_sin));
+    g_sout = (opusgpu_noise_shape_out *)calloc(max_records, sizeof(*g_sout));
+}
+int refcap_count_shape(void) { return g_ns; }
+int refcap_sizes_shape(int which) { return which == 0 ? sizeof(opusgpu_noise_shape_in) : sizeof(opusgpu_noise_shape_out); }
+void refcap_get_shape(void *sin_, void *sout)
+{
+    memcpy(sin_, g_sin, (size_t)g_ns * sizeof(*g_sin)); memcpy(sout, g_sout, (size_t)g_ns * sizeof(*g_sout));
+}
+
+void __real_silk_noise_shape_analysis_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, const opus_int16 *pitch_res,
+                                          const opus_int16 *x, int arch);
+void __wrap_silk_noise_shape_analysis_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, const opus_int16 *pitch_res,
+                                          const opus_int16 *x, int arch)
+{
+    const silk_encoder_state *c = &psEnc->sCmn;
+    int rec = (g_on && g_sin && g_ns < g_caps && c->la_shape <= OPUSGPU_SILK_MAX_LA_SHAPE && c->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_ns : -1;
+    if (rec >= 0) {
+        opusgpu_noise_shape_in *r = &g_sin[rec];
+        memcpy(r->x, x - c->la_shape, sizeof(opus_int16) * (c->frame_length + 2 * c->la_shape));
+        memcpy(r->pitch_res, pitch_res, sizeof(opus_int16) * c->frame_length);
+        r->fs_kHz = c->fs_kHz; r->nb_subfr = c->nb_subfr; r->subfr_length = c->subfr_length; r->la_shape = c->la_shape;
+        r->shapeWinLength = c->shapeWinLength; r->shapingLPCOrder = c->shapingLPCOrder; r->warping_Q16 = c->warping_Q16;
+        r->SNR_dB_Q7 = c->SNR_dB_Q7; r->useCBR = c->useCBR; r->speech_activity_Q8 = c->speech_activity_Q8;
+        r->signalType = c->indices.signalType; r->LTPCorr_Q15 = psEnc->LTPCorr_Q15;
+        r->input_quality_bands_Q15[0] = c->input_quality_bands_Q15[0]; r->input_quality_bands_Q15[1] = c->input_quality_bands_Q15[1];
+        r->predGain_Q16 = psEncCtrl->predGain_Q16;
+        for (int k = 0; k < MAX_NB_SUBFR; k++) r->pitchL[k] = psEncCtrl->pitchL[k];
+        r->HarmBoost_smth_Q16 = psEnc->sShape.HarmBoost_smth_Q16; r->HarmShapeGain_smth_Q16 = psEnc->sShape.HarmShapeGain_smth_Q16;
+        r->Tilt_smth_Q16 = psEnc->sShape.Tilt_smth_Q16;
+    }
+    __real_silk_noise_shape_analysis_FIX(psEnc, psEncCtrl, pitch_res, x, arch);
+    if (rec >= 0) {
+        opusgpu_noise_shape_out *o = &g_sout[rec];
+        for (int k = 0; k < c->nb_subfr; k++) {
+            o->Gains_Q16[k] = psEncCtrl->Gains_Q16[k]; o->GainsPre_Q14[k] = psEncCtrl->GainsPre_Q14[k]; o->LF_shp_Q14[k] = psEncCtrl->LF_shp_Q14[k];
+            memcpy(&o->AR1_Q13[k * 16], &psEncCtrl->AR1_Q13[k * MAX_SHAPE_LPC_ORDER], sizeof(opus_int16) * c->shapingLPCOrder);
+            memcpy(&o->AR2_Q13[k * 16], &psEncCtrl->AR2_Q13[k * MAX_SHAPE_LPC_ORDER], sizeof(opus_int16) * c->shapingLPCOrder);
+        }
+        for (int k = 0; k < MAX_NB_SUBFR; k++) {
+            o->HarmBoost_Q14[k] = psEncCtrl->HarmBoost_Q14[k]; o->HarmShapeGain_Q14[k] = psEncCtrl->HarmShapeGain_Q14[k]; o->Tilt_Q14[k] = psEncCtrl->Tilt_Q14[k];
+        }
+        o->HarmBoost_smth_Q16 = psEnc->sShape.HarmBoost_smth_Q16; o->HarmShapeGain_smth_Q16 = psEnc->sShape.HarmShapeGain_smth_Q16;
+        o->Tilt_smth_Q16 = psEnc->sShape.Tilt_smth_Q16;
+        o->input_quality_Q14 = psEncCtrl->input_quality_Q14; o->coding_quality_Q14 = psEncCtrl->coding_quality_Q14;
+        o->sparseness_Q8 = psEncCtrl->sparseness_Q8; o->quantOffsetType = c->indices.quantOffsetType; o->status = 0;
+        g_ns++;
     }
 }

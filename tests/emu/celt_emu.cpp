@@ -257,3 +257,37 @@ extern "C" void emu_silk_process_gains(const opusgpu_process_gains_in *in, opusg
         out[r].quantOffsetType = g.quantOffsetType;
     }
 }
+
+// ---- silk_noise_shape_analysis_FIX, host build of concentus_amd/csrc/silk_shape_dev.h ----
+#include "../../concentus_amd/csrc/silk_shape_dev.h"
+static void shape_cfg_from_record(const opusgpu_noise_shape_in &i, ca::ShapeCfg &c, ca::ShapeOut &o)
+{
+    c.fs_kHz = i.fs_kHz; c.nb_subfr = i.nb_subfr; c.subfr_length = i.subfr_length; c.la_shape = i.la_shape; c.shapeWinLength = i.shapeWinLength;
+    c.shapingLPCOrder = i.shapingLPCOrder; c.warping_Q16 = i.warping_Q16; c.SNR_dB_Q7 = i.SNR_dB_Q7; c.useCBR = i.useCBR;
+    c.speech_activity_Q8 = i.speech_activity_Q8; c.signalType = i.signalType; c.input_quality_bands_Q15[0] = i.input_quality_bands_Q15[0];
+    c.input_quality_bands_Q15[1] = i.input_quality_bands_Q15[1]; c.LTPCorr_Q15 = i.LTPCorr_Q15; c.predGain_Q16 = i.predGain_Q16;
+    for (int k = 0; k < 4; k++) c.pitchL[k] = i.pitchL[k];
+    memset(&o, 0, sizeof(o));
+    o.HarmBoost_smth_Q16 = i.HarmBoost_smth_Q16; o.HarmShapeGain_smth_Q16 = i.HarmShapeGain_smth_Q16; o.Tilt_smth_Q16 = i.Tilt_smth_Q16;
+}
+static void shape_out_to_record(const ca::ShapeOut &o, int nb, opusgpu_noise_shape_out &r)
+{
+    memset(&r, 0, sizeof(r));
+    for (int k = 0; k < nb; k++) { r.Gains_Q16[k] = o.Gains_Q16[k]; r.GainsPre_Q14[k] = o.GainsPre_Q14[k]; r.LF_shp_Q14[k] = o.LF_shp_Q14[k]; }
+    for (int k = 0; k < 64; k++) { r.AR1_Q13[k] = o.AR1_Q13[k]; r.AR2_Q13[k] = o.AR2_Q13[k]; }
+    for (int k = 0; k < 4; k++) { r.HarmBoost_Q14[k] = o.HarmBoost_Q14[k]; r.HarmShapeGain_Q14[k] = o.HarmShapeGain_Q14[k]; r.Tilt_Q14[k] = o.Tilt_Q14[k]; }
+    r.HarmBoost_smth_Q16 = o.HarmBoost_smth_Q16; r.HarmShapeGain_smth_Q16 = o.HarmShapeGain_smth_Q16; r.Tilt_smth_Q16 = o.Tilt_smth_Q16;
+    r.input_quality_Q14 = o.input_quality_Q14; r.coding_quality_Q14 = o.coding_quality_Q14; r.sparseness_Q8 = o.sparseness_Q8;
+    r.quantOffsetType = o.quantOffsetType;
+}
+extern "C" void emu_silk_noise_shape_analysis(const opusgpu_noise_shape_in *in, opusgpu_noise_shape_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        ca::ShapeCfg c;
+        ca::ShapeOut o;
+        shape_cfg_from_record(in[r], c, o);
+        int16_t xw[256], xs[256];
+        ca::silk_noise_shape_analysis_dev(c, (const int16_t *)in[r].pitch_res, (const int16_t *)in[r].x + in[r].la_shape, (int16_t *)xw, (int16_t *)xs, o);
+        shape_out_to_record(o, in[r].nb_subfr, out[r]);
+    }
+}

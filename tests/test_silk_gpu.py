@@ -384,3 +384,30 @@ def test_process_gains_32768_distinct_records_vs_reference_outputs(ca):
     assert ca.silk.bad_records() == 2
     good = np.setdiff1d(np.arange(256), [4, 8])
     assert np.array_equal(o2[good, :52], want[:256][good, :52]) and (o2[[4, 8], 52:56].view(np.int32) == -1).all()
+
+
+def test_noise_shape_analysis_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_noise_shape_analysis_FIX on the GPU against what the unmodified reference wrote when the records were captured
+    (tests/silk_corpus.py kind "shape"; complexity 3 -> plain autocorrelation, 5 / 8 / 10 -> warped, orders 10 / 12 / 16 / 16)."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "shape")
+    out = ca.silk_noise_shape_analysis(_dev(rec["shape_in"]))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.asarray(rec["shape_out"])
+    assert (out[:, 380:384].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :380] != want[:, :380]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], np.nonzero(out[bad[0], :380] != want[bad[0], :380])[0][:12])
+    hdr = np.asarray(rec["shape_in"])[:, 1600:1696].view(np.int32)
+    assert (hdr[:, 6] == 0).sum() > 2000 and (hdr[:, 6] > 0).sum() > 2000
+    ca.silk.bad_records()
+    sin_ = np.array(rec["shape_in"][:256])
+    sin_[6, 1600 + 20:1600 + 24].view(np.int32)[0] = 40          # shapingLPCOrder
+    sin_[12, 1600 + 16:1600 + 20].view(np.int32)[0] = 1000       # shapeWinLength
+    o2 = ca.silk_noise_shape_analysis(_dev(sin_)).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [6, 12])
+    assert np.array_equal(o2[good, :380], want[:256][good, :380]) and (o2[[6, 12], 380:384].view(np.int32) == -1).all()

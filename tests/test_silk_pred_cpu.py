@@ -57,3 +57,29 @@ def test_process_gains_sources_match_the_reference_on_fresh_records():
         bad = np.nonzero((got[:, :52] != want[:, :52]).any(1))[0]
         assert bad.size == 0, (bad.size, bad[:8], got[bad[:1], :52].view(np.int32), want[bad[:1], :52].view(np.int32))
         del c
+
+
+@pytest.mark.ref
+def test_noise_shape_analysis_sources_match_the_reference_on_fresh_records():
+    """silk_noise_shape_analysis_FIX (fifth slice; concentus_amd/csrc/silk_shape_dev.h): every field the call
+    writes. Complexity 3 records take the plain autocorrelation (_celt_autocorr), 5 / 8 / 10 the warped one with shaping orders
+    12 / 16 / 16."""
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    emu = emulib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4 * silk_corpus.SEG_FRAMES, "shape", cache=tmp, workers=4)
+        sin_ = np.ascontiguousarray(c["shape_in"])
+        want = np.asarray(c["shape_out"])
+        n = sin_.shape[0]
+        got = np.zeros((n, silk_corpus.SIZES["shape_out"]), np.uint8)
+        emu.emu_silk_noise_shape_analysis(sin_.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_long(n))
+        hdr = sin_[:, 1600:1696].view(np.int32)
+        assert (hdr[:, 6] == 0).sum() > 500 and (hdr[:, 6] > 0).sum() > 500, "plain and warped autocorrelation"
+        assert (hdr[:, 10] == 2).sum() > 1000 and (hdr[:, 10] != 2).sum() > 200, "voiced and unvoiced frames"
+        bad = np.nonzero((got[:, :380] != want[:, :380]).any(1))[0]
+        if bad.size:
+            k = bad[0]
+            cols = np.nonzero(got[k, :380] != want[k, :380])[0]
+            raise AssertionError((bad.size, bad[:8], "warping", hdr[k, 6], "signalType", hdr[k, 10], "first differing bytes", cols[:12]))
+        del c
