@@ -3,6 +3,7 @@
 // autocorrelation) of each of the wavefront's 64 frames lives in LDS laid out [sample][lane].
 #include <string.h>
 #include "silk_shape_dev.h"
+#include "silk_prefilter_dev.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
 #include "silk_validate.h"
@@ -53,9 +54,72 @@ __global__ __launch_bounds__(64) void silk_noise_shape_kernel(const opusgpu_nois
     out.status = OPUSGPU_OK;
 }
 
+struct OutCol32 {                                              // xw_Q3 straight into the output record
+    i32 *p;
+    __device__ __forceinline__ i32 &operator[](int k) const { return p[k]; }
+};
+
+__global__ __launch_bounds__(64) void silk_prefilter_kernel(const opusgpu_prefilter_in *__restrict__ recs, opusgpu_prefilter_state *__restrict__ states,
+                                                            opusgpu_prefilter_out *__restrict__ outs, int n_rec, int *__restrict__ bad_records)
+{
+    __shared__ i16 ltp_s[LTP_BUF_LENGTH * 64];                 // the 64 harmonic-shaping ring buffers, [slot][lane]
+    const int r = blockIdx.x * 64 + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_prefilter_in &in = recs[r];
+    opusgpu_prefilter_state &st = states[r];
+    opusgpu_prefilter_out &out = outs[r];
+    if (!prefilter_record_ok(in, st)) {
+        for (int k = 0; k < OPUSGPU_SILK_MAX_FRAME; k++) out.xw_Q3[k] = 0;
+        out.status = OPUSGPU_BAD_ARG;
+        atomicAdd(bad_records, 1);
+        return;
+    }
+    ShapeCol ltp;
+    ltp.p = ltp_s + threadIdx.x;
+    for (int k = 0; k < LTP_BUF_LENGTH; k += 2) {
+        const int w = *reinterpret_cast<const int *>(&st.sLTP_shp[k]);
+        ltp[k] = (i16)w;
+        ltp[k + 1] = (i16)(w >> 16);
+    }
+    PrefilterState P;
+    for (int k = 0; k <= MAX_SHAPE_LPC_ORDER; k++) P.sAR_shp[k] = st.sAR_shp[k];
+    P.sLTP_shp_buf_idx = st.sLTP_shp_buf_idx; P.sLF_AR_shp_Q12 = st.sLF_AR_shp_Q12; P.sLF_MA_shp_Q12 = st.sLF_MA_shp_Q12;
+    P.sHarmHP_Q2 = st.sHarmHP_Q2; P.rand_seed = st.rand_seed; P.lagPrev = st.lagPrev;
+    PrefilterCtrl c;
+    for (int k = 0; k < 4; k++) {
+        c.pitchL[k] = in.pitchL[k]; c.HarmShapeGain_Q14[k] = in.HarmShapeGain_Q14[k]; c.HarmBoost_Q14[k] = in.HarmBoost_Q14[k];
+        c.Tilt_Q14[k] = in.Tilt_Q14[k]; c.GainsPre_Q14[k] = in.GainsPre_Q14[k]; c.LF_shp_Q14[k] = in.LF_shp_Q14[k];
+    }
+    for (int k = 0; k < 4 * MAX_SHAPE_LPC_ORDER; k++) c.AR1_Q13[k] = in.AR1_Q13[k];
+    c.coding_quality_Q14 = in.coding_quality_Q14; c.nb_subfr = in.nb_subfr; c.subfr_length = in.subfr_length; c.signalType = in.signalType;
+    c.warping_Q16 = in.warping_Q16; c.shapingLPCOrder = in.shapingLPCOrder;
+    OutCol32 xw;
+    xw.p = out.xw_Q3;
+    silk_prefilter_dev(P, c, (const i16 *)in.x, xw, ltp);
+    for (int k = in.nb_subfr * in.subfr_length; k < OPUSGPU_SILK_MAX_FRAME; k++) out.xw_Q3[k] = 0;
+    for (int k = 0; k < LTP_BUF_LENGTH; k += 2)
+        *reinterpret_cast<int *>(&st.sLTP_shp[k]) = (int)((u32)(u16)ltp[k] | ((u32)(u16)ltp[k + 1] << 16));
+    for (int k = 0; k <= MAX_SHAPE_LPC_ORDER; k++) st.sAR_shp[k] = P.sAR_shp[k];
+    st.sLTP_shp_buf_idx = P.sLTP_shp_buf_idx; st.sLF_AR_shp_Q12 = P.sLF_AR_shp_Q12; st.sLF_MA_shp_Q12 = P.sLF_MA_shp_Q12;
+    st.sHarmHP_Q2 = P.sHarmHP_Q2; st.lagPrev = P.lagPrev;
+    out.status = OPUSGPU_OK;
+}
+
 }  // namespace ca
 
 using namespace ca;
+
+extern "C" int opusgpu_silk_prefilter_batch(const opusgpu_prefilter_in *d_in, opusgpu_prefilter_state *d_state, opusgpu_prefilter_out *d_out, int n,
+                                            void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_state || !d_out) return OPUSGPU_BAD_ARG;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_prefilter_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out, n, bad);
+    return opusgpu_check_launch();
+}
 
 extern "C" int opusgpu_silk_noise_shape_analysis_batch(const opusgpu_noise_shape_in *d_in, opusgpu_noise_shape_out *d_out, int n, void *stream)
 {

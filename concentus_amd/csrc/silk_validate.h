@@ -90,6 +90,17 @@ __device__ __forceinline__ bool noise_shape_record_ok(const opusgpu_noise_shape_
     return true;
 }
 
+__device__ __forceinline__ bool prefilter_record_ok(const opusgpu_prefilter_in &in, const opusgpu_prefilter_state &st)
+{
+    const int n = in.nb_subfr, L = in.subfr_length, D = in.shapingLPCOrder;
+    if (!((n == 2 || n == 4) && L >= 1 && L <= 80 && n * L <= OPUSGPU_SILK_MAX_FRAME && D >= 2 && D <= 16 && !(D & 1))) return false;
+    if ((unsigned)in.signalType > 2u || in.warping_Q16 < 0 || in.warping_Q16 > 32767) return false;
+    if ((unsigned)st.sLTP_shp_buf_idx > 511u || st.lagPrev < 0 || st.lagPrev > 508) return false;      // ring-buffer taps stay distinct from the write slot
+    for (int k = 0; k < n; k++)
+        if (in.pitchL[k] < 0 || in.pitchL[k] > 508) return false;
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -282,3 +282,43 @@ def silk_noise_shape_analysis(shape_in, shape_out=None):
     (opusgpu_noise_shape_out)."""
     return _record_op("opusgpu_silk_noise_shape_analysis_batch", shape_in, shape_out, SIZES["noise_shape_in"], SIZES["noise_shape_out"],
                       "shape")
+
+
+class PrefilterState(C.Structure):
+    """opusgpu_prefilter_state == silk_prefilter_state_FIX (opus-fix/silk/fixed/structs_FIX.h:53-62)."""
+    _fields_ = [("sLTP_shp", C.c_int16 * 512), ("sAR_shp", C.c_int32 * 17), ("sLTP_shp_buf_idx", C.c_int32), ("sLF_AR_shp_Q12", C.c_int32),
+                ("sLF_MA_shp_Q12", C.c_int32), ("sHarmHP_Q2", C.c_int32), ("rand_seed", C.c_int32), ("lagPrev", C.c_int32)]
+
+
+class PrefilterIn(C.Structure):
+    """opusgpu_prefilter_in: one silk_prefilter_FIX() call (opus-fix/silk/fixed/prefilter_FIX.c:102)."""
+    _fields_ = [("x", C.c_int16 * 320), ("AR1_Q13", C.c_int16 * 64), ("pitchL", C.c_int32 * 4), ("HarmShapeGain_Q14", C.c_int32 * 4),
+                ("HarmBoost_Q14", C.c_int32 * 4), ("Tilt_Q14", C.c_int32 * 4), ("GainsPre_Q14", C.c_int32 * 4), ("LF_shp_Q14", C.c_int32 * 4),
+                ("coding_quality_Q14", C.c_int32), ("nb_subfr", C.c_int32), ("subfr_length", C.c_int32), ("signalType", C.c_int32),
+                ("warping_Q16", C.c_int32), ("shapingLPCOrder", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class PrefilterOut(C.Structure):
+    _fields_ = [("xw_Q3", C.c_int32 * 320), ("status", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+SIZES["prefilter_in"] = C.sizeof(PrefilterIn)
+SIZES["prefilter_state"] = C.sizeof(PrefilterState)
+SIZES["prefilter_out"] = C.sizeof(PrefilterOut)
+
+
+def silk_prefilter(pf_in, pf_state, pf_out=None):
+    """silk_prefilter_FIX() over a batch of records: pf_in uint8 [N][896], pf_state uint8 [N][1116] (silk_prefilter_state_FIX, updated
+    in place) -> uint8 [N][1296] (xw_Q3 int32[320], status)."""
+    import torch
+    _check(pf_in, SIZES["prefilter_in"], "prefilter_in")
+    _check(pf_state, SIZES["prefilter_state"], "prefilter_state")
+    n = pf_in.shape[0]
+    if pf_state.shape[0] != n:
+        raise ValueError("prefilter_state: %d records for %d inputs" % (pf_state.shape[0], n))
+    if pf_out is None:
+        pf_out = torch.empty((n, SIZES["prefilter_out"]), dtype=torch.uint8, device=pf_in.device)
+    _check(pf_out, SIZES["prefilter_out"], "prefilter_out")
+    rc = _lib.load().opusgpu_silk_prefilter_batch(pf_in.data_ptr(), pf_state.data_ptr(), pf_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_prefilter_batch")
+    return pf_out

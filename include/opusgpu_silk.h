@@ -284,6 +284,36 @@ typedef struct opusgpu_noise_shape_out {
 
 int opusgpu_silk_noise_shape_analysis_batch(const opusgpu_noise_shape_in *d_in, opusgpu_noise_shape_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_prefilter_FIX, batched (sixth slice) ----------------------------------------------------------
+ * Replaces silk_prefilter_FIX(psEnc, psEncCtrl, xw_Q3, x) (opus-fix/silk/fixed/prefilter_FIX.c:102-184, called from
+ * silk_encode_frame_FIX right before the noise-shaping quantiser): warped short-term analysis filter, harmonic high-pass,
+ * tilt / low-frequency / harmonic shaping. The state record has the layout of silk_prefilter_state_FIX (structs_FIX.h:53-62)
+ * and is updated in place; the output is xw_Q3[frame_length], the x_Q3 argument of silk_NSQ / silk_NSQ_del_dec. */
+typedef struct opusgpu_prefilter_state {
+    int16_t sLTP_shp[512];
+    int32_t sAR_shp[17];
+    int32_t sLTP_shp_buf_idx;
+    int32_t sLF_AR_shp_Q12, sLF_MA_shp_Q12, sHarmHP_Q2, rand_seed;
+    int32_t lagPrev;
+} opusgpu_prefilter_state;
+
+typedef struct opusgpu_prefilter_in {
+    int16_t x[OPUSGPU_SILK_MAX_FRAME];
+    int16_t AR1_Q13[4 * 16];                 /* psEncCtrl->AR1_Q13 */
+    int32_t pitchL[4], HarmShapeGain_Q14[4], HarmBoost_Q14[4], Tilt_Q14[4], GainsPre_Q14[4], LF_shp_Q14[4];
+    int32_t coding_quality_Q14, nb_subfr, subfr_length, signalType;
+    int32_t warping_Q16, shapingLPCOrder, reserved[2];
+} opusgpu_prefilter_in;
+
+typedef struct opusgpu_prefilter_out {
+    int32_t xw_Q3[OPUSGPU_SILK_MAX_FRAME];
+    int32_t status;
+    int32_t reserved[3];
+} opusgpu_prefilter_out;
+
+int opusgpu_silk_prefilter_batch(const opusgpu_prefilter_in *d_in, opusgpu_prefilter_state *d_state, opusgpu_prefilter_out *d_out, int n,
+                                 void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

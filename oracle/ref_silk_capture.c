@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -417,5 +417,54 @@ void __wrap_silk_noise_shape_analysis_FIX(silk_encoder_state_FIX *psEnc, silk_en
         o->input_quality_Q14 = psEncCtrl->input_quality_Q14; o->coding_quality_Q14 = psEncCtrl->coding_quality_Q14;
         o->sparseness_Q8 = psEncCtrl->sparseness_Q8; o->quantOffsetType = c->indices.quantOffsetType; o->status = 0;
         g_ns++;
+    }
+}
+
+/* ---- silk_prefilter_FIX (opus-fix/silk/fixed/prefilter_FIX.c:102): arguments + the fields read, psEnc->sPrefilt before / after -> xw_Q3 ---- */
+static opusgpu_prefilter_in *g_xin; static opusgpu_prefilter_state *g_xst0, *g_xst1; static opusgpu_prefilter_out *g_xout; static int g_nx, g_capx;
+void refcap_start_prefilter(int max_records)
+{
+    g_capx = max_records; g_nx = 0; g_on = 1;
+    g_xin = (opusgpu_prefilter_in *)calloc(max_records, sizeof(*g_xin));
+    g_xst0 = (opusgpu_prefilter_state *)calloc(max_records, sizeof(*g_xst0));
+    g_xst1 = (opusgpu_prefilter_state *)calloc(max_records, sizeof(*g_xst1));
+    g_xout = (opusgpu_prefilter_out *)calloc(max_records, sizeof(*g_xout));
+}
+int refcap_count_prefilter(void) { return g_nx; }
+int refcap_sizes_prefilter(int which)
+{
+    return which == 0 ? sizeof(opusgpu_prefilter_in) : which == 1 ? sizeof(opusgpu_prefilter_state) : which == 2 ? sizeof(opusgpu_prefilter_out)
+         : (int)sizeof(silk_prefilter_state_FIX);
+}
+void refcap_get_prefilter(void *xin, void *st0, void *st1, void *xout)
+{
+    memcpy(xin, g_xin, (size_t)g_nx * sizeof(*g_xin)); memcpy(st0, g_xst0, (size_t)g_nx * sizeof(*g_xst0));
+    memcpy(st1, g_xst1, (size_t)g_nx * sizeof(*g_xst1)); memcpy(xout, g_xout, (size_t)g_nx * sizeof(*g_xout));
+}
+
+void __real_silk_prefilter_FIX(silk_encoder_state_FIX *psEnc, const silk_encoder_control_FIX *psEncCtrl, opus_int32 xw_Q3[], const opus_int16 x[]);
+void __wrap_silk_prefilter_FIX(silk_encoder_state_FIX *psEnc, const silk_encoder_control_FIX *psEncCtrl, opus_int32 xw_Q3[], const opus_int16 x[])
+{
+    typedef char prefilter_state_layout[sizeof(opusgpu_prefilter_state) == sizeof(silk_prefilter_state_FIX) ? 1 : -1];
+    const silk_encoder_state *c = &psEnc->sCmn;
+    int rec = (g_on && g_xin && g_nx < g_capx && c->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nx : -1;
+    if (rec >= 0) {
+        opusgpu_prefilter_in *r = &g_xin[rec];
+        memcpy(r->x, x, sizeof(opus_int16) * c->frame_length);
+        memcpy(r->AR1_Q13, psEncCtrl->AR1_Q13, sizeof(r->AR1_Q13));
+        for (int k = 0; k < MAX_NB_SUBFR; k++) {
+            r->pitchL[k] = psEncCtrl->pitchL[k]; r->HarmShapeGain_Q14[k] = psEncCtrl->HarmShapeGain_Q14[k]; r->HarmBoost_Q14[k] = psEncCtrl->HarmBoost_Q14[k];
+            r->Tilt_Q14[k] = psEncCtrl->Tilt_Q14[k]; r->GainsPre_Q14[k] = psEncCtrl->GainsPre_Q14[k]; r->LF_shp_Q14[k] = psEncCtrl->LF_shp_Q14[k];
+        }
+        r->coding_quality_Q14 = psEncCtrl->coding_quality_Q14; r->nb_subfr = c->nb_subfr; r->subfr_length = c->subfr_length;
+        r->signalType = c->indices.signalType; r->warping_Q16 = c->warping_Q16; r->shapingLPCOrder = c->shapingLPCOrder;
+        memcpy(&g_xst0[rec], &psEnc->sPrefilt, sizeof(g_xst0[rec]));
+    }
+    __real_silk_prefilter_FIX(psEnc, psEncCtrl, xw_Q3, x);
+    if (rec >= 0) {
+        memcpy(&g_xst1[rec], &psEnc->sPrefilt, sizeof(g_xst1[rec]));
+        memcpy(g_xout[rec].xw_Q3, xw_Q3, sizeof(opus_int32) * c->frame_length);
+        g_xout[rec].status = 0;
+        g_nx++;
     }
 }

@@ -291,3 +291,29 @@ extern "C" void emu_silk_noise_shape_analysis(const opusgpu_noise_shape_in *in, 
         shape_out_to_record(o, in[r].nb_subfr, out[r]);
     }
 }
+
+// ---- silk_prefilter_FIX, host build of concentus_amd/csrc/silk_prefilter_dev.h ----
+#include "../../concentus_amd/csrc/silk_prefilter_dev.h"
+extern "C" void emu_silk_prefilter(const opusgpu_prefilter_in *in, opusgpu_prefilter_state *st, opusgpu_prefilter_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        const opusgpu_prefilter_in &i = in[r];
+        ca::PrefilterState P;
+        for (int k = 0; k <= 16; k++) P.sAR_shp[k] = st[r].sAR_shp[k];
+        P.sLTP_shp_buf_idx = st[r].sLTP_shp_buf_idx; P.sLF_AR_shp_Q12 = st[r].sLF_AR_shp_Q12; P.sLF_MA_shp_Q12 = st[r].sLF_MA_shp_Q12;
+        P.sHarmHP_Q2 = st[r].sHarmHP_Q2; P.rand_seed = st[r].rand_seed; P.lagPrev = st[r].lagPrev;
+        ca::PrefilterCtrl c;
+        for (int k = 0; k < 4; k++) {
+            c.pitchL[k] = i.pitchL[k]; c.HarmShapeGain_Q14[k] = i.HarmShapeGain_Q14[k]; c.HarmBoost_Q14[k] = i.HarmBoost_Q14[k];
+            c.Tilt_Q14[k] = i.Tilt_Q14[k]; c.GainsPre_Q14[k] = i.GainsPre_Q14[k]; c.LF_shp_Q14[k] = i.LF_shp_Q14[k];
+        }
+        for (int k = 0; k < 64; k++) c.AR1_Q13[k] = i.AR1_Q13[k];
+        c.coding_quality_Q14 = i.coding_quality_Q14; c.nb_subfr = i.nb_subfr; c.subfr_length = i.subfr_length; c.signalType = i.signalType;
+        c.warping_Q16 = i.warping_Q16; c.shapingLPCOrder = i.shapingLPCOrder;
+        memset(&out[r], 0, sizeof(out[r]));
+        ca::silk_prefilter_dev(P, c, (const int16_t *)i.x, (int32_t *)out[r].xw_Q3, (int16_t *)st[r].sLTP_shp);
+        for (int k = 0; k <= 16; k++) st[r].sAR_shp[k] = P.sAR_shp[k];
+        st[r].sLTP_shp_buf_idx = P.sLTP_shp_buf_idx; st[r].sLF_AR_shp_Q12 = P.sLF_AR_shp_Q12; st[r].sLF_MA_shp_Q12 = P.sLF_MA_shp_Q12;
+        st[r].sHarmHP_Q2 = P.sHarmHP_Q2; st[r].lagPrev = P.lagPrev;
+    }
+}

@@ -411,3 +411,34 @@ def test_noise_shape_analysis_32768_distinct_records_vs_reference_outputs(ca):
     assert ca.silk.bad_records() == 2
     good = np.setdiff1d(np.arange(256), [6, 12])
     assert np.array_equal(o2[good, :380], want[:256][good, :380]) and (o2[[6, 12], 380:384].view(np.int32) == -1).all()
+
+
+def test_prefilter_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_prefilter_FIX on the GPU against what the unmodified reference produced when the records were captured
+    (tests/silk_corpus.py kind "prefilter"): xw_Q3 and every byte of silk_prefilter_state_FIX after the call."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "prefilter")
+    st = _dev(rec["prefilter_state_in"])
+    out = ca.silk_prefilter(_dev(rec["prefilter_in"]), st)
+    torch.cuda.synchronize()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    want, want_st = np.asarray(rec["prefilter_out"]), np.asarray(rec["prefilter_state_out"])
+    assert (out[:, 1280:1284].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :1280] != want[:, :1280]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8])
+    bad = np.nonzero((st != want_st).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], np.nonzero(st[bad[0]] != want_st[bad[0]])[0][:12])
+    ca.silk.bad_records()
+    xin = np.array(rec["prefilter_in"][:256])
+    xin[5, 864 + 20:864 + 24].view(np.int32)[0] = 40              # shapingLPCOrder
+    st2 = np.array(rec["prefilter_state_in"][:256])
+    st2[9, 1092:1096].view(np.int32)[0] = 4000                   # sLTP_shp_buf_idx
+    d_st2 = _dev(st2)
+    o2 = ca.silk_prefilter(_dev(xin), d_st2).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [5, 9])
+    assert np.array_equal(o2[good, :1280], want[:256][good, :1280]) and (o2[[5, 9], 1280:1284].view(np.int32) == -1).all()
+    assert np.array_equal(d_st2.cpu().numpy()[[5, 9]], st2[[5, 9]]), "the state of a skipped record is left as it was"

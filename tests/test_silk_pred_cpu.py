@@ -83,3 +83,27 @@ def test_noise_shape_analysis_sources_match_the_reference_on_fresh_records():
             cols = np.nonzero(got[k, :380] != want[k, :380])[0]
             raise AssertionError((bad.size, bad[:8], "warping", hdr[k, 6], "signalType", hdr[k, 10], "first differing bytes", cols[:12]))
         del c
+
+
+@pytest.mark.ref
+def test_prefilter_sources_match_the_reference_on_fresh_records():
+    """silk_prefilter_FIX (sixth slice; concentus_amd/csrc/silk_prefilter_dev.h): xw_Q3 (the quantiser's input) and
+    every byte of silk_prefilter_state_FIX after the call, from the state captured before it."""
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    emu = emulib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4 * silk_corpus.SEG_FRAMES, "prefilter", cache=tmp, workers=4)
+        xin = np.ascontiguousarray(c["prefilter_in"])
+        st = np.array(c["prefilter_state_in"])
+        want, want_st = np.asarray(c["prefilter_out"]), np.asarray(c["prefilter_state_out"])
+        n = xin.shape[0]
+        got = np.zeros((n, silk_corpus.SIZES["prefilter_out"]), np.uint8)
+        emu.emu_silk_prefilter(xin.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_long(n))
+        hdr = xin[:, 864:896].view(np.int32)
+        assert (hdr[:, 3] == 2).sum() > 1000 and (hdr[:, 3] != 2).sum() > 200 and (hdr[:, 4] == 0).sum() > 500 and (hdr[:, 4] > 0).sum() > 500
+        bad = np.nonzero((got[:, :1280] != want[:, :1280]).any(1))[0]
+        assert bad.size == 0, (bad.size, bad[:8], got[bad[:1], :32].view(np.int32), want[bad[:1], :32].view(np.int32))
+        bad = np.nonzero((st != want_st).any(1))[0]
+        assert bad.size == 0, (bad.size, bad[:8], np.nonzero(st[bad[0]] != want_st[bad[0]])[0][:12])
+        del c
