@@ -101,6 +101,16 @@ __device__ __forceinline__ bool prefilter_record_ok(const opusgpu_prefilter_in &
     return true;
 }
 
+__device__ __forceinline__ bool find_pitch_lags_record_ok(const opusgpu_find_pitch_lags_in &in)
+{
+    const int fs = in.fs_kHz, n = in.nb_subfr, D = in.pitchEstimationLPCOrder, W = in.pitch_LPC_win_length, la = in.la_pitch;
+    if (!((fs == 8 || fs == 16) && (n == 2 || n == 4) && in.frame_length == n * 5 * fs && in.ltp_mem_length == 20 * fs && la == 2 * fs)) return false;
+    if (!(D >= 6 && D <= 16 && !(D & 1) && W >= 2 * la + D && W <= la + in.frame_length + in.ltp_mem_length && W <= 384)) return false;
+    if ((unsigned)in.pitchEstimationComplexity > 2u || (unsigned)in.signalType > 2u || (unsigned)in.prevSignalType > 2u) return false;
+    if ((unsigned)in.pitchEstimationThreshold_Q16 > 65536u || (unsigned)in.speech_activity_Q8 > 256u || in.prevLag < 0 || in.prevLag > 18 * fs) return false;
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

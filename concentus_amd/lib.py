@@ -46,6 +46,7 @@ SYMBOLS = [
     ("opusgpu_silk_process_gains_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_noise_shape_analysis_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_prefilter_batch", _i, [_vp, _vp, _vp, _i, _vp]),
+    ("opusgpu_silk_find_pitch_lags_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_residual_energy_FIX", None, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_celt_dec_state_size", _i, []),
     ("opusgpu_celt_dec_state_init", _i, [_vp, _i, _vp]),

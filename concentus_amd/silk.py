@@ -322,3 +322,28 @@ def silk_prefilter(pf_in, pf_state, pf_out=None):
     rc = _lib.load().opusgpu_silk_prefilter_batch(pf_in.data_ptr(), pf_state.data_ptr(), pf_out.data_ptr(), n, _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_prefilter_batch")
     return pf_out
+
+
+class FindPitchLagsIn(C.Structure):
+    """opusgpu_find_pitch_lags_in: one silk_find_pitch_lags_FIX() call (opus-fix/silk/fixed/find_pitch_lags_FIX.c:37)."""
+    _fields_ = [("x_buf", C.c_int16 * 672)] + [(k, C.c_int32) for k in (
+        "fs_kHz", "nb_subfr", "frame_length", "ltp_mem_length", "la_pitch", "pitch_LPC_win_length", "pitchEstimationLPCOrder",
+        "pitchEstimationComplexity", "pitchEstimationThreshold_Q16", "signalType", "first_frame_after_reset", "speech_activity_Q8",
+        "prevSignalType", "input_tilt_Q15", "prevLag", "LTPCorr_Q15")]
+
+
+class FindPitchLagsOut(C.Structure):
+    _fields_ = [("res", C.c_int16 * 672), ("pitchL", C.c_int32 * 4), ("lagIndex", C.c_int32), ("contourIndex", C.c_int32),
+                ("LTPCorr_Q15", C.c_int32), ("signalType", C.c_int32), ("predGain_Q16", C.c_int32), ("status", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+SIZES["find_pitch_lags_in"] = C.sizeof(FindPitchLagsIn)
+SIZES["find_pitch_lags_out"] = C.sizeof(FindPitchLagsOut)
+
+
+def silk_find_pitch_lags(pitch_in, pitch_out=None):
+    """silk_find_pitch_lags_FIX() over a batch of records: pitch_in uint8 [N][1408] (opusgpu_find_pitch_lags_in) -> uint8 [N][1392]
+    (res int16[672], pitchL, lagIndex, contourIndex, LTPCorr_Q15, signalType, predGain_Q16, status)."""
+    return _record_op("opusgpu_silk_find_pitch_lags_batch", pitch_in, pitch_out, SIZES["find_pitch_lags_in"], SIZES["find_pitch_lags_out"],
+                      "pitch")

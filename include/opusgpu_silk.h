@@ -314,6 +314,30 @@ typedef struct opusgpu_prefilter_out {
 int opusgpu_silk_prefilter_batch(const opusgpu_prefilter_in *d_in, opusgpu_prefilter_state *d_state, opusgpu_prefilter_out *d_out, int n,
                                  void *hip_stream);
 
+/* ---- silk_find_pitch_lags_FIX, batched (seventh slice) --------------------------------------------------
+ * Replaces silk_find_pitch_lags_FIX(psEnc, psEncCtrl, res, x, arch) (opus-fix/silk/fixed/find_pitch_lags_FIX.c:37-145, the first
+ * analysis call of silk_encode_frame_FIX) including silk_pitch_analysis_core (silk/fixed/pitch_analysis_core_FIX.c:86-581):
+ * windowed autocorrelation, Schur recursion, LPC whitening of the whole pitch buffer (res[], which the later analysis calls
+ * read), the three-stage pitch search at 4 / 8 / input kHz and the voicing decision. 8 and 16 kHz (fs_kHz 12 -> BAD_ARG). */
+#define OPUSGPU_SILK_MAX_LA_PITCH 32             /* LA_PITCH_MS * MAX_FS_KHZ */
+#define OPUSGPU_SILK_PITCH_BUF (OPUSGPU_SILK_MAX_LA_PITCH + OPUSGPU_SILK_MAX_FRAME + OPUSGPU_SILK_MAX_LTP_MEM)
+typedef struct opusgpu_find_pitch_lags_in {
+    int16_t x_buf[OPUSGPU_SILK_PITCH_BUF];   /* x[-ltp_mem_length .. frame_length + la_pitch) */
+    int32_t fs_kHz, nb_subfr, frame_length, ltp_mem_length;
+    int32_t la_pitch, pitch_LPC_win_length, pitchEstimationLPCOrder, pitchEstimationComplexity;
+    int32_t pitchEstimationThreshold_Q16, signalType, first_frame_after_reset, speech_activity_Q8;
+    int32_t prevSignalType, input_tilt_Q15, prevLag, LTPCorr_Q15;   /* LTPCorr_Q15: psEnc->LTPCorr_Q15 of the previous frame */
+} opusgpu_find_pitch_lags_in;
+
+typedef struct opusgpu_find_pitch_lags_out {
+    int16_t res[OPUSGPU_SILK_PITCH_BUF];     /* the whitened buffer (res_pitch) */
+    int32_t pitchL[4];
+    int32_t lagIndex, contourIndex, LTPCorr_Q15, signalType;
+    int32_t predGain_Q16, status, reserved[2];
+} opusgpu_find_pitch_lags_out;
+
+int opusgpu_silk_find_pitch_lags_batch(const opusgpu_find_pitch_lags_in *d_in, opusgpu_find_pitch_lags_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

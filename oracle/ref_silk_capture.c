@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -466,5 +466,47 @@ void __wrap_silk_prefilter_FIX(silk_encoder_state_FIX *psEnc, const silk_encoder
         memcpy(g_xout[rec].xw_Q3, xw_Q3, sizeof(opus_int32) * c->frame_length);
         g_xout[rec].status = 0;
         g_nx++;
+    }
+}
+
+/* ---- silk_find_pitch_lags_FIX (opus-fix/silk/fixed/find_pitch_lags_FIX.c:37): arguments + the psEnc fields it reads -> res[], pitch lags,
+ * indices, voicing, LTPCorr_Q15, predGain_Q16 ---- */
+static opusgpu_find_pitch_lags_in *g_tin; static opusgpu_find_pitch_lags_out *g_tout; static int g_nt, g_capt;
+void refcap_start_pitch(int max_records)
+{
+    g_capt = max_records; g_nt = 0; g_on = 1;
+    g_tin = (opusgpu_find_pitch_lags_in *)calloc(max_records, sizeof(*g_tin));
+    g_tout = (opusgpu_find_pitch_lags_out *)calloc(max_records, sizeof(*g_tout));
+}
+int refcap_count_pitch(void) { return g_nt; }
+int refcap_sizes_pitch(int which) { return which == 0 ? sizeof(opusgpu_find_pitch_lags_in) : sizeof(opusgpu_find_pitch_lags_out); }
+void refcap_get_pitch(void *tin, void *tout)
+{
+    memcpy(tin, g_tin, (size_t)g_nt * sizeof(*g_tin)); memcpy(tout, g_tout, (size_t)g_nt * sizeof(*g_tout));
+}
+
+void __real_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, opus_int16 res[], const opus_int16 x[], int arch);
+void __wrap_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_control_FIX *psEncCtrl, opus_int16 res[], const opus_int16 x[], int arch)
+{
+    const silk_encoder_state *c = &psEnc->sCmn;
+    const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length;
+    int rec = (g_on && g_tin && g_nt < g_capt && buf_len <= OPUSGPU_SILK_PITCH_BUF) ? g_nt : -1;
+    if (rec >= 0) {
+        opusgpu_find_pitch_lags_in *r = &g_tin[rec];
+        memcpy(r->x_buf, x - c->ltp_mem_length, sizeof(opus_int16) * buf_len);
+        r->fs_kHz = c->fs_kHz; r->nb_subfr = c->nb_subfr; r->frame_length = c->frame_length; r->ltp_mem_length = c->ltp_mem_length;
+        r->la_pitch = c->la_pitch; r->pitch_LPC_win_length = c->pitch_LPC_win_length; r->pitchEstimationLPCOrder = c->pitchEstimationLPCOrder;
+        r->pitchEstimationComplexity = c->pitchEstimationComplexity; r->pitchEstimationThreshold_Q16 = c->pitchEstimationThreshold_Q16;
+        r->signalType = c->indices.signalType; r->first_frame_after_reset = c->first_frame_after_reset; r->speech_activity_Q8 = c->speech_activity_Q8;
+        r->prevSignalType = c->prevSignalType; r->input_tilt_Q15 = c->input_tilt_Q15; r->prevLag = c->prevLag; r->LTPCorr_Q15 = psEnc->LTPCorr_Q15;
+    }
+    __real_silk_find_pitch_lags_FIX(psEnc, psEncCtrl, res, x, arch);
+    if (rec >= 0) {
+        opusgpu_find_pitch_lags_out *o = &g_tout[rec];
+        memcpy(o->res, res, sizeof(opus_int16) * buf_len);
+        for (int k = 0; k < c->nb_subfr; k++) o->pitchL[k] = psEncCtrl->pitchL[k];
+        o->lagIndex = c->indices.lagIndex; o->contourIndex = c->indices.contourIndex; o->LTPCorr_Q15 = psEnc->LTPCorr_Q15;
+        o->signalType = c->indices.signalType; o->predGain_Q16 = psEncCtrl->predGain_Q16; o->status = 0;
+        g_nt++;
     }
 }

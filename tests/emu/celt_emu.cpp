@@ -317,3 +317,26 @@ extern "C" void emu_silk_prefilter(const opusgpu_prefilter_in *in, opusgpu_prefi
         st[r].sHarmHP_Q2 = P.sHarmHP_Q2; st[r].lagPrev = P.lagPrev;
     }
 }
+
+// ---- silk_find_pitch_lags_FIX, host build of concentus_amd/csrc/silk_pitch_dev.h ----
+#include "../../concentus_amd/csrc/silk_pitch_dev.h"
+extern "C" void emu_silk_find_pitch_lags(const opusgpu_find_pitch_lags_in *in, opusgpu_find_pitch_lags_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        const opusgpu_find_pitch_lags_in &i = in[r];
+        ca::PitchCfg c;
+        c.fs_kHz = i.fs_kHz; c.nb_subfr = i.nb_subfr; c.frame_length = i.frame_length; c.ltp_mem_length = i.ltp_mem_length; c.la_pitch = i.la_pitch;
+        c.pitch_LPC_win_length = i.pitch_LPC_win_length; c.pitchEstimationLPCOrder = i.pitchEstimationLPCOrder;
+        c.pitchEstimationComplexity = i.pitchEstimationComplexity; c.pitchEstimationThreshold_Q16 = i.pitchEstimationThreshold_Q16;
+        c.signalType = i.signalType; c.first_frame_after_reset = i.first_frame_after_reset; c.speech_activity_Q8 = i.speech_activity_Q8;
+        c.prevSignalType = i.prevSignalType; c.input_tilt_Q15 = i.input_tilt_Q15; c.prevLag = i.prevLag; c.LTPCorr_Q15 = i.LTPCorr_Q15;
+        ca::PitchOut o;
+        memset(&o, 0, sizeof(o));
+        memset(&out[r], 0, sizeof(out[r]));
+        int16_t ws[384], xs[384], scr[640];
+        ca::silk_find_pitch_lags_dev(c, (const int16_t *)i.x_buf, (int16_t *)out[r].res, (int16_t *)ws, (int16_t *)xs, (int16_t *)scr, o);
+        for (int k = 0; k < i.nb_subfr; k++) out[r].pitchL[k] = o.pitchL[k];
+        out[r].lagIndex = o.lagIndex; out[r].contourIndex = o.contourIndex; out[r].LTPCorr_Q15 = o.LTPCorr_Q15; out[r].signalType = o.signalType;
+        out[r].predGain_Q16 = o.predGain_Q16;
+    }
+}

@@ -29,7 +29,8 @@ WARMUP = 8                  # leading frames of a segment whose records are drop
 SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq_out": 320, "dd_in": 1648, "dd_out": 324,
          "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40,
          "fpc_in": 2688, "fpc_out": 208, "gains_in": 112, "gains_out": 56,
-         "shape_in": 1696, "shape_out": 384, "prefilter_in": 896, "prefilter_state": 1116, "prefilter_out": 1296}
+         "shape_in": 1696, "shape_out": 384, "prefilter_in": 896, "prefilter_state": 1116, "prefilter_out": 1296,
+         "pitch_in": 1408, "pitch_out": 1392}
 
 
 def available():
@@ -115,6 +116,8 @@ def _capture_segment(args):
         lib.refcap_start_shape(cap)
     elif kind == "prefilter":
         lib.refcap_start_prefilter(cap)
+    elif kind == "pitch":
+        lib.refcap_start_pitch(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -127,7 +130,15 @@ def _capture_segment(args):
         fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
         assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
-    if kind == "prefilter":
+    if kind == "pitch":
+        nt = lib.refcap_count_pitch()
+        assert nt >= nfr, (nt, nfr)
+        assert (lib.refcap_sizes_pitch(0), lib.refcap_sizes_pitch(1)) == (SIZES["pitch_in"], SIZES["pitch_out"])
+        bufs = [np.zeros((nt, SIZES["pitch_in"]), np.uint8), np.zeros((nt, SIZES["pitch_out"]), np.uint8)]
+        lib.refcap_get_pitch(*[_p(b) for b in bufs])
+        for name, b in zip(("pitch_in", "pitch_out"), bufs):
+            files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    elif kind == "prefilter":
         nx = lib.refcap_count_prefilter()
         assert nx >= nfr, (nx, nfr)
         assert [lib.refcap_sizes_prefilter(k) for k in range(4)] == [SIZES["prefilter_in"], SIZES["prefilter_state"], SIZES["prefilter_out"],
@@ -210,6 +221,7 @@ _LAYOUT = {
     "fpc": (("fpc_in", "fpc_in"), ("fpc_out", "fpc_out")),
     "gains": (("gains_in", "gains_in"), ("gains_out", "gains_out")),
     "shape": (("shape_in", "shape_in"), ("shape_out", "shape_out")),
+    "pitch": (("pitch_in", "pitch_in"), ("pitch_out", "pitch_out")),
     "prefilter": (("prefilter_in", "prefilter_in"), ("prefilter_state_in", "prefilter_state"), ("prefilter_state_out", "prefilter_state"),
                   ("prefilter_out", "prefilter_out")),
     "pred": (("nlsf_in", "nlsf_in"), ("nlsf_out", "nlsf_out"), ("resnrg_in", "resnrg_in"), ("resnrg_out", "resnrg_out")),
@@ -249,7 +261,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301}[kind], complexities[k % len(complexities)],
                          row, take, n))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

@@ -442,3 +442,31 @@ def test_prefilter_32768_distinct_records_vs_reference_outputs(ca):
     good = np.setdiff1d(np.arange(256), [5, 9])
     assert np.array_equal(o2[good, :1280], want[:256][good, :1280]) and (o2[[5, 9], 1280:1284].view(np.int32) == -1).all()
     assert np.array_equal(d_st2.cpu().numpy()[[5, 9]], st2[[5, 9]]), "the state of a skipped record is left as it was"
+
+
+def test_find_pitch_lags_32768_distinct_records_vs_reference_outputs(ca):
+    """silk_find_pitch_lags_FIX (with silk_pitch_analysis_core) on the GPU against what the unmodified reference wrote when the
+    records were captured (tests/silk_corpus.py kind "pitch"): the whitened pitch buffer res[], pitchL, lagIndex, contourIndex,
+    LTPCorr_Q15, the voicing decision, predGain_Q16."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(32768, "pitch")
+    out = ca.silk_find_pitch_lags(_dev(rec["pitch_in"]))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    want = np.asarray(rec["pitch_out"])
+    assert (out[:, 1380:1384].view(np.int32) == 0).all()
+    bad = np.nonzero((out[:, :1380] != want[:, :1380]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:8], np.nonzero(out[bad[0], :1380] != want[bad[0], :1380])[0][:12])
+    st = want[:, 1372:1376].view(np.int32)[:, 0]
+    assert (st == 2).sum() > 5000 and (st == 1).sum() > 1000
+    ca.silk.bad_records()
+    tin = np.array(rec["pitch_in"][:256])
+    tin[3, 1344:1348].view(np.int32)[0] = 12                    # fs_kHz: the 12 kHz path is not provided
+    tin[10, 1344 + 24:1344 + 28].view(np.int32)[0] = 40         # pitchEstimationLPCOrder
+    o2 = ca.silk_find_pitch_lags(_dev(tin)).cpu().numpy()
+    assert ca.silk.bad_records() == 2
+    good = np.setdiff1d(np.arange(256), [3, 10])
+    assert np.array_equal(o2[good, :1380], want[:256][good, :1380]) and (o2[[3, 10], 1380:1384].view(np.int32) == -1).all()

@@ -107,3 +107,28 @@ def test_prefilter_sources_match_the_reference_on_fresh_records():
         bad = np.nonzero((st != want_st).any(1))[0]
         assert bad.size == 0, (bad.size, bad[:8], np.nonzero(st[bad[0]] != want_st[bad[0]])[0][:12])
         del c
+
+
+@pytest.mark.ref
+def test_find_pitch_lags_sources_match_the_reference_on_fresh_records():
+    """silk_find_pitch_lags_FIX with silk_pitch_analysis_core (seventh slice; concentus_amd/csrc/silk_pitch_dev.h):
+    the whitened buffer res[], pitchL, lagIndex, contourIndex, LTPCorr_Q15, the voicing decision and predGain_Q16 of every
+    captured call, at pitch-estimation complexities 1 and 2 (encoder complexity 3 / 5 / 8 / 10)."""
+    if not silk_corpus.available():
+        pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
+    emu = emulib.lib()
+    with tempfile.TemporaryDirectory() as tmp:
+        c = silk_corpus.corpus(4 * silk_corpus.SEG_FRAMES, "pitch", cache=tmp, workers=4)
+        tin = np.ascontiguousarray(c["pitch_in"])
+        want = np.asarray(c["pitch_out"])
+        n = tin.shape[0]
+        got = np.zeros((n, silk_corpus.SIZES["pitch_out"]), np.uint8)
+        emu.emu_silk_find_pitch_lags(tin.ctypes.data_as(C.c_void_p), got.ctypes.data_as(C.c_void_p), C.c_long(n))
+        st = want[:, 1344 + 28:1344 + 32].view(np.int32)[:, 0]
+        assert (st == 2).sum() > 1000 and (st == 1).sum() > 200, "voiced and unvoiced decisions"
+        bad = np.nonzero((got[:, :1380] != want[:, :1380]).any(1))[0]
+        if bad.size:
+            k = bad[0]
+            cols = np.nonzero(got[k, :1380] != want[k, :1380])[0]
+            raise AssertionError((bad.size, bad[:8], "first differing bytes", cols[:12], got[k, 1344:1380].view(np.int32), want[k, 1344:1380].view(np.int32)))
+        del c
