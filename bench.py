@@ -15,6 +15,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  silk_analysis   the five analysis calls of silk_encode_frame_FIX between the VAD and the quantiser (silk_find_pitch_lags_FIX,
+                  silk_noise_shape_analysis_FIX, silk_find_pred_coefs_FIX, silk_process_gains_FIX, silk_prefilter_FIX), 65 536
+                  distinct captured records each; value = frames/s through all five.
   silk_pred       silk_find_pred_coefs_FIX whole (LTP analysis + quantisation, silk_find_LPC_FIX, silk_process_NLSFs,
                   silk_residual_energy_FIX) over 65 536 distinct records (voiced and unvoiced frames).
   silk_nlsf       silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX) over 65 536 distinct records
@@ -62,7 +65,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -327,6 +330,41 @@ def cpu_baseline_silk_nlsf(nin, ein):
     return {"value": round(multi, 1), "unit": "records/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
             "sample": "%d (silk_process_NLSFs + silk_residual_energy_FIX) record pairs per pass through the host build of "
                       "concentus_amd/csrc/silk_nlsf_dev.h, repeated ~8 s on %d thread(s); 1 thread: %.0f records/s" % (n, cores, one)}
+
+
+ANALYSIS_OPS = (   # (corpus kind, input key, output key, bytes compared, emu entry, python op, kernel)
+    ("pitch", "pitch_in", "pitch_out", 1380, "emu_silk_find_pitch_lags", "silk_find_pitch_lags", "silk_find_pitch_lags_kernel"),
+    ("shape", "shape_in", "shape_out", 380, "emu_silk_noise_shape_analysis", "silk_noise_shape_analysis", "silk_noise_shape_kernel"),
+    ("fpc", "fpc_in", "fpc_out", 204, "emu_silk_find_pred_coefs", "silk_find_pred_coefs", "silk_find_pred_coefs_kernel"),
+    ("gains", "gains_in", "gains_out", 52, "emu_silk_process_gains", "silk_process_gains", "silk_process_gains_kernel"),
+    ("prefilter", "prefilter_in", "prefilter_out", 1280, "emu_silk_prefilter", "silk_prefilter", "silk_prefilter_kernel"),
+)
+
+
+def cpu_baseline_silk_analysis(recs):
+    """CPU baseline for the SILK analysis chain: the kernel sources compiled for the host (tests/emu, kind "port"), the five
+    functions one after the other on each chunk, chunks on a thread pool."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulib
+    emu = emulib.lib()
+    cores = host_threads()
+    n = recs["pitch_in"].shape[0]
+    outs = {k: np.zeros((n, recs[ok].shape[1]), np.uint8) for _, _, ok, _, _, k, _ in ANALYSIS_OPS}
+    st = np.array(recs["prefilter_state_in"])
+
+    def work(lo, hi):
+        for kind, ik, ok, _, entry, k, _ in ANALYSIS_OPS:
+            i, o = recs[ik], outs[k]
+            args = [C.c_void_p(i.ctypes.data + lo * i.shape[1])]
+            if kind == "prefilter":
+                args.append(C.c_void_p(st.ctypes.data + lo * st.shape[1]))
+            args += [C.c_void_p(o.ctypes.data + lo * o.shape[1]), C.c_long(hi - lo)]
+            getattr(emu, entry)(*args)
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d frames' worth of records per pass (find_pitch_lags, noise_shape_analysis, find_pred_coefs, process_gains, "
+                      "prefilter) through the host build of the kernel sources, repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s"
+                      % (n, cores, one)}
 
 
 def cpu_baseline_silk_pred(fin):
@@ -684,6 +722,65 @@ def main(argv=None):
             if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
                 raise SystemExit("PARITY FAILURE (silk_find_LPC)")
             parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
+    elif a.workload == "silk_analysis":
+        F = a.frames or 65536
+        steps = a.steps or 5
+        warm = a.warmup if a.warmup is not None else 1
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        if not silk_corpus.available():
+            raise SystemExit("silk_analysis needs oracle/_ref/libopus_ref_silkcap.so (records are captured from the reference encoder)")
+        rec = {}
+        for kind, *_ in ANALYSIS_OPS:
+            rec.update({k: np.array(v) for k, v in silk_corpus.corpus(F, kind, seed=20260401 + 1000003 * rank).items()})
+        d_in = {ik: torch.from_numpy(rec[ik]).to(dev) for _, ik, *_ in ANALYSIS_OPS}
+        d_out = {ok: torch.empty((F, rec[ok].shape[1]), dtype=torch.uint8, device=dev) for _, _, ok, *_ in ANALYSIS_OPS}
+        pf_st0 = torch.from_numpy(rec["prefilter_state_in"]).to(dev)
+        pf_st = pf_st0.clone()
+
+        def run_all(events=None):
+            for j, (kind, ik, ok, _, _, op, _) in enumerate(ANALYSIS_OPS):
+                if events is not None:
+                    events[j].record()
+                if kind == "prefilter":
+                    pf_st.copy_(pf_st0)
+                    ca.silk_prefilter(d_in[ik], pf_st, d_out[ok])
+                else:
+                    getattr(ca, op)(d_in[ik], d_out[ok])
+            if events is not None:
+                events[len(ANALYSIS_OPS)].record()
+        for _ in range(warm):
+            run_all()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(ANALYSIS_OPS) + 1)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            run_all(ev[k])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        per = [float(np.mean([e[j].elapsed_time(e[j + 1]) for e in ev])) for j in range(len(ANALYSIS_OPS))]
+        kern = [{"kernel": ANALYSIS_OPS[j][6], "avg_launch_ms": round(per[j], 4),
+                 "bytes_per_record": int(rec[ANALYSIS_OPS[j][1]].shape[1] + rec[ANALYSIS_OPS[j][2]].shape[1])} for j in range(len(ANALYSIS_OPS))]
+        jmax = int(np.argmax(per))
+        kms, kname = per[jmax], ANALYSIS_OPS[jmax][6]
+        kbytes = F * kern[jmax]["bytes_per_record"]
+        limiter = "latency / VALU issue (serial fixed-point recurrences, one lane per frame; scratch-resident work arrays)"
+        metric = "SILK 16kHz mono 20ms frames/sec (analysis chain: find_pitch_lags + noise_shape_analysis + find_pred_coefs + process_gains + prefilter)"
+        workload = ("%d distinct records per function and per GPU captured from the reference encoder (synthetic 16 kHz mono speech, 32 kb/s "
+                    "VOIP, complexity 3/5/8/10 in turn): the five analysis calls silk_encode_frame_FIX makes between the VAD and the "
+                    "noise-shaping quantiser, each bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {"kernels": kern}
+        m_cpu = min(F, 2048)
+        cpu = (lambda: cpu_baseline_silk_analysis({k: np.ascontiguousarray(v[:m_cpu]) for k, v in rec.items()}))
+        if not a.no_parity and rank == 0:
+            for kind, ik, ok, nb, _, op, _ in ANALYSIS_OPS:
+                if not np.array_equal(d_out[ok].cpu().numpy()[:, :nb], rec[ok][:, :nb]):
+                    raise SystemExit("PARITY FAILURE (%s)" % op)
+            if not np.array_equal(pf_st.cpu().numpy(), rec["prefilter_state_out"]):
+                raise SystemExit("PARITY FAILURE (silk_prefilter state)")
+            parity = {"checked": F * len(ANALYSIS_OPS), "note": "every record of all five functions (every field written, and the prefilter state) vs the reference's own captured outputs"}
     elif a.workload == "silk_pred":
         F = a.frames or 65536
         steps = a.steps or 10
