@@ -11,6 +11,13 @@
 
 typedef char nsq_state_layout_check[sizeof(silk_nsq_state) == sizeof(opusgpu_nsq_state) ? 1 : -1];
 
+/* Frame bookkeeping for the aligned ("chain") capture: g_frame counts calls of silk_find_pitch_lags_FIX (one per encoded frame);
+ * every wrap notes the frame its record belongs to, so that the records of one frame can be matched across functions. */
+enum { FID_PITCH, FID_SHAPE, FID_FPC, FID_GAINS, FID_PREFILTER, FID_NSQ, FID_DD, FID_KINDS };
+static int g_frame, *g_fid[FID_KINDS], g_fid_cap;
+static void fid_note(int kind, int rec) { if (g_fid[kind] && rec >= 0 && rec < g_fid_cap) g_fid[kind][rec] = g_frame; }
+void refcap_get_frame_ids(int kind, int *out, int n) { if (g_fid[kind]) memcpy(out, g_fid[kind], sizeof(int) * (size_t)n); }
+
 static opusgpu_burg_in *g_bin; static opusgpu_burg_out *g_bout; static int g_nb, g_capb;
 static opusgpu_nsq_in *g_nin; static opusgpu_nsq_state *g_nst_in, *g_nst_out; static opusgpu_nsq_out *g_nout;
 static int g_nn, g_capn, g_on;
@@ -66,7 +73,8 @@ void __wrap_silk_NSQ_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, Si
                        const opus_int HarmShapeGain_Q14[], const opus_int Tilt_Q14[], const opus_int32 LF_shp_Q14[],
                        const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14)
 {
-    int rec = (g_on && g_nn < g_capn && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nn : -1;
+    int rec = (g_on && g_nin && g_nn < g_capn && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nn : -1;
+    fid_note(FID_NSQ, rec);
     if (rec >= 0) {
         opusgpu_nsq_in *r = &g_nin[rec];
         r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
@@ -123,6 +131,7 @@ void __wrap_silk_NSQ_del_dec_c(const silk_encoder_state *psEncC, silk_nsq_state 
                        const opus_int32 Gains_Q16[], const opus_int pitchL[], const opus_int Lambda_Q10, const opus_int LTP_scale_Q14)
 {
     int rec = (g_on && g_din && g_nd < g_capd && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nd : -1;
+    fid_note(FID_DD, rec);
     if (rec >= 0) {
         opusgpu_nsq_in *r = &g_din[rec].base;
         r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
@@ -290,6 +299,7 @@ void __wrap_silk_find_pred_coefs_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
     const silk_encoder_state *c = &psEnc->sCmn;
     int rec = (g_on && g_fin && g_nf < g_capf && c->ltp_mem_length <= OPUSGPU_SILK_MAX_LTP_MEM && c->frame_length <= OPUSGPU_SILK_MAX_FRAME)
                   ? g_nf : -1;
+    fid_note(FID_FPC, rec);
     if (rec >= 0) {
         opusgpu_find_pred_coefs_in *r = &g_fin[rec];
         memcpy(r->res_pitch, res_pitch, sizeof(opus_int16) * (c->ltp_mem_length + c->frame_length));
@@ -343,6 +353,7 @@ void __wrap_silk_process_gains_FIX(silk_encoder_state_FIX *psEnc, silk_encoder_c
 {
     const silk_encoder_state *c = &psEnc->sCmn;
     int rec = (g_on && g_gin && g_ng < g_capg) ? g_ng : -1;
+    fid_note(FID_GAINS, rec);
     if (rec >= 0) {
         opusgpu_process_gains_in *r = &g_gin[rec];
         for (int k = 0; k < MAX_NB_SUBFR; k++) { r->Gains_Q16[k] = psEncCtrl->Gains_Q16[k]; r->ResNrg[k] = psEncCtrl->ResNrg[k]; r->ResNrgQ[k] = psEncCtrl->ResNrgQ[k]; }
@@ -387,6 +398,7 @@ void __wrap_silk_noise_shape_analysis_FIX(silk_encoder_state_FIX *psEnc, silk_en
 {
     const silk_encoder_state *c = &psEnc->sCmn;
     int rec = (g_on && g_sin && g_ns < g_caps && c->la_shape <= OPUSGPU_SILK_MAX_LA_SHAPE && c->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_ns : -1;
+    fid_note(FID_SHAPE, rec);
     if (rec >= 0) {
         opusgpu_noise_shape_in *r = &g_sin[rec];
         memcpy(r->x, x - c->la_shape, sizeof(opus_int16) * (c->frame_length + 2 * c->la_shape));
@@ -448,6 +460,7 @@ void __wrap_silk_prefilter_FIX(silk_encoder_state_FIX *psEnc, const silk_encoder
     typedef char prefilter_state_layout[sizeof(opusgpu_prefilter_state) == sizeof(silk_prefilter_state_FIX) ? 1 : -1];
     const silk_encoder_state *c = &psEnc->sCmn;
     int rec = (g_on && g_xin && g_nx < g_capx && c->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nx : -1;
+    fid_note(FID_PREFILTER, rec);
     if (rec >= 0) {
         opusgpu_prefilter_in *r = &g_xin[rec];
         memcpy(r->x, x, sizeof(opus_int16) * c->frame_length);
@@ -490,7 +503,9 @@ void __wrap_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
 {
     const silk_encoder_state *c = &psEnc->sCmn;
     const int buf_len = c->la_pitch + c->frame_length + c->ltp_mem_length;
+    g_frame++;
     int rec = (g_on && g_tin && g_nt < g_capt && buf_len <= OPUSGPU_SILK_PITCH_BUF) ? g_nt : -1;
+    fid_note(FID_PITCH, rec);
     if (rec >= 0) {
         opusgpu_find_pitch_lags_in *r = &g_tin[rec];
         memcpy(r->x_buf, x - c->ltp_mem_length, sizeof(opus_int16) * buf_len);
@@ -509,4 +524,14 @@ void __wrap_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
         o->signalType = c->indices.signalType; o->predGain_Q16 = psEncCtrl->predGain_Q16; o->status = 0;
         g_nt++;
     }
+}
+
+/* Aligned capture of one encoder run: every analysis function and both quantisers record at once. */
+void refcap_start_dd(int max_records);
+void refcap_start_chain(int max_records)
+{
+    refcap_start(max_records); refcap_start_dd(max_records); refcap_start_fpc(max_records); refcap_start_gains(max_records);
+    refcap_start_shape(max_records); refcap_start_prefilter(max_records); refcap_start_pitch(max_records);
+    g_frame = 0; g_fid_cap = max_records;
+    for (int k = 0; k < FID_KINDS; k++) g_fid[k] = (int *)calloc(max_records, sizeof(int));
 }
