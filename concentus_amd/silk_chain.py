@@ -1,0 +1,115 @@
+"""The SILK analysis chain of one frame, end to end on the device:
+
+    silk_find_pitch_lags_FIX -> silk_noise_shape_analysis_FIX -> silk_find_pred_coefs_FIX -> silk_process_gains_FIX
+        -> silk_prefilter_FIX -> silk_NSQ / silk_NSQ_del_dec
+
+i.e. what silk_encode_frame_FIX (opus-fix/silk/fixed/encode_frame_FIX.c:176-317) runs between the VAD and the range coder for
+the first pass of a frame. Every stage is one batched kernel of libopusgpu.so driven from a flat record; this module is the
+host-side plumbing a batched SILK front end needs between them: after each stage it moves the fields the next records take
+from it -- byte ranges of device tensors, no arithmetic -- exactly along the edges that tests/test_silk_chain_cpu.py pins
+against the unmodified reference. What the caller provides per frame are the records' remaining fields: the input buffer,
+the VAD results, the configuration and the states the previous frame left behind.
+
+Geometry is fixed per chain object (all frames of a batch share fs_kHz / nb_subfr, as one encoder configuration does)."""
+import ctypes as C
+
+from . import silk as S
+
+
+def _off(cls, name):
+    d = getattr(cls, name)
+    return d.offset, d.size
+
+
+class SilkAnalysisChain:
+    """chain = SilkAnalysisChain(fs_kHz=16, nb_subfr=4); out = chain.run(records...)"""
+
+    def __init__(self, fs_kHz=16, nb_subfr=4):
+        if fs_kHz not in (8, 16) or nb_subfr not in (2, 4):
+            raise ValueError("fs_kHz 8 or 16, nb_subfr 2 or 4")
+        self.fs_kHz, self.nb_subfr = fs_kHz, nb_subfr
+        self.frame_length = 5 * fs_kHz * nb_subfr
+        self.ltp_mem_length = 20 * fs_kHz
+
+    @staticmethod
+    def _move(dst, dcls, dname, src, scls, sname, nbytes=None, src_skip=0):
+        do, dn = _off(dcls, dname)
+        so, sn = _off(scls, sname)
+        n = min(dn, sn - src_skip) if nbytes is None else nbytes
+        dst[:, do:do + n] = src[:, so + src_skip:so + src_skip + n]
+
+    @staticmethod
+    def _move_i8_to_i32(dst, dcls, dname, src, scls, sname):
+        import torch
+        do, _ = _off(dcls, dname)
+        so, _ = _off(scls, sname)
+        v = src[:, so:so + 1].contiguous().view(torch.int8).to(torch.int32)
+        dst[:, do:do + 4] = v.view(torch.uint8)
+
+    def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec):
+        """All arguments are uint8 CUDA tensors [N][record bytes]. shape_in / fpc_in / gains_in / prefilter_in / q_in are
+        completed in place from the outputs of the earlier stages; prefilter_state and nsq_state are updated in place.
+        q_in is opusgpu_nsq_dd_in when del_dec else opusgpu_nsq_in. Returns a dict of the stage outputs; "pulses" is
+        int8 [N][320] (and "Seed" int32 [N] for the delayed-decision quantiser)."""
+        import torch
+        mv, fl, ltp = self._move, self.frame_length, self.ltp_mem_length
+        PO, SI, SO, FI, FO, GI, GO, XI, XO, Q = (S.FindPitchLagsOut, S.NoiseShapeIn, S.NoiseShapeOut, S.FindPredCoefsIn, S.FindPredCoefsOut,
+                                                 S.ProcessGainsIn, S.ProcessGainsOut, S.PrefilterIn, S.PrefilterOut, S.NsqIn)
+        pitch_out = S.silk_find_pitch_lags(pitch_in)
+        # noise_shape_analysis <- find_pitch_lags
+        mv(shape_in, SI, "pitch_res", pitch_out, PO, "res", nbytes=2 * fl, src_skip=2 * ltp)
+        for name in ("signalType", "LTPCorr_Q15", "predGain_Q16", "pitchL"):
+            mv(shape_in, SI, name, pitch_out, PO, name)
+        shape_out = S.silk_noise_shape_analysis(shape_in)
+        # find_pred_coefs <- find_pitch_lags, noise_shape_analysis
+        mv(fpc_in, FI, "res_pitch", pitch_out, PO, "res", nbytes=2 * (ltp + fl))
+        mv(fpc_in, FI, "pitchL", pitch_out, PO, "pitchL")
+        mv(fpc_in, FI, "signalType", pitch_out, PO, "signalType")
+        mv(fpc_in, FI, "Gains_Q16", shape_out, SO, "Gains_Q16")
+        mv(fpc_in, FI, "coding_quality_Q14", shape_out, SO, "coding_quality_Q14")
+        fpc_out = S.silk_find_pred_coefs(fpc_in)
+        # process_gains <- noise_shape_analysis, find_pred_coefs
+        mv(gains_in, GI, "Gains_Q16", shape_out, SO, "Gains_Q16")
+        for name in ("ResNrg", "ResNrgQ", "LTPredCodGain_Q7"):
+            mv(gains_in, GI, name, fpc_out, FO, name)
+        for name in ("quantOffsetType", "input_quality_Q14", "coding_quality_Q14"):
+            mv(gains_in, GI, name, shape_out, SO, name)
+        mv(gains_in, GI, "signalType", pitch_out, PO, "signalType")
+        gains_out = S.silk_process_gains(gains_in)
+        # prefilter <- noise_shape_analysis, find_pitch_lags
+        for name in ("AR1_Q13", "HarmShapeGain_Q14", "HarmBoost_Q14", "Tilt_Q14", "GainsPre_Q14", "LF_shp_Q14", "coding_quality_Q14"):
+            mv(prefilter_in, XI, name, shape_out, SO, name)
+        mv(prefilter_in, XI, "pitchL", pitch_out, PO, "pitchL")
+        mv(prefilter_in, XI, "signalType", pitch_out, PO, "signalType")
+        prefilter_out = S.silk_prefilter(prefilter_in, prefilter_state)
+        # quantiser <- everything before (opusgpu_nsq_dd_in starts with an opusgpu_nsq_in)
+        mv(q_in, Q, "x_Q3", prefilter_out, XO, "xw_Q3")
+        for name in ("PredCoef_Q12", "LTPCoef_Q14", "LTP_scale_Q14"):
+            mv(q_in, Q, name, fpc_out, FO, name)
+        self._move_i8_to_i32(q_in, Q, "NLSFInterpCoef_Q2", fpc_out, FO, "NLSFInterpCoef_Q2")
+        for name in ("AR2_Q13", "HarmShapeGain_Q14", "Tilt_Q14", "LF_shp_Q14"):
+            mv(q_in, Q, name, shape_out, SO, name)
+        for name in ("Gains_Q16", "Lambda_Q10", "quantOffsetType"):
+            mv(q_in, Q, name, gains_out, GO, name)
+        mv(q_in, Q, "pitchL", pitch_out, PO, "pitchL")
+        mv(q_in, Q, "signalType", pitch_out, PO, "signalType")
+        out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out}
+        if del_dec:
+            dd_out = S.silk_NSQ_del_dec(q_in, nsq_state)
+            out["pulses"] = dd_out[:, :320].view(torch.int8)
+            out["Seed"] = dd_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
+        else:
+            out["pulses"] = S.silk_NSQ(q_in, nsq_state)
+        return out
+
+
+CHAIN_FED_FIELDS = {       # the record fields run() fills: a caller (and the test) may leave them zero
+    "shape_in": (S.NoiseShapeIn, ("pitch_res", "signalType", "LTPCorr_Q15", "predGain_Q16", "pitchL")),
+    "fpc_in": (S.FindPredCoefsIn, ("res_pitch", "pitchL", "signalType", "Gains_Q16", "coding_quality_Q14")),
+    "gains_in": (S.ProcessGainsIn, ("Gains_Q16", "ResNrg", "ResNrgQ", "LTPredCodGain_Q7", "quantOffsetType", "input_quality_Q14",
+                                    "coding_quality_Q14", "signalType")),
+    "prefilter_in": (S.PrefilterIn, ("AR1_Q13", "HarmShapeGain_Q14", "HarmBoost_Q14", "Tilt_Q14", "GainsPre_Q14", "LF_shp_Q14",
+                                     "coding_quality_Q14", "pitchL", "signalType")),
+    "q_in": (S.NsqIn, ("x_Q3", "PredCoef_Q12", "LTPCoef_Q14", "LTP_scale_Q14", "NLSFInterpCoef_Q2", "AR2_Q13", "HarmShapeGain_Q14", "Tilt_Q14",
+                       "LF_shp_Q14", "Gains_Q16", "Lambda_Q10", "quantOffsetType", "pitchL", "signalType")),
+}

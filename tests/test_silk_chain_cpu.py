@@ -60,11 +60,13 @@ def _capture(complexity, nframes, seed):
         q = [np.zeros(nn, np.dtype(S.NsqIn)), np.zeros(nn, np.dtype(S.NsqState)), np.zeros(nn, np.dtype(S.NsqState)), np.zeros((nn, 320), np.int8)]
         lib.refcap_get(*[p(a) for a in b + q])
         r["q"] = (q[0], fids("nsq", nn))
+        r["q_full"] = (q[0], q[1], q[2], q[3].view(np.uint8), False)
     else:
         nd = lib.refcap_count_dd()
         q = [np.zeros(nd, np.dtype(S.NsqDdIn)), np.zeros(nd, np.dtype(S.NsqState)), np.zeros(nd, np.dtype(S.NsqState)), np.zeros((nd, 324), np.uint8)]
         lib.refcap_get_dd(*[p(a) for a in q])
         r["q"] = (q[0]["base"], fids("dd", nd))
+        r["q_full"] = (q[0], q[1], q[2], q[3], True)
     return r
 
 

@@ -1,0 +1,67 @@
+"""GPU tier: the SILK analysis chain END TO END on the device: from the pitch-analysis buffer of a frame to the
+quantiser's pulses through the seven batched kernels, the records between them filled on the device by
+concentus_amd.silk_chain.SilkAnalysisChain (byte moves along the edges tests/test_silk_chain_cpu.py pins). Input: the records of
+ONE run of the unmodified reference encoder captured with frame numbers; every field the chain is supposed to fill is ZEROED
+before the run. Compared with what the reference computed for the same frames: every stage's output record, the prefilter
+state, the pulses, Seed and every byte of silk_nsq_state."""
+import numpy as np
+import pytest
+
+import silk_corpus
+from test_silk_chain_cpu import _capture, _first_of_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _bytes(a):
+    return np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1)
+
+
+@pytest.mark.parametrize("complexity", [3, 5, 10])
+def test_chain_from_pitch_buffer_to_pulses(complexity):
+    import torch
+    import concentus_amd as ca
+    from concentus_amd import silk as S
+    from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    nframes = 700
+    r = _capture(complexity, nframes, 9000 + complexity)
+    (pin, pout, pf), (sin_, sout, sf), (fin, fout, ff), (gin, gout, gf), (xin, xst0, xst1, xout, xf), (_, qf) = (
+        r["pitch"], r["shape"], r["fpc"], r["gains"], r["prefilter"], r["q"])
+    qin, qst0, qst1, qout, del_dec = r["q_full"]
+    idx = {k: [] for k in "psfgxq"}
+    for frame in range(9, nframes + 1):
+        ks = [_first_of_frame(a, frame) for a in (pf, sf, ff, gf, xf, qf)]
+        assert None not in ks
+        for key, k in zip("psfgxq", ks):
+            idx[key].append(k)
+    sel = {k: np.array(v) for k, v in idx.items()}
+    rec = {"pitch_in": _bytes(pin[sel["p"]]), "shape_in": _bytes(sin_[sel["s"]]), "fpc_in": _bytes(fin[sel["f"]]), "gains_in": _bytes(gin[sel["g"]]),
+           "prefilter_in": _bytes(xin[sel["x"]]), "q_in": _bytes(qin[sel["q"]])}
+    # zero every field the chain fills
+    for name, (cls, fields) in CHAIN_FED_FIELDS.items():
+        for f in fields:
+            d = getattr(cls, f)
+            rec[name][:, d.offset:d.offset + d.size] = 0
+    dev = {k: torch.from_numpy(v.copy()).cuda() for k, v in rec.items()}
+    pf_state = torch.from_numpy(_bytes(xst0[sel["x"]]).copy()).cuda()
+    nsq_state = torch.from_numpy(_bytes(qst0[sel["q"]]).copy()).cuda()
+    out = SilkAnalysisChain(16, 4).run(dev["pitch_in"], dev["shape_in"], dev["fpc_in"], dev["gains_in"], dev["prefilter_in"], pf_state,
+                                       dev["q_in"], nsq_state, del_dec)
+    torch.cuda.synchronize()
+    assert ca.silk.bad_records() == 0
+    n = len(sel["p"])
+    for key, want, nb in (("pitch_out", pout[sel["p"]], 1380), ("shape_out", sout[sel["s"]], 380), ("fpc_out", fout[sel["f"]], 204),
+                          ("gains_out", gout[sel["g"]], 52), ("prefilter_out", xout[sel["x"]], 1280)):
+        got = out[key].cpu().numpy()
+        bad = np.nonzero((got[:, :nb] != _bytes(want)[:, :nb]).any(1))[0]
+        assert bad.size == 0, (key, bad.size, bad[:6])
+    assert np.array_equal(pf_state.cpu().numpy(), _bytes(xst1[sel["x"]]))
+    want_q = qout[sel["q"]]
+    assert np.array_equal(out["pulses"].cpu().numpy().view(np.uint8), want_q[:, :320]), "pulses"
+    if del_dec:
+        assert np.array_equal(out["Seed"].cpu().numpy(), want_q[:, 320:324].copy().view(np.int32)[:, 0]), "Seed"
+    assert np.array_equal(nsq_state.cpu().numpy(), _bytes(qst1[sel["q"]])), "silk_nsq_state"
+    voiced = (pout[sel["p"]]["signalType"] == 2).sum()
+    assert n > 600 and 50 < voiced < n
