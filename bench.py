@@ -15,6 +15,9 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk            BASELINE.json configs[3]: 65 536 distinct function-boundary records, silk_burg_modified + silk_NSQ
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
+  silk_frames     65 536 frames through the WHOLE chain on the device: pitch buffer -> find_pitch_lags -> noise_shape_analysis ->
+                  find_pred_coefs -> process_gains -> prefilter -> NSQ_del_dec -> pulses (records between the kernels filled on the
+                  device, concentus_amd/silk_chain.py); parity per frame against the reference's own results.
   silk_analysis   the five analysis calls of silk_encode_frame_FIX between the VAD and the quantiser (silk_find_pitch_lags_FIX,
                   silk_noise_shape_analysis_FIX, silk_find_pred_coefs_FIX, silk_process_gains_FIX, silk_prefilter_FIX), 65 536
                   distinct captured records each; value = frames/s through all five.
@@ -65,7 +68,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "silk_frames", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -722,6 +725,77 @@ def main(argv=None):
             if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
                 raise SystemExit("PARITY FAILURE (silk_find_LPC)")
             parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
+    elif a.workload == "silk_frames":
+        F = a.frames or 65536
+        steps = a.steps or 5
+        warm = a.warmup if a.warmup is not None else 1
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS
+        if not silk_corpus.available():
+            raise SystemExit("silk_frames needs oracle/_ref/libopus_ref_silkcap.so (frames are captured from the reference encoder)")
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "chain_dd", seed=20260401 + 1000003 * rank).items()}
+        names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in",
+                 "prefilter_in": "c_prefilter_in", "q_in": "c_q_in"}
+        host_in = {k: rec[v].copy() for k, v in names.items()}
+        for name, (cls, fields) in CHAIN_FED_FIELDS.items():              # what the chain has to produce itself starts out as zero
+            for f in fields:
+                d = getattr(cls, f)
+                host_in[name][:, d.offset:d.offset + d.size] = 0
+        d_in = {k: torch.from_numpy(v).to(dev) for k, v in host_in.items()}
+        pf0, nsq0 = torch.from_numpy(rec["c_prefilter_state_in"]).to(dev), torch.from_numpy(rec["c_q_state_in"]).to(dev)
+        pf_st, nsq_st = pf0.clone(), nsq0.clone()
+        chain = SilkAnalysisChain(16, 4)
+
+        def one_step():
+            pf_st.copy_(pf0)
+            nsq_st.copy_(nsq0)
+            return chain.run(d_in["pitch_in"], d_in["shape_in"], d_in["fpc_in"], d_in["gains_in"], d_in["prefilter_in"], pf_st, d_in["q_in"],
+                             nsq_st, True)
+        for _ in range(warm):
+            one_step()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            res = one_step()
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_find_pred_coefs_kernel"
+        kbytes = F * (1408 + 324 + 4380 + 1116)        # per frame: pitch buffer in, pulses + Seed out, the two carried states rewritten
+        limiter = "latency / VALU issue (seven lane-per-frame kernels of serial fixed-point recurrences; whole step timed, kernel = the longest)"
+        metric = "SILK 16kHz mono 20ms frames/sec (analysis chain + silk_NSQ_del_dec, pitch buffer -> pulses)"
+        workload = ("%d frames per GPU, each with the records of ONE frame captured from the reference encoder (synthetic 16 kHz mono "
+                    "speech, 32 kb/s VOIP, complexity 5/7/10 in turn); the seven kernels run back to back (find_pitch_lags, "
+                    "noise_shape_analysis, find_pred_coefs, process_gains, prefilter, NSQ_del_dec), records between them filled on "
+                    "the device; bit-exact vs FIXED_POINT" % F)
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {"note": "avg_launch_ms is the whole seven-kernel step (incl. the device-side record moves and the reset of the two carried states)"}
+        m_cpu = min(F, 2048)
+
+        def cpu():
+            sub = {k[2:]: np.ascontiguousarray(v[:m_cpu]) for k, v in rec.items() if k.startswith("c_") and not k.startswith("c_q")}
+            a_ = cpu_baseline_silk_analysis(sub)
+            b_ = cpu_baseline_silk_dd(np.ascontiguousarray(rec["c_q_in"][:m_cpu]), np.ascontiguousarray(rec["c_q_state_in"][:m_cpu]))
+            v = 1.0 / (1.0 / a_["value"] + 1.0 / b_["value"])
+            return {"value": round(v, 1), "unit": "frames/s", "cores": a_["cores"], "kind": "port", "cpu": a_["cpu"],
+                    "sample": "analysis: " + a_["sample"] + "; quantiser: " + b_["sample"] + "; combined as 1 / (1/a + 1/b)"}
+        if not a.no_parity and rank == 0:
+            for key, want, nb in (("pitch_out", "c_pitch_out", 1380), ("shape_out", "c_shape_out", 380), ("fpc_out", "c_fpc_out", 204),
+                                  ("gains_out", "c_gains_out", 52), ("prefilter_out", "c_prefilter_out", 1280)):
+                if not np.array_equal(res[key].cpu().numpy()[:, :nb], rec[want][:, :nb]):
+                    raise SystemExit("PARITY FAILURE (silk_frames: %s)" % key)
+            ok = (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), rec["c_q_out"][:, :320])
+                  and np.array_equal(res["Seed"].cpu().numpy(), rec["c_q_out"][:, 320:324].copy().view(np.int32)[:, 0])
+                  and np.array_equal(nsq_st.cpu().numpy(), rec["c_q_state_out"]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"]))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (silk_frames: pulses / Seed / silk_nsq_state / prefilter state)")
+            parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX "
+                                           "vs what the reference computed for the same frame"}
     elif a.workload == "silk_analysis":
         F = a.frames or 65536
         steps = a.steps or 5

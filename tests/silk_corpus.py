@@ -102,7 +102,9 @@ def _capture_segment(args):
     nfr = take + WARMUP
     pcm = synth_voice(nfr * FRAME, seed)
     cap = 3 * nfr + 16
-    if kind == "dd":
+    if kind.startswith("chain"):
+        lib.refcap_start_chain(4 * nfr + 16)
+    elif kind == "dd":
         lib.refcap_start_dd(cap)
     elif kind == "lpc":
         lib.refcap_start_lpc(cap)
@@ -130,6 +132,52 @@ def _capture_segment(args):
         fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
         assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
+    if kind.startswith("chain"):
+        dd = kind == "chain_dd"
+
+        def fids(k, n):
+            a = np.zeros(max(n, 1), np.int32)
+            lib.refcap_get_frame_ids(k, _p(a), n)
+            return a[:n]
+
+        def grab(n, getter, sizes):
+            bufs = [np.zeros((n, SIZES[z]), np.uint8) for z in sizes]
+            getter(*[_p(b) for b in bufs])
+            return bufs
+        got = {}
+        n = lib.refcap_count_pitch(); got["pitch"] = (grab(n, lib.refcap_get_pitch, ("pitch_in", "pitch_out")), fids(0, n))
+        n = lib.refcap_count_shape(); got["shape"] = (grab(n, lib.refcap_get_shape, ("shape_in", "shape_out")), fids(1, n))
+        n = lib.refcap_count_fpc(); got["fpc"] = (grab(n, lib.refcap_get_fpc, ("fpc_in", "fpc_out")), fids(2, n))
+        n = lib.refcap_count_gains(); got["gains"] = (grab(n, lib.refcap_get_gains, ("gains_in", "gains_out")), fids(3, n))
+        n = lib.refcap_count_prefilter()
+        got["prefilter"] = (grab(n, lib.refcap_get_prefilter, ("prefilter_in", "prefilter_state", "prefilter_state", "prefilter_out")), fids(4, n))
+        if dd:
+            n = lib.refcap_count_dd(); got["q"] = (grab(n, lib.refcap_get_dd, ("dd_in", "nsq_state", "nsq_state", "dd_out")), fids(6, n))
+        else:
+            nb, n = lib.refcap_count_burg(), lib.refcap_count_nsq()
+            b = [np.zeros((nb, SIZES["burg_in"]), np.uint8), np.zeros((nb, SIZES["burg_out"]), np.uint8)]
+            q = [np.zeros((n, SIZES[z]), np.uint8) for z in ("nsq_in", "nsq_state", "nsq_state", "nsq_out")]
+            lib.refcap_get(*[_p(a) for a in b + q])
+            got["q"] = (q, fids(5, n))
+        first = {}
+        for key, (_, fid) in got.items():
+            # index of the first record of every frame number (frame numbers start at 1)
+            order = np.argsort(fid, kind="stable")
+            uniq, start = np.unique(fid[order], return_index=True)
+            first[key] = dict(zip(uniq.tolist(), order[start].tolist()))
+        frames = [f for f in range(WARMUP + 1, nfr + 1) if all(f in first[k] for k in first)][:take]
+        assert len(frames) == take, (len(frames), take)
+        names = {"pitch": ("c_pitch_in", "c_pitch_out"), "shape": ("c_shape_in", "c_shape_out"), "fpc": ("c_fpc_in", "c_fpc_out"),
+                 "gains": ("c_gains_in", "c_gains_out"),
+                 "prefilter": ("c_prefilter_in", "c_prefilter_state_in", "c_prefilter_state_out", "c_prefilter_out"),
+                 "q": ("c_q_in", "c_q_state_in", "c_q_state_out", "c_q_out")}
+        for key, (bufs, _) in got.items():
+            sel = np.array([first[key][f] for f in frames])
+            for name, b in zip(names[key], bufs):
+                files[name][row0:row0 + take] = b[sel]
+        for f in files.values():
+            f.flush()
+        return take
     if kind == "pitch":
         nt = lib.refcap_count_pitch()
         assert nt >= nfr, (nt, nfr)
@@ -213,6 +261,10 @@ def _capture_segment(args):
     return take
 
 
+_CHAIN_LAYOUT = (("c_pitch_in", "pitch_in"), ("c_pitch_out", "pitch_out"), ("c_shape_in", "shape_in"), ("c_shape_out", "shape_out"),
+                 ("c_fpc_in", "fpc_in"), ("c_fpc_out", "fpc_out"), ("c_gains_in", "gains_in"), ("c_gains_out", "gains_out"),
+                 ("c_prefilter_in", "prefilter_in"), ("c_prefilter_state_in", "prefilter_state"), ("c_prefilter_state_out", "prefilter_state"),
+                 ("c_prefilter_out", "prefilter_out"), ("c_q_state_in", "nsq_state"), ("c_q_state_out", "nsq_state"))
 _LAYOUT = {
     "nsq": (("burg_in", "burg_in"), ("burg_out", "burg_out"), ("nsq_in", "nsq_in"), ("nsq_state_in", "nsq_state"),
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
@@ -222,6 +274,9 @@ _LAYOUT = {
     "gains": (("gains_in", "gains_in"), ("gains_out", "gains_out")),
     "shape": (("shape_in", "shape_in"), ("shape_out", "shape_out")),
     "pitch": (("pitch_in", "pitch_in"), ("pitch_out", "pitch_out")),
+    # aligned capture of ONE encoder run: row r of every array belongs to the same frame (first call of the frame)
+    "chain_nsq": _CHAIN_LAYOUT + (("c_q_in", "nsq_in"), ("c_q_out", "nsq_out")),
+    "chain_dd": _CHAIN_LAYOUT + (("c_q_in", "dd_in"), ("c_q_out", "dd_out")),
     "prefilter": (("prefilter_in", "prefilter_in"), ("prefilter_state_in", "prefilter_state"), ("prefilter_state_out", "prefilter_state"),
                   ("prefilter_out", "prefilter_out")),
     "pred": (("nlsf_in", "nlsf_in"), ("nlsf_out", "nlsf_out"), ("resnrg_in", "resnrg_in"), ("resnrg_out", "resnrg_out")),
@@ -248,7 +303,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     # kind "fpc": silk_find_pred_coefs_FIX whole (voiced and unvoiced frames), complexities as "lpc"
     # kind "pred": silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX), complexities as "lpc"
     # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
-    complexities = complexities or ((3,) if kind == "nsq" else (5, 7, 10) if kind == "dd" else (3, 5, 8, 10))
+    complexities = complexities or ((3,) if kind in ("nsq", "chain_nsq") else (5, 7, 10) if kind in ("dd", "chain_dd") else (3, 5, 8, 10))
     # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
     cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
                          "%s_%d_%s_%d" % (kind, n, "-".join(map(str, complexities)), seed))
@@ -261,7 +316,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
                          row, take, n))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
