@@ -47,6 +47,10 @@ SYMBOLS = [
     ("opusgpu_silk_noise_shape_analysis_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_prefilter_batch", _i, [_vp, _vp, _vp, _i, _vp]),
     ("opusgpu_silk_find_pitch_lags_batch", _i, [_vp, _vp, _i, _vp]),
+    ("opusgpu_silk_find_pitch_lags_FIX", None, [_vp, _vp, _vp, _vp, _i]),
+    ("opusgpu_silk_noise_shape_analysis_FIX", None, [_vp, _vp, _vp, _vp, _i]),
+    ("opusgpu_silk_process_gains_FIX", None, [_vp, _vp, _i]),
+    ("opusgpu_silk_prefilter_FIX", None, [_vp, _vp, _vp, _vp]),
     ("opusgpu_silk_residual_energy_FIX", None, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_celt_dec_state_size", _i, []),
     ("opusgpu_celt_dec_state_init", _i, [_vp, _i, _vp]),

@@ -136,6 +136,57 @@ void opusgpu_silk_residual_energy_FIX(int32_t nrgs[], int nrgsQ[], const int16_t
 #define OPUSGPU_REF_OFF_CTRL_RES_NRG_Q 516          /* .ResNrgQ[4]                                (opus_int) */
 void opusgpu_silk_find_pred_coefs_FIX(void *psEnc, void *psEncCtrl, const int16_t res_pitch[], const int16_t x[], int condCoding);
 
+/* The other four analysis calls of silk_encode_frame_FIX (opus-fix/silk/fixed/encode_frame_FIX.c:176-243) with the reference's own
+ * argument lists; psEnc / psEncCtrl are the reference's silk_encoder_state_FIX / silk_encoder_control_FIX. Each reads and writes
+ * exactly the fields the reference function does (listed with the batched records in include/opusgpu_silk.h), at these offsets:
+ *   silk_find_pitch_lags_FIX(psEnc, psEncCtrl, res, x, arch)            silk/fixed/find_pitch_lags_FIX.c:37   (8 / 16 kHz)
+ *   silk_noise_shape_analysis_FIX(psEnc, psEncCtrl, pitch_res, x, arch) silk/fixed/noise_shape_analysis_FIX.c:146
+ *   silk_process_gains_FIX(psEnc, psEncCtrl, condCoding)                silk/fixed/process_gains_FIX.c:37
+ *   silk_prefilter_FIX(psEnc, psEncCtrl, xw_Q3, x)                      silk/fixed/prefilter_FIX.c:102 */
+#define OPUSGPU_REF_OFF_FS_KHZ 4600                                  /* silk_encoder_state.fs_kHz */
+#define OPUSGPU_REF_OFF_LA_PITCH 4620                                /* silk_encoder_state.la_pitch */
+#define OPUSGPU_REF_OFF_LA_SHAPE 4624                                /* silk_encoder_state.la_shape */
+#define OPUSGPU_REF_OFF_SHAPE_WIN_LENGTH 4628                        /* silk_encoder_state.shapeWinLength */
+#define OPUSGPU_REF_OFF_PITCH_LPC_WIN_LENGTH 4572                    /* silk_encoder_state.pitch_LPC_win_length */
+#define OPUSGPU_REF_OFF_PITCH_EST_LPC_ORDER 4672                     /* silk_encoder_state.pitchEstimationLPCOrder */
+#define OPUSGPU_REF_OFF_PITCH_EST_COMPLEXITY 4668                    /* silk_encoder_state.pitchEstimationComplexity */
+#define OPUSGPU_REF_OFF_PITCH_EST_THRESHOLD_Q16 4676                 /* silk_encoder_state.pitchEstimationThreshold_Q16 */
+#define OPUSGPU_REF_OFF_SNR_DB_Q7 4764                               /* silk_encoder_state.SNR_dB_Q7 */
+#define OPUSGPU_REF_OFF_USE_CBR 4708                                 /* silk_encoder_state.useCBR */
+#define OPUSGPU_REF_OFF_INPUT_QUALITY_BANDS_Q15 4744                 /* silk_encoder_state.input_quality_bands_Q15 */
+#define OPUSGPU_REF_OFF_INPUT_TILT_Q15 4760                          /* silk_encoder_state.input_tilt_Q15 */
+#define OPUSGPU_REF_OFF_PREV_SIGNAL_TYPE 4565                        /* silk_encoder_state.prevSignalType */
+#define OPUSGPU_REF_OFF_PREV_LAG 4568                                /* silk_encoder_state.prevLag */
+#define OPUSGPU_REF_OFF_GAINS_INDICES 0                              /* SideInfoIndices.GainsIndices */
+#define OPUSGPU_REF_OFF_LAG_INDEX 26                                 /* SideInfoIndices.lagIndex */
+#define OPUSGPU_REF_OFF_CONTOUR_INDEX 28                             /* SideInfoIndices.contourIndex */
+#define OPUSGPU_REF_OFF_FIX_SSHAPE 7224                              /* silk_encoder_state_FIX.sShape */
+#define OPUSGPU_REF_OFF_FIX_SPREFILT 7240                            /* silk_encoder_state_FIX.sPrefilt */
+#define OPUSGPU_REF_OFF_FIX_LTPCORR_Q15 9796                         /* silk_encoder_state_FIX.LTPCorr_Q15 */
+#define OPUSGPU_REF_OFF_SHAPE_LAST_GAIN_INDEX 0                      /* silk_shape_state_FIX.LastGainIndex */
+#define OPUSGPU_REF_OFF_SHAPE_HARM_BOOST_SMTH_Q16 4                  /* silk_shape_state_FIX.HarmBoost_smth_Q16 */
+#define OPUSGPU_REF_OFF_SHAPE_HARM_SHAPE_GAIN_SMTH_Q16 8             /* silk_shape_state_FIX.HarmShapeGain_smth_Q16 */
+#define OPUSGPU_REF_OFF_SHAPE_TILT_SMTH_Q16 12                       /* silk_shape_state_FIX.Tilt_smth_Q16 */
+#define OPUSGPU_REF_OFF_CTRL_AR1_Q13 140                             /* silk_encoder_control_FIX.AR1_Q13 */
+#define OPUSGPU_REF_OFF_CTRL_AR2_Q13 268                             /* silk_encoder_control_FIX.AR2_Q13 */
+#define OPUSGPU_REF_OFF_CTRL_LF_SHP_Q14 396                          /* silk_encoder_control_FIX.LF_shp_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_GAINS_PRE_Q14 412                       /* silk_encoder_control_FIX.GainsPre_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_HARM_BOOST_Q14 428                      /* silk_encoder_control_FIX.HarmBoost_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_TILT_Q14 444                            /* silk_encoder_control_FIX.Tilt_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_HARM_SHAPE_GAIN_Q14 460                 /* silk_encoder_control_FIX.HarmShapeGain_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_LAMBDA_Q10 476                          /* silk_encoder_control_FIX.Lambda_Q10 */
+#define OPUSGPU_REF_OFF_CTRL_INPUT_QUALITY_Q14 480                   /* silk_encoder_control_FIX.input_quality_Q14 */
+#define OPUSGPU_REF_OFF_CTRL_SPARSENESS_Q8 488                       /* silk_encoder_control_FIX.sparseness_Q8 */
+#define OPUSGPU_REF_OFF_CTRL_PRED_GAIN_Q16 492                       /* silk_encoder_control_FIX.predGain_Q16 */
+#define OPUSGPU_REF_OFF_CTRL_GAINS_UNQ_Q16 532                       /* silk_encoder_control_FIX.GainsUnq_Q16 */
+#define OPUSGPU_REF_OFF_CTRL_LAST_GAIN_INDEX_PREV 548                /* silk_encoder_control_FIX.lastGainIndexPrev */
+#define OPUSGPU_REF_SIZEOF_SILK_PREFILTER_STATE_FIX 1116
+#define OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE_FIX 9800
+void opusgpu_silk_find_pitch_lags_FIX(void *psEnc, void *psEncCtrl, int16_t res[], const int16_t x[], int arch);
+void opusgpu_silk_noise_shape_analysis_FIX(void *psEnc, void *psEncCtrl, const int16_t *pitch_res, const int16_t *x, int arch);
+void opusgpu_silk_process_gains_FIX(void *psEnc, void *psEncCtrl, int condCoding);
+void opusgpu_silk_prefilter_FIX(void *psEnc, const void *psEncCtrl, int32_t xw_Q3[], const int16_t x[]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,10 +24,48 @@ int main(void)
     F(silk_encoder_control_FIX, Gains_Q16); F(silk_encoder_control_FIX, PredCoef_Q12); F(silk_encoder_control_FIX, LTPCoef_Q14);
     F(silk_encoder_control_FIX, LTP_scale_Q14); F(silk_encoder_control_FIX, pitchL); F(silk_encoder_control_FIX, LTPredCodGain_Q7);
     F(silk_encoder_control_FIX, ResNrg); F(silk_encoder_control_FIX, ResNrgQ); F(silk_encoder_control_FIX, coding_quality_Q14);
+    F(silk_encoder_state, fs_kHz);
+    F(silk_encoder_state, la_pitch);
+    F(silk_encoder_state, la_shape);
+    F(silk_encoder_state, shapeWinLength);
+    F(silk_encoder_state, pitch_LPC_win_length);
+    F(silk_encoder_state, pitchEstimationLPCOrder);
+    F(silk_encoder_state, pitchEstimationComplexity);
+    F(silk_encoder_state, pitchEstimationThreshold_Q16);
+    F(silk_encoder_state, SNR_dB_Q7);
+    F(silk_encoder_state, useCBR);
+    F(silk_encoder_state, input_quality_bands_Q15);
+    F(silk_encoder_state, input_tilt_Q15);
+    F(silk_encoder_state, prevSignalType);
+    F(silk_encoder_state, prevLag);
+    F(SideInfoIndices, GainsIndices);
+    F(SideInfoIndices, lagIndex);
+    F(SideInfoIndices, contourIndex);
+    F(silk_encoder_state_FIX, sShape);
+    F(silk_encoder_state_FIX, sPrefilt);
+    F(silk_encoder_state_FIX, LTPCorr_Q15);
+    F(silk_shape_state_FIX, LastGainIndex);
+    F(silk_shape_state_FIX, HarmBoost_smth_Q16);
+    F(silk_shape_state_FIX, HarmShapeGain_smth_Q16);
+    F(silk_shape_state_FIX, Tilt_smth_Q16);
+    F(silk_encoder_control_FIX, AR1_Q13);
+    F(silk_encoder_control_FIX, AR2_Q13);
+    F(silk_encoder_control_FIX, LF_shp_Q14);
+    F(silk_encoder_control_FIX, GainsPre_Q14);
+    F(silk_encoder_control_FIX, HarmBoost_Q14);
+    F(silk_encoder_control_FIX, Tilt_Q14);
+    F(silk_encoder_control_FIX, HarmShapeGain_Q14);
+    F(silk_encoder_control_FIX, Lambda_Q10);
+    F(silk_encoder_control_FIX, input_quality_Q14);
+    F(silk_encoder_control_FIX, sparseness_Q8);
+    F(silk_encoder_control_FIX, predGain_Q16);
+    F(silk_encoder_control_FIX, GainsUnq_Q16);
+    F(silk_encoder_control_FIX, lastGainIndexPrev);
     F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
     F(SideInfoIndices, Seed); F(SideInfoIndices, NLSFIndices);
     F(SideInfoIndices, LTPIndex); F(SideInfoIndices, PERIndex); F(SideInfoIndices, LTP_scaleIndex);
-    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu\n}\n",
-           sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state), sizeof(silk_encoder_control_FIX));
+    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu,\n  \"sizeof.silk_prefilter_state_FIX\": %zu,\n  \"sizeof.silk_encoder_state_FIX\": %zu\n}\n",
+           sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state), sizeof(silk_encoder_control_FIX),
+           sizeof(silk_prefilter_state_FIX), sizeof(silk_encoder_state_FIX));
     return 0;
 }

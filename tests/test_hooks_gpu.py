@@ -315,6 +315,121 @@ def test_silk_find_pred_coefs_FIX_hook_with_the_reference_argument_list(L, ref):
     assert seen == {True, False}, "voiced and unvoiced frames among the picks"
 
 
+def _fix_images(d, sets_state, sets_ctrl):
+    """A zeroed silk_encoder_state_FIX / silk_encoder_control_FIX pair with the given (macro suffix, value, ctype) fields set."""
+    enc = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE_FIX"] + 64, np.uint8)
+    ctl = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_CONTROL_FIX"], np.uint8)
+    for img, sets in ((enc, sets_state), (ctl, sets_ctrl)):
+        for off, val, dt in sets:
+            a = np.atleast_1d(np.asarray(val)).astype(dt)
+            img[off:off + a.nbytes] = a.view(np.uint8)
+    return enc, ctl
+
+
+def test_the_four_frame_analysis_hooks_with_the_reference_argument_lists(L, ref):
+    """opusgpu_silk_find_pitch_lags_FIX / _noise_shape_analysis_FIX / _process_gains_FIX / _prefilter_FIX against the same functions
+    of the compiled reference: both get identical silk_encoder_state_FIX / silk_encoder_control_FIX images (zero except the fields
+    the function reads, placed at the offsets of include/opusgpu_hooks.h) and identical signal buffers; compared afterwards:
+    EVERY byte of both structures and the output arrays (res[], xw_Q3[])."""
+    import silk_corpus
+    from concentus_amd import silk as S
+    r, _ = ref
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    d = header_defines()
+    O = lambda name: d["OPUSGPU_REF_OFF_" + name]
+    IND, SHP, PF = O("INDICES"), O("FIX_SSHAPE"), O("FIX_SPREFILT")
+    i32, i8, i16 = np.int32, np.int8, np.int16
+
+    def both(fn_ref, fn_gpu, make_args):
+        imgs = []
+        for fn in (fn_ref, fn_gpu):
+            enc, ctl, extra, call = make_args()
+            call(fn, enc, ctl, extra)
+            imgs.append((enc, ctl, extra))
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(imgs[0][1], imgs[1][1]), ("silk_encoder_control_FIX", np.nonzero(imgs[0][1] != imgs[1][1])[0][:8])
+        assert np.array_equal(imgs[0][0], imgs[1][0]), ("silk_encoder_state_FIX", np.nonzero(imgs[0][0] != imgs[1][0])[0][:8])
+        for a, b in zip(imgs[0][2], imgs[1][2]):
+            assert np.array_equal(a, b)
+
+    # ---- silk_find_pitch_lags_FIX
+    rec = np.asarray(silk_corpus.corpus(4096, "pitch")["pitch_in"])
+    for k in range(0, 4096, 211):
+        R = np.frombuffer(np.ascontiguousarray(rec[k]).tobytes(), np.dtype(S.FindPitchLagsIn))[0]
+
+        def mk():
+            enc, ctl = _fix_images(d, [(O(n), int(R[f]), i32) for n, f in (
+                ("FS_KHZ", "fs_kHz"), ("NB_SUBFR", "nb_subfr"), ("FRAME_LENGTH", "frame_length"), ("LTP_MEM_LENGTH", "ltp_mem_length"),
+                ("LA_PITCH", "la_pitch"), ("PITCH_LPC_WIN_LENGTH", "pitch_LPC_win_length"), ("PITCH_EST_LPC_ORDER", "pitchEstimationLPCOrder"),
+                ("PITCH_EST_COMPLEXITY", "pitchEstimationComplexity"), ("PITCH_EST_THRESHOLD_Q16", "pitchEstimationThreshold_Q16"),
+                ("FIRST_FRAME_AFTER_RESET", "first_frame_after_reset"), ("SPEECH_ACTIVITY_Q8", "speech_activity_Q8"),
+                ("INPUT_TILT_Q15", "input_tilt_Q15"), ("PREV_LAG", "prevLag"), ("FIX_LTPCORR_Q15", "LTPCorr_Q15"))] + [
+                (IND + O("SIGNAL_TYPE"), int(R["signalType"]), i8), (O("PREV_SIGNAL_TYPE"), int(R["prevSignalType"]), i8)], [])
+            xbuf = np.zeros(1024, i16)
+            xbuf[:672] = R["x_buf"]
+            res = np.full(1024, 0, i16)
+            return enc, ctl, (res, xbuf), lambda fn, e, c, x: fn(p(e), p(c), p(x[0]), C.c_void_p(x[1].ctypes.data + 2 * int(R["ltp_mem_length"])), C.c_int(0))
+        both(r.silk_find_pitch_lags_FIX, L.opusgpu_silk_find_pitch_lags_FIX, mk)
+
+    # ---- silk_noise_shape_analysis_FIX
+    rec = np.asarray(silk_corpus.corpus(4096, "shape")["shape_in"])
+    for k in range(0, 4096, 211):
+        R = np.frombuffer(np.ascontiguousarray(rec[k]).tobytes(), np.dtype(S.NoiseShapeIn))[0]
+
+        def mk():
+            enc, ctl = _fix_images(d, [(O(n), int(R[f]), i32) for n, f in (
+                ("FS_KHZ", "fs_kHz"), ("NB_SUBFR", "nb_subfr"), ("SUBFR_LENGTH", "subfr_length"), ("LA_SHAPE", "la_shape"),
+                ("SHAPE_WIN_LENGTH", "shapeWinLength"), ("SHAPING_LPC_ORDER", "shapingLPCOrder"), ("WARPING_Q16", "warping_Q16"),
+                ("SNR_DB_Q7", "SNR_dB_Q7"), ("USE_CBR", "useCBR"), ("SPEECH_ACTIVITY_Q8", "speech_activity_Q8"), ("FIX_LTPCORR_Q15", "LTPCorr_Q15"))] + [
+                (O("INPUT_QUALITY_BANDS_Q15"), R["input_quality_bands_Q15"], i32), (IND + O("SIGNAL_TYPE"), int(R["signalType"]), i8),
+                (SHP + O("SHAPE_HARM_BOOST_SMTH_Q16"), int(R["HarmBoost_smth_Q16"]), i32),
+                (SHP + O("SHAPE_HARM_SHAPE_GAIN_SMTH_Q16"), int(R["HarmShapeGain_smth_Q16"]), i32),
+                (SHP + O("SHAPE_TILT_SMTH_Q16"), int(R["Tilt_smth_Q16"]), i32)],
+                [(O("CTRL_PRED_GAIN_Q16"), int(R["predGain_Q16"]), i32), (O("CTRL_PITCHL"), R["pitchL"], i32)])
+            x = np.zeros(1024, i16)
+            x[:480] = R["x"]
+            pr = np.ascontiguousarray(R["pitch_res"]).astype(i16)
+            return enc, ctl, (pr, x), lambda fn, e, c, a: fn(p(e), p(c), p(a[0]), C.c_void_p(a[1].ctypes.data + 2 * int(R["la_shape"])), C.c_int(0))
+        both(r.silk_noise_shape_analysis_FIX, L.opusgpu_silk_noise_shape_analysis_FIX, mk)
+
+    # ---- silk_process_gains_FIX
+    rec = np.asarray(silk_corpus.corpus(4096, "gains")["gains_in"])
+    for k in range(0, 4096, 211):
+        R = np.frombuffer(np.ascontiguousarray(rec[k]).tobytes(), np.dtype(S.ProcessGainsIn))[0]
+
+        def mk():
+            enc, ctl = _fix_images(d, [(O(n), int(R[f]), i32) for n, f in (
+                ("NB_SUBFR", "nb_subfr"), ("SUBFR_LENGTH", "subfr_length"), ("SNR_DB_Q7", "SNR_dB_Q7"), ("INPUT_TILT_Q15", "input_tilt_Q15"),
+                ("N_STATES_DEL_DEC", "nStatesDelayedDecision"), ("SPEECH_ACTIVITY_Q8", "speech_activity_Q8"))] + [
+                (IND + O("SIGNAL_TYPE"), int(R["signalType"]), i8), (IND + O("QUANT_OFFSET_TYPE"), int(R["quantOffsetType"]), i8),
+                (SHP + O("SHAPE_LAST_GAIN_INDEX"), int(R["LastGainIndex"]), i8)],
+                [(O("CTRL_GAINS_Q16"), R["Gains_Q16"], i32), (O("CTRL_RES_NRG"), R["ResNrg"], i32), (O("CTRL_RES_NRG_Q"), R["ResNrgQ"], i32),
+                 (O("CTRL_LTP_RED_COD_GAIN_Q7"), int(R["LTPredCodGain_Q7"]), i32), (O("CTRL_INPUT_QUALITY_Q14"), int(R["input_quality_Q14"]), i32),
+                 (O("CTRL_CODING_QUALITY_Q14"), int(R["coding_quality_Q14"]), i32)])
+            return enc, ctl, (), lambda fn, e, c, a: fn(p(e), p(c), C.c_int(int(R["condCoding"])))
+        both(r.silk_process_gains_FIX, L.opusgpu_silk_process_gains_FIX, mk)
+
+    # ---- silk_prefilter_FIX
+    pc = silk_corpus.corpus(4096, "prefilter")
+    rec, st0 = np.asarray(pc["prefilter_in"]), np.asarray(pc["prefilter_state_in"])
+    for k in range(0, 4096, 211):
+        R = np.frombuffer(np.ascontiguousarray(rec[k]).tobytes(), np.dtype(S.PrefilterIn))[0]
+
+        def mk():
+            enc, ctl = _fix_images(d, [(O(n), int(R[f]), i32) for n, f in (
+                ("NB_SUBFR", "nb_subfr"), ("SUBFR_LENGTH", "subfr_length"), ("WARPING_Q16", "warping_Q16"), ("SHAPING_LPC_ORDER", "shapingLPCOrder"))] + [
+                (IND + O("SIGNAL_TYPE"), int(R["signalType"]), i8), (PF, st0[k], np.uint8)],
+                [(O("CTRL_PITCHL"), R["pitchL"], i32), (O("CTRL_HARM_SHAPE_GAIN_Q14"), R["HarmShapeGain_Q14"], i32),
+                 (O("CTRL_HARM_BOOST_Q14"), R["HarmBoost_Q14"], i32), (O("CTRL_TILT_Q14"), R["Tilt_Q14"], i32),
+                 (O("CTRL_GAINS_PRE_Q14"), R["GainsPre_Q14"], i32), (O("CTRL_LF_SHP_Q14"), R["LF_shp_Q14"], i32),
+                 (O("CTRL_AR1_Q13"), R["AR1_Q13"], i16), (O("CTRL_CODING_QUALITY_Q14"), int(R["coding_quality_Q14"]), i32)])
+            xw = np.zeros(320, i32)
+            x = np.ascontiguousarray(R["x"]).astype(i16)
+            return enc, ctl, (xw, x), lambda fn, e, c, a: fn(p(e), p(c), p(a[0]), p(a[1]))
+        both(r.silk_prefilter_FIX, L.opusgpu_silk_prefilter_FIX, mk)
+
+
 def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
     """opusgpu_quant_all_bands with the tree's 21-argument list and its ec_ctx (EC_DIFF included) against quant_all_bands of the
     compiled reference ON THE CALLS THE REFERENCE ENCODER ITSELF MAKES: oracle/_ref/libopus_ref_celtcap.so (--wrap=quant_all_bands,

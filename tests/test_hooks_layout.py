@@ -51,6 +51,45 @@ PAIRS = {
     "OPUSGPU_REF_OFF_CTRL_LTP_RED_COD_GAIN_Q7": "silk_encoder_control_FIX.LTPredCodGain_Q7",
     "OPUSGPU_REF_OFF_CTRL_RES_NRG": "silk_encoder_control_FIX.ResNrg",
     "OPUSGPU_REF_OFF_CTRL_RES_NRG_Q": "silk_encoder_control_FIX.ResNrgQ",
+    "OPUSGPU_REF_OFF_FS_KHZ": "silk_encoder_state.fs_kHz",
+    "OPUSGPU_REF_OFF_LA_PITCH": "silk_encoder_state.la_pitch",
+    "OPUSGPU_REF_OFF_LA_SHAPE": "silk_encoder_state.la_shape",
+    "OPUSGPU_REF_OFF_SHAPE_WIN_LENGTH": "silk_encoder_state.shapeWinLength",
+    "OPUSGPU_REF_OFF_PITCH_LPC_WIN_LENGTH": "silk_encoder_state.pitch_LPC_win_length",
+    "OPUSGPU_REF_OFF_PITCH_EST_LPC_ORDER": "silk_encoder_state.pitchEstimationLPCOrder",
+    "OPUSGPU_REF_OFF_PITCH_EST_COMPLEXITY": "silk_encoder_state.pitchEstimationComplexity",
+    "OPUSGPU_REF_OFF_PITCH_EST_THRESHOLD_Q16": "silk_encoder_state.pitchEstimationThreshold_Q16",
+    "OPUSGPU_REF_OFF_SNR_DB_Q7": "silk_encoder_state.SNR_dB_Q7",
+    "OPUSGPU_REF_OFF_USE_CBR": "silk_encoder_state.useCBR",
+    "OPUSGPU_REF_OFF_INPUT_QUALITY_BANDS_Q15": "silk_encoder_state.input_quality_bands_Q15",
+    "OPUSGPU_REF_OFF_INPUT_TILT_Q15": "silk_encoder_state.input_tilt_Q15",
+    "OPUSGPU_REF_OFF_PREV_SIGNAL_TYPE": "silk_encoder_state.prevSignalType",
+    "OPUSGPU_REF_OFF_PREV_LAG": "silk_encoder_state.prevLag",
+    "OPUSGPU_REF_OFF_GAINS_INDICES": "SideInfoIndices.GainsIndices",
+    "OPUSGPU_REF_OFF_LAG_INDEX": "SideInfoIndices.lagIndex",
+    "OPUSGPU_REF_OFF_CONTOUR_INDEX": "SideInfoIndices.contourIndex",
+    "OPUSGPU_REF_OFF_FIX_SSHAPE": "silk_encoder_state_FIX.sShape",
+    "OPUSGPU_REF_OFF_FIX_SPREFILT": "silk_encoder_state_FIX.sPrefilt",
+    "OPUSGPU_REF_OFF_FIX_LTPCORR_Q15": "silk_encoder_state_FIX.LTPCorr_Q15",
+    "OPUSGPU_REF_OFF_SHAPE_LAST_GAIN_INDEX": "silk_shape_state_FIX.LastGainIndex",
+    "OPUSGPU_REF_OFF_SHAPE_HARM_BOOST_SMTH_Q16": "silk_shape_state_FIX.HarmBoost_smth_Q16",
+    "OPUSGPU_REF_OFF_SHAPE_HARM_SHAPE_GAIN_SMTH_Q16": "silk_shape_state_FIX.HarmShapeGain_smth_Q16",
+    "OPUSGPU_REF_OFF_SHAPE_TILT_SMTH_Q16": "silk_shape_state_FIX.Tilt_smth_Q16",
+    "OPUSGPU_REF_OFF_CTRL_AR1_Q13": "silk_encoder_control_FIX.AR1_Q13",
+    "OPUSGPU_REF_OFF_CTRL_AR2_Q13": "silk_encoder_control_FIX.AR2_Q13",
+    "OPUSGPU_REF_OFF_CTRL_LF_SHP_Q14": "silk_encoder_control_FIX.LF_shp_Q14",
+    "OPUSGPU_REF_OFF_CTRL_GAINS_PRE_Q14": "silk_encoder_control_FIX.GainsPre_Q14",
+    "OPUSGPU_REF_OFF_CTRL_HARM_BOOST_Q14": "silk_encoder_control_FIX.HarmBoost_Q14",
+    "OPUSGPU_REF_OFF_CTRL_TILT_Q14": "silk_encoder_control_FIX.Tilt_Q14",
+    "OPUSGPU_REF_OFF_CTRL_HARM_SHAPE_GAIN_Q14": "silk_encoder_control_FIX.HarmShapeGain_Q14",
+    "OPUSGPU_REF_OFF_CTRL_LAMBDA_Q10": "silk_encoder_control_FIX.Lambda_Q10",
+    "OPUSGPU_REF_OFF_CTRL_INPUT_QUALITY_Q14": "silk_encoder_control_FIX.input_quality_Q14",
+    "OPUSGPU_REF_OFF_CTRL_SPARSENESS_Q8": "silk_encoder_control_FIX.sparseness_Q8",
+    "OPUSGPU_REF_OFF_CTRL_PRED_GAIN_Q16": "silk_encoder_control_FIX.predGain_Q16",
+    "OPUSGPU_REF_OFF_CTRL_GAINS_UNQ_Q16": "silk_encoder_control_FIX.GainsUnq_Q16",
+    "OPUSGPU_REF_OFF_CTRL_LAST_GAIN_INDEX_PREV": "silk_encoder_control_FIX.lastGainIndexPrev",
+    "OPUSGPU_REF_SIZEOF_SILK_PREFILTER_STATE_FIX": "sizeof.silk_prefilter_state_FIX",
+    "OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE_FIX": "sizeof.silk_encoder_state_FIX",
 }
 
 
