@@ -1,0 +1,12 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun), second half of a round's evidence: kernel-trace stats of the SILK analysis-chain workloads
+# (each builds its corpus from the capture build of the reference first, outside any clock). usage: tools/round_profile_silk.sh <tag>
+TAG=${1:?tag}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for w in silk_frames silk_analysis silk_pred silk_nlsf; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > $O/bench_prof_$w.json 2> $O/prof_$w.err
+  echo "$w rc=$?"; cut -c1-200 $O/bench_prof_$w.json
+done
