@@ -43,7 +43,13 @@ CA_DEV void silk_prefilter_dev(PrefilterState &P, const PrefilterCtrl &c, XG x, 
         HarmShapeFIRPacked_Q12 |= shl32((i32)(HarmShapeGain_Q12 >> 1), 16);
         const int Tilt_Q14 = c.Tilt_Q14[k];
         const i32 LF_shp_Q14 = c.LF_shp_Q14[k];
-        const i16 *coef_Q13 = &c.AR1_Q13[k * MAX_SHAPE_LPC_ORDER];
+        i32 coef_Q13[MAX_SHAPE_LPC_ORDER];                                                  // this subframe's filter, in registers
+#pragma unroll
+        for (int i = 0; i < MAX_SHAPE_LPC_ORDER; i++) coef_Q13[i] = c.AR1_Q13[k * MAX_SHAPE_LPC_ORDER + i];
+        i32 coef_last = 0;                                                                  // coef_Q13[order - 1]
+#pragma unroll
+        for (int i = 1; i < MAX_SHAPE_LPC_ORDER; i += 2)
+            if (i == order - 1) coef_last = coef_Q13[i];
         const i32 B0 = (i16)s_rshift_round(c.GainsPre_Q14[k], 4);
         i32 tmp_32 = s_addw(3355443, s_smulbb(c.HarmBoost_Q14[k], HarmShapeGain_Q12));        // SILK_FIX_CONST(INPUT_TILT, 26)
         tmp_32 = s_addw(tmp_32, s_smulbb(c.coding_quality_Q14, 410));                           // SILK_FIX_CONST(HIGH_RATE_INPUT_TILT, 12)
@@ -62,16 +68,21 @@ CA_DEV void silk_prefilter_dev(PrefilterState &P, const PrefilterCtrl &c, XG x, 
             P.sAR_shp[1] = tmp2;
             i32 acc_Q11 = order >> 1;
             acc_Q11 = s_smlawb(acc_Q11, tmp2, coef_Q13[0]);
-            for (int i = 2; i < order; i += 2) {
-                tmp2 = s_smlawb(P.sAR_shp[i], s_subw(P.sAR_shp[i + 1], tmp1), lambda_Q16);
-                P.sAR_shp[i] = tmp1;
-                acc_Q11 = s_smlawb(acc_Q11, tmp1, coef_Q13[i - 1]);
-                tmp1 = s_smlawb(P.sAR_shp[i + 1], s_subw(P.sAR_shp[i + 2], tmp2), lambda_Q16);
-                P.sAR_shp[i + 1] = tmp2;
-                acc_Q11 = s_smlawb(acc_Q11, tmp2, coef_Q13[i]);
+#pragma unroll
+            for (int i = 2; i < MAX_SHAPE_LPC_ORDER; i += 2) {                              // unrolled: sAR_shp[] stays in registers
+                if (i < order) {
+                    tmp2 = s_smlawb(P.sAR_shp[i], s_subw(P.sAR_shp[i + 1], tmp1), lambda_Q16);
+                    P.sAR_shp[i] = tmp1;
+                    acc_Q11 = s_smlawb(acc_Q11, tmp1, coef_Q13[i - 1]);
+                    tmp1 = s_smlawb(P.sAR_shp[i + 1], s_subw(P.sAR_shp[i + 2], tmp2), lambda_Q16);
+                    P.sAR_shp[i + 1] = tmp2;
+                    acc_Q11 = s_smlawb(acc_Q11, tmp2, coef_Q13[i]);
+                }
             }
-            P.sAR_shp[order] = tmp1;
-            acc_Q11 = s_smlawb(acc_Q11, tmp1, coef_Q13[order - 1]);
+#pragma unroll
+            for (int i = 2; i <= MAX_SHAPE_LPC_ORDER; i += 2)
+                if (i == order) P.sAR_shp[i] = tmp1;
+            acc_Q11 = s_smlawb(acc_Q11, tmp1, coef_last);
             const i32 st_res_Q2 = s_subw(shl32(in, 2), s_rshift_round(acc_Q11, 9));
             // harmonic high-pass (:158-164)
             const i32 x_filt_Q12 = s_addw(s_mulw(st_res_Q2, B0), s_mulw(prev_res_Q2, B1));

@@ -59,27 +59,34 @@ CA_DEV void silk_warped_autocorrelation_dev(i32 *corr, int *scale, XA input, int
     i32 state_QS[MAX_SHAPE_LPC_ORDER + 1];
     i64 corr_QC[MAX_SHAPE_LPC_ORDER + 1];
     for (int i = 0; i <= MAX_SHAPE_LPC_ORDER; i++) { state_QS[i] = 0; corr_QC[i] = 0; }
+    // The section loop is unrolled to the maximum order with the trip test inside, so that state_QS[] / corr_QC[] are indexed
+    // by constants only and live in registers (a run-time index would put both arrays, 204 bytes per lane, in scratch memory).
     for (int n = 0; n < length; n++) {
         i32 tmp1_QS = shl32((i32)input[n], 14);
-        for (int i = 0; i < order; i += 2) {
-            const i32 tmp2_QS = s_smlawb(state_QS[i], s_subw(state_QS[i + 1], tmp1_QS), warping_Q16);
-            state_QS[i] = tmp1_QS;
-            corr_QC[i] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 14 - 10);
-            tmp1_QS = s_smlawb(state_QS[i + 1], s_subw(state_QS[i + 2], tmp2_QS), warping_Q16);
-            state_QS[i + 1] = tmp2_QS;
-            corr_QC[i + 1] += ((i64)tmp2_QS * state_QS[0]) >> (2 * 14 - 10);
+#pragma unroll
+        for (int i = 0; i < MAX_SHAPE_LPC_ORDER; i += 2) {
+            if (i < order) {
+                const i32 tmp2_QS = s_smlawb(state_QS[i], s_subw(state_QS[i + 1], tmp1_QS), warping_Q16);
+                state_QS[i] = tmp1_QS;
+                corr_QC[i] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 14 - 10);
+                tmp1_QS = s_smlawb(state_QS[i + 1], s_subw(state_QS[i + 2], tmp2_QS), warping_Q16);
+                state_QS[i + 1] = tmp2_QS;
+                corr_QC[i + 1] += ((i64)tmp2_QS * state_QS[0]) >> (2 * 14 - 10);
+                if (i + 2 == order) {                                                       // after the last section (:76-77)
+                    state_QS[i + 2] = tmp1_QS;
+                    corr_QC[i + 2] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 14 - 10);
+                }
+            }
         }
-        state_QS[order] = tmp1_QS;
-        corr_QC[order] += ((i64)tmp1_QS * state_QS[0]) >> (2 * 14 - 10);
     }
     const i32 c_hi = (i32)(corr_QC[0] >> 32);                                               // silk_CLZ64 (macros.h)
     int lsh = (c_hi == 0 ? 32 + s_clz32((i32)corr_QC[0]) : s_clz32(c_hi)) - 35;
     lsh = s_limit(lsh, -12 - 10, 30 - 10);
     *scale = -(10 + lsh);
-    if (lsh >= 0) {
-        for (int i = 0; i < order + 1; i++) corr[i] = (i32)(corr_QC[i] << lsh);
-    } else {
-        for (int i = 0; i < order + 1; i++) corr[i] = (i32)(corr_QC[i] >> -lsh);
+#pragma unroll
+    for (int i = 0; i <= MAX_SHAPE_LPC_ORDER; i++) {
+        const i32 v = lsh >= 0 ? (i32)(corr_QC[i] << lsh) : (i32)(corr_QC[i] >> -lsh);
+        if (i <= order) corr[i] = v;
     }
 }
 
