@@ -13,3 +13,5 @@ extern "C" void opusgpu_timing_end(int slot, hipStream_t s);
 extern "C" int opusgpu_lane_frames(void);
 // device counter of SILK records whose header failed the bounds checks (silk_validate.h); nullptr = allocation failed
 extern "C" int *opusgpu_bad_record_counter(void);
+// records per wavefront of the lane-per-record SILK analysis kernels that keep no per-lane LDS: 64, 32, 16 or 8 (OPUSGPU_SILK_LANES)
+extern "C" int opusgpu_silk_lanes_per_block(void);

@@ -126,3 +126,12 @@ extern "C" int opusgpu_silk_bad_records(void *stream)
         return OPUSGPU_INTERNAL_ERROR;
     return n;
 }
+
+// Records per wavefront of the scratch-resident SILK analysis kernels (silk_pitch_kernels.hip, silk_nlsf_kernels.hip). Read per
+// call so that tests and sweeps can compare the mappings.
+extern "C" int opusgpu_silk_lanes_per_block(void)
+{
+    const char *e = getenv("OPUSGPU_SILK_LANES");
+    const int v = e ? atoi(e) : 64;
+    return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 64;
+}

@@ -51,6 +51,40 @@ CA_DEV NlsfCB nlsf_codebook(int order)
     return cb;
 }
 
+// A workgroup's LDS copy of both codebooks (2.1 KB): the VQ, the entropy-table look-ups of the trellis and the decode read them
+// per lane at data-dependent addresses, a global / L2 round trip each otherwise.
+struct NlsfTablesLds {
+    u8 wb_cb1[512], wb_icdf[64], wb_pred[32], wb_ec_sel[256], wb_ec_icdf[72], wb_rates[72];
+    u8 nb_cb1[320], nb_icdf[64], nb_pred[20], nb_ec_sel[160], nb_ec_icdf[72], nb_rates[72];
+    i16 wb_delta[18], nb_delta[12];
+};
+
+CA_DEV void nlsf_stage_tables(NlsfTablesLds &T, int tid, int nthreads)
+{
+#define CA_NLSF_COPY(dst, src, n) for (int k = tid; k < (n); k += nthreads) (dst)[k] = (src)[k]
+    CA_NLSF_COPY(T.wb_cb1, SILK_NLSF_WB_CB1_Q8, 512); CA_NLSF_COPY(T.wb_icdf, SILK_NLSF_WB_CB1_iCDF, 64); CA_NLSF_COPY(T.wb_pred, SILK_NLSF_WB_pred_Q8, 30);
+    CA_NLSF_COPY(T.wb_ec_sel, SILK_NLSF_WB_ec_sel, 256); CA_NLSF_COPY(T.wb_ec_icdf, SILK_NLSF_WB_ec_iCDF, 72); CA_NLSF_COPY(T.wb_rates, SILK_NLSF_WB_ec_Rates_Q5, 72);
+    CA_NLSF_COPY(T.wb_delta, SILK_NLSF_WB_deltaMin_Q15, 17);
+    CA_NLSF_COPY(T.nb_cb1, SILK_NLSF_NB_MB_CB1_Q8, 320); CA_NLSF_COPY(T.nb_icdf, SILK_NLSF_NB_MB_CB1_iCDF, 64); CA_NLSF_COPY(T.nb_pred, SILK_NLSF_NB_MB_pred_Q8, 18);
+    CA_NLSF_COPY(T.nb_ec_sel, SILK_NLSF_NB_MB_ec_sel, 160); CA_NLSF_COPY(T.nb_ec_icdf, SILK_NLSF_NB_MB_ec_iCDF, 72); CA_NLSF_COPY(T.nb_rates, SILK_NLSF_NB_MB_ec_Rates_Q5, 72);
+    CA_NLSF_COPY(T.nb_delta, SILK_NLSF_NB_MB_deltaMin_Q15, 11);
+#undef CA_NLSF_COPY
+}
+
+CA_DEV NlsfCB nlsf_codebook(int order, const NlsfTablesLds *T)
+{
+    NlsfCB cb = nlsf_codebook(order);
+    if (!T) return cb;
+    if (order == 16) {
+        cb.CB1_Q8 = T->wb_cb1; cb.CB1_iCDF = T->wb_icdf; cb.pred_Q8 = T->wb_pred; cb.ec_sel = T->wb_ec_sel; cb.ec_iCDF = T->wb_ec_icdf;
+        cb.ec_Rates_Q5 = T->wb_rates; cb.deltaMin_Q15 = T->wb_delta;
+    } else {
+        cb.CB1_Q8 = T->nb_cb1; cb.CB1_iCDF = T->nb_icdf; cb.pred_Q8 = T->nb_pred; cb.ec_sel = T->nb_ec_sel; cb.ec_iCDF = T->nb_ec_icdf;
+        cb.ec_Rates_Q5 = T->nb_rates; cb.deltaMin_Q15 = T->nb_delta;
+    }
+    return cb;
+}
+
 CA_DEV i32 s_lin2log(i32 inLin)                                                            // lin2log.c:35-45, Inlines.h:56-66
 {
     const int lz = s_clz32(inLin);
@@ -357,9 +391,9 @@ CA_DEV i32 silk_NLSF_encode_dev(i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &c
 // silk_process_NLSFs (process_NLSFs.c:35-106). pNLSF_Q15: in = silk_find_LPC_FIX's NLSFs, out = the quantised ones.
 CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
                                    int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
-                                   int nSurvivors, int signalType)
+                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
 {
-    const NlsfCB cb = nlsf_codebook(order);
+    const NlsfCB cb = nlsf_codebook(order, tables);
     i16 pNLSF0_temp_Q15[SILK_MAX_LPC], pNLSFW_QW[SILK_MAX_LPC], pNLSFW0_temp_QW[SILK_MAX_LPC];
     // NLSF_mu = 0.003 - 0.001 * speech_activity  (SILK_FIX_CONST(0.003, 20) = 3146, SILK_FIX_CONST(-0.001, 28) = -268434)
     i32 NLSF_mu_Q20 = s_smlawb(3146, -268434, speech_activity_Q8);

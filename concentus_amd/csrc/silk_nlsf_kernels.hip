@@ -14,7 +14,10 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
                                                                 opusgpu_process_nlsf_out *__restrict__ outs, int n_rec,
                                                                 int *__restrict__ bad_records)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+    __shared__ NlsfTablesLds tables;
+    nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_process_nlsf_in in = recs[r];
     opusgpu_process_nlsf_out o;
@@ -30,7 +33,7 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
     for (int k = 0; k < SILK_MAX_LPC; k++) { nlsf[k] = in.NLSF_Q15[k]; prev[k] = in.prev_NLSFq_Q15[k]; pc[0][k] = pc[1][k] = 0; }
     for (int k = 0; k <= SILK_MAX_LPC; k++) idx[k] = 0;
     silk_process_NLSFs_dev(pc, idx, nlsf, prev, in.speech_activity_Q8, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
-                           in.NLSFInterpCoef_Q2, in.NLSF_MSVQ_Survivors, in.signalType);
+                           in.NLSFInterpCoef_Q2, in.NLSF_MSVQ_Survivors, in.signalType, &tables);
     for (int k = 0; k < in.predictLPCOrder; k++) { o.PredCoef_Q12[0][k] = pc[0][k]; o.PredCoef_Q12[1][k] = pc[1][k]; o.NLSF_Q15[k] = nlsf[k]; }
     for (int k = 0; k <= in.predictLPCOrder; k++) o.NLSFIndices[k] = idx[k];
     o.status = OPUSGPU_OK;
@@ -93,7 +96,8 @@ extern "C" int opusgpu_silk_process_nlsfs_batch(const opusgpu_process_nlsf_in *d
     if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
-    hipLaunchKernelGGL(silk_process_nlsfs_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
+    const int lpb = opusgpu_silk_lanes_per_block();
+    hipLaunchKernelGGL(silk_process_nlsfs_kernel, dim3((n + lpb - 1) / lpb), dim3(lpb), 0, (hipStream_t)stream, d_in, d_out, n, bad);
     return opusgpu_check_launch();
 }
 

@@ -13,7 +13,7 @@ __global__ __launch_bounds__(64) void silk_find_pitch_lags_kernel(const opusgpu_
                                                                   opusgpu_find_pitch_lags_out *__restrict__ outs, int n_rec,
                                                                   int *__restrict__ bad_records)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_find_pitch_lags_in &in = recs[r];
     opusgpu_find_pitch_lags_out &out = outs[r];
@@ -52,6 +52,9 @@ extern "C" int opusgpu_silk_find_pitch_lags_batch(const opusgpu_find_pitch_lags_
     if (!d_in || !d_out) return OPUSGPU_BAD_ARG;
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
-    hipLaunchKernelGGL(silk_find_pitch_lags_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n, bad);
+    // Lanes per wavefront: the kernel is bound by the latency of one frame's serial chain (its work arrays live in scratch memory),
+    // not by issue slots, so partially filled wavefronts -- more of them per SIMD -- hide that latency (OPUSGPU_SILK_LANES=16/32/64).
+    const int lpb = opusgpu_silk_lanes_per_block();
+    hipLaunchKernelGGL(silk_find_pitch_lags_kernel, dim3((n + lpb - 1) / lpb), dim3(lpb), 0, (hipStream_t)stream, d_in, d_out, n, bad);
     return opusgpu_check_launch();
 }

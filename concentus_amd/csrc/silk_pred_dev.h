@@ -30,7 +30,7 @@ struct PredCoefsCfg {                                   // the psEnc / psEncCtrl
 
 // res_pitch: index 0 = res_pitch[0]; x: index 0 = the reference's x[0] (the frame), negative indices reach into x_buf.
 template <class XG, class PRE>
-CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, PredCoefsOut &o)
+CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr)
 {
     const int order = c.predictLPCOrder, nb = c.nb_subfr, L = c.subfr_length;
     i32 invGains_Q16[4], local_gains[4], Wght_Q15[4];
@@ -81,7 +81,7 @@ CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, 
     o.NLSFInterpCoef_Q2 = silk_find_LPC_dev(pre, minInvGain_Q30, L, nb, order, c.useInterpolatedNLSFs, c.first_frame_after_reset,
                                             c.prev_NLSFq_Q15, o.NLSF_Q15);
     silk_process_NLSFs_dev(o.PredCoef_Q12, o.NLSFIndices, o.NLSF_Q15, c.prev_NLSFq_Q15, c.speech_activity_Q8, nb, order,
-                           c.useInterpolatedNLSFs, o.NLSFInterpCoef_Q2, c.NLSF_MSVQ_Survivors, c.signalType);
+                           c.useInterpolatedNLSFs, o.NLSFInterpCoef_Q2, c.NLSF_MSVQ_Survivors, c.signalType, tables);
     silk_residual_energy_dev(o.ResNrg, o.ResNrgQ, pre, o.PredCoef_Q12, local_gains, L, nb, order);
 }
 

@@ -23,6 +23,9 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
                                                                   int *__restrict__ bad_records)
 {
     __shared__ i16 pre_s[OPUSGPU_SILK_BURG_MAX_X * 64];
+    __shared__ NlsfTablesLds tables;
+    nlsf_stage_tables(tables, threadIdx.x, 64);
+    __syncthreads();
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_find_pred_coefs_in &in = recs[r];
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     memset(&o, 0, sizeof(o));
     PreCol pre;
     pre.p = pre_s + threadIdx.x;
-    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, pre, o);
+    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, pre, o, &tables);
     const int order = in.predictLPCOrder, nb = in.nb_subfr;
     memset(&out, 0, sizeof(out));
     for (int k = 0; k < order; k++) { out.PredCoef_Q12[0][k] = o.PredCoef_Q12[0][k]; out.PredCoef_Q12[1][k] = o.PredCoef_Q12[1][k]; out.NLSF_Q15[k] = o.NLSF_Q15[k]; }
