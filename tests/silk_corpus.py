@@ -23,6 +23,7 @@ ROOT = os.path.dirname(HERE)
 CAPLIB = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_silkcap.so")
 FS = 16000
 FRAME = 320
+VARIANTS = {"wb20": (16000, 320), "nb20": (8000, 160), "wb10": (16000, 160)}     # (input rate, samples per opus_encode call)
 SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder each)
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
@@ -95,12 +96,13 @@ def _p(a):
 def _capture_segment(args):
     """Worker: encode SEG_FRAMES + WARMUP frames of synth_voice(seed) with a fresh reference encoder and write the
     records of frames [WARMUP, WARMUP + take) into rows [row0, row0 + take) of the corpus files."""
-    cache, kind, seed, complexity, row0, take, total = args
+    cache, kind, seed, complexity, row0, take, total, variant = args
+    fs, frame = VARIANTS[variant]
     lib = C.CDLL(CAPLIB)
     lib.opus_encoder_create.restype = C.c_void_p
     lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
     nfr = take + WARMUP
-    pcm = synth_voice(nfr * FRAME, seed)
+    pcm = synth_voice(nfr * frame * (FS // fs), seed)[::FS // fs]          # 8 kHz: every second sample of the 16 kHz synthesis
     cap = 3 * nfr + 16
     if kind.startswith("chain"):
         lib.refcap_start_chain(4 * nfr + 16)
@@ -123,14 +125,14 @@ def _capture_segment(args):
     else:
         lib.refcap_start(cap)
     err = C.c_int()
-    enc = C.c_void_p(lib.opus_encoder_create(FS, 1, 2048, C.byref(err)))          # OPUS_APPLICATION_VOIP
+    enc = C.c_void_p(lib.opus_encoder_create(fs, 1, 2048, C.byref(err)))          # OPUS_APPLICATION_VOIP
     assert enc and err.value == 0
     for req, v in ((4002, 32000), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
         lib.opus_encoder_ctl(enc, req, v)
     out = (C.c_ubyte * 1500)()
     for f in range(nfr):
-        fr = np.ascontiguousarray(pcm[f * FRAME:(f + 1) * FRAME])
-        assert lib.opus_encode(enc, _p(fr), FRAME, out, 1500) > 0
+        fr = np.ascontiguousarray(pcm[f * frame:(f + 1) * frame])
+        assert lib.opus_encode(enc, _p(fr), frame, out, 1500) > 0
     files = _files(cache, kind, total, mode="r+")
     if kind.startswith("chain"):
         dd = kind == "chain_dd"
@@ -294,7 +296,7 @@ def _files(cache, kind, n, mode):
     return out
 
 
-def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=20260401):
+def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=20260401, variant="wb20"):
     """n distinct records: kind "nsq" -> burg_in/burg_out/nsq_in/nsq_state_in/nsq_state_out/nsq_out captured at
     complexity 3 (silk_NSQ_c, control_codec.c:333-343); kind "dd" -> dd_in/dd_state_in/dd_state_out/dd_out captured at
     complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
@@ -306,7 +308,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     complexities = complexities or ((3,) if kind in ("nsq", "chain_nsq") else (5, 7, 10) if kind in ("dd", "chain_dd") else (3, 5, 8, 10))
     # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
     cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
-                         "%s_%d_%s_%d" % (kind, n, "-".join(map(str, complexities)), seed))
+                         "%s_%d_%s_%d%s" % (kind, n, "-".join(map(str, complexities)), seed, "" if variant == "wb20" else "_" + variant))
     os.makedirs(cache, exist_ok=True)
     done = os.path.join(cache, "done")
     if not os.path.exists(done):
@@ -317,7 +319,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
             jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
-                         row, take, n))
+                         row, take, n, variant))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))
         if workers == 1:

@@ -20,22 +20,23 @@ from concentus_amd import silk as S
 FID = {"pitch": 0, "shape": 1, "fpc": 2, "gains": 3, "prefilter": 4, "nsq": 5, "dd": 6}
 
 
-def _capture(complexity, nframes, seed):
+def _capture(complexity, nframes, seed, variant="wb20"):
     lib = C.CDLL(silk_corpus.CAPLIB)
     lib.opus_encoder_create.restype = C.c_void_p
     lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
     cap = 4 * nframes + 16
     lib.refcap_start_chain(cap)
     err = C.c_int()
-    enc = C.c_void_p(lib.opus_encoder_create(16000, 1, 2048, C.byref(err)))
+    fs, frame = silk_corpus.VARIANTS[variant]
+    enc = C.c_void_p(lib.opus_encoder_create(fs, 1, 2048, C.byref(err)))
     assert enc and err.value == 0
     for req, v in ((4002, 32000), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
         lib.opus_encoder_ctl(enc, req, v)
-    pcm = silk_corpus.synth_voice(nframes * 320, seed)
+    pcm = silk_corpus.synth_voice(nframes * frame * (16000 // fs), seed)[::16000 // fs]
     out = (C.c_ubyte * 1500)()
     for f in range(nframes):
-        fr = np.ascontiguousarray(pcm[f * 320:(f + 1) * 320])
-        assert lib.opus_encode(enc, fr.ctypes.data_as(C.c_void_p), 320, out, 1500) > 0
+        fr = np.ascontiguousarray(pcm[f * frame:(f + 1) * frame])
+        assert lib.opus_encode(enc, fr.ctypes.data_as(C.c_void_p), frame, out, 1500) > 0
     p = lambda a: a.ctypes.data_as(C.c_void_p)
 
     def grab(count, getter, classes):
@@ -76,12 +77,12 @@ def _first_of_frame(fid, frame):
 
 
 @pytest.mark.ref
-@pytest.mark.parametrize("complexity", [3, 8])
-def test_every_record_field_is_an_output_of_an_earlier_call(complexity):
+@pytest.mark.parametrize("complexity,variant", [(3, "wb20"), (8, "wb20"), (7, "nb20"), (5, "wb10")])
+def test_every_record_field_is_an_output_of_an_earlier_call(complexity, variant):
     if not silk_corpus.available():
         pytest.skip("oracle/_ref/libopus_ref_silkcap.so not built")
     nframes = 160
-    r = _capture(complexity, nframes, 424242 + complexity)
+    r = _capture(complexity, nframes, 424242 + complexity, variant)
     (pin, pout, pf), (sin_, sout, sf), (fin, fout, ff), (gin, gout, gf), (xin, xst0, xst1, xout, xf), (qin, qf) = (
         r["pitch"], r["shape"], r["fpc"], r["gains"], r["prefilter"], r["q"])
     eq = np.array_equal
@@ -96,7 +97,8 @@ def test_every_record_field_is_an_output_of_an_earlier_call(complexity):
         seen_voiced += voiced
         # ---- noise_shape_analysis <- find_pitch_lags (+ the input buffer)
         assert eq(SI["pitch_res"][:fl], PO["res"][ltp:ltp + fl])
-        assert eq(SI["x"][:la_s + fl + 32], P["x_buf"][ltp - la_s:ltp + fl + 32])          # the part of x_buf both records hold
+        lap = int(P["la_pitch"])
+        assert eq(SI["x"][:la_s + fl + lap], P["x_buf"][ltp - la_s:ltp + fl + lap])        # the part of x_buf both records hold
         assert int(SI["signalType"]) == int(PO["signalType"]) and int(SI["LTPCorr_Q15"]) == int(PO["LTPCorr_Q15"])
         assert int(SI["predGain_Q16"]) == int(PO["predGain_Q16"]) and eq(SI["pitchL"][:nb], PO["pitchL"][:nb])
         # ---- find_pred_coefs <- find_pitch_lags, noise_shape_analysis

@@ -17,8 +17,8 @@ def _bytes(a):
     return np.ascontiguousarray(a).view(np.uint8).reshape(a.shape[0], -1)
 
 
-@pytest.mark.parametrize("complexity", [3, 5, 10])
-def test_chain_from_pitch_buffer_to_pulses(complexity):
+@pytest.mark.parametrize("complexity,variant", [(3, "wb20"), (5, "wb20"), (10, "wb20"), (8, "nb20"), (6, "wb10")])
+def test_chain_from_pitch_buffer_to_pulses(complexity, variant):
     import torch
     import concentus_amd as ca
     from concentus_amd import silk as S
@@ -26,7 +26,7 @@ def test_chain_from_pitch_buffer_to_pulses(complexity):
     if not silk_corpus.available():
         pytest.skip("capture library did not travel")
     nframes = 700
-    r = _capture(complexity, nframes, 9000 + complexity)
+    r = _capture(complexity, nframes, 9000 + complexity, variant)
     (pin, pout, pf), (sin_, sout, sf), (fin, fout, ff), (gin, gout, gf), (xin, xst0, xst1, xout, xf), (_, qf) = (
         r["pitch"], r["shape"], r["fpc"], r["gains"], r["prefilter"], r["q"])
     qin, qst0, qst1, qout, del_dec = r["q_full"]
@@ -47,7 +47,7 @@ def test_chain_from_pitch_buffer_to_pulses(complexity):
     dev = {k: torch.from_numpy(v.copy()).cuda() for k, v in rec.items()}
     pf_state = torch.from_numpy(_bytes(xst0[sel["x"]]).copy()).cuda()
     nsq_state = torch.from_numpy(_bytes(qst0[sel["q"]]).copy()).cuda()
-    out = SilkAnalysisChain(16, 4).run(dev["pitch_in"], dev["shape_in"], dev["fpc_in"], dev["gains_in"], dev["prefilter_in"], pf_state,
+    out = SilkAnalysisChain(8 if variant == "nb20" else 16, 2 if variant == "wb10" else 4).run(dev["pitch_in"], dev["shape_in"], dev["fpc_in"], dev["gains_in"], dev["prefilter_in"], pf_state,
                                        dev["q_in"], nsq_state, del_dec)
     torch.cuda.synchronize()
     assert ca.silk.bad_records() == 0

@@ -470,3 +470,34 @@ def test_find_pitch_lags_32768_distinct_records_vs_reference_outputs(ca):
     assert ca.silk.bad_records() == 2
     good = np.setdiff1d(np.arange(256), [3, 10])
     assert np.array_equal(o2[good, :1380], want[:256][good, :1380]) and (o2[[3, 10], 1380:1384].view(np.int32) == -1).all()
+
+
+@pytest.mark.parametrize("variant", ["nb20", "wb10"])
+def test_analysis_kernels_at_8_kHz_and_with_10_ms_frames(ca, variant):
+    """The six analysis kernels on records captured from the reference at its other operating points (tests/silk_corpus.py
+    variants: 8 kHz narrowband input -> order 10, NB/MB codebook, stage-2-only pitch search; 10 ms frames -> nb_subfr 2),
+    4 096 records each, every field compared; cf. tests/test_silk_variants_cpu.py."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    ops = (("lpc", "lpc_in", "lpc_out", 36, lambda r: ca.silk_find_LPC(_dev(r["lpc_in"]))),
+           ("fpc", "fpc_in", "fpc_out", 204, lambda r: ca.silk_find_pred_coefs(_dev(r["fpc_in"]))),
+           ("gains", "gains_in", "gains_out", 52, lambda r: ca.silk_process_gains(_dev(r["gains_in"]))),
+           ("shape", "shape_in", "shape_out", 380, lambda r: ca.silk_noise_shape_analysis(_dev(r["shape_in"]))),
+           ("pitch", "pitch_in", "pitch_out", 1380, lambda r: ca.silk_find_pitch_lags(_dev(r["pitch_in"]))))
+    ca.silk.bad_records()
+    for kind, ik, ok, nb, run in ops:
+        rec = silk_corpus.corpus(4096, kind, variant=variant, complexities=(4, 9))
+        out = run(rec)
+        torch.cuda.synchronize()
+        out = out.cpu().numpy()
+        want = np.asarray(rec[ok])
+        bad = np.nonzero((out[:, :nb] != want[:, :nb]).any(1))[0]
+        assert bad.size == 0, (kind, variant, bad.size, bad[:6])
+    rec = silk_corpus.corpus(4096, "prefilter", variant=variant, complexities=(4, 9))
+    st = _dev(rec["prefilter_state_in"])
+    out = ca.silk_prefilter(_dev(rec["prefilter_in"]), st).cpu().numpy()
+    assert np.array_equal(out[:, :1280], np.asarray(rec["prefilter_out"])[:, :1280])
+    assert np.array_equal(st.cpu().numpy(), np.asarray(rec["prefilter_state_out"]))
+    assert ca.silk.bad_records() == 0
