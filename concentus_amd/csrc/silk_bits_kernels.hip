@@ -1,0 +1,64 @@
+// silk_bits_kernels.hip -- batched silk_encode_indices + silk_encode_pulses (opus-fix/silk/encode_indices.c:36, encode_pulses.c:64): side
+// information and excitation of one SILK frame onto the Opus range coder, one lane per frame; the arithmetic lives in
+// silk_bits_dev.h, the coder in rangecoder.h (lane build: every lane writes its own buffer).
+#define CA_LANE_FRAME 1
+#include <string.h>
+#include "silk_bits_dev.h"
+#include "opusgpu_internal.h"
+#include "../../include/opusgpu_silk.h"
+#include "silk_validate.h"
+
+namespace ca {
+
+__global__ __launch_bounds__(64) void silk_encode_bits_kernel(const opusgpu_silk_bits_in *__restrict__ recs, opusgpu_ec_state *__restrict__ ecs,
+                                                              opusgpu_silk_bits_out *__restrict__ outs, int n_rec, int *__restrict__ bad_records)
+{
+    __shared__ NlsfTablesLds tables;
+    nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const opusgpu_silk_bits_in &in = recs[r];
+    opusgpu_ec_state &st = ecs[r];
+    opusgpu_silk_bits_out o;
+    o.ec_prevSignalType = in.ec_prevSignalType; o.ec_prevLagIndex = in.ec_prevLagIndex; o.status = OPUSGPU_OK; o.reserved = 0;
+    if (!silk_bits_record_ok(in, st)) {
+        o.status = OPUSGPU_BAD_ARG;
+        outs[r] = o;
+        atomicAdd(bad_records, 1);
+        return;
+    }
+    RangeEnc ec;
+    ec.buf = st.buf; ec.storage = st.storage; ec.end_offs = st.end_offs; ec.end_window = st.end_window; ec.nend_bits = st.nend_bits;
+    ec.nbits_total = st.nbits_total; ec.offs = st.offs; ec.rng = st.rng; ec.val = st.val; ec.ext = st.ext; ec.rem = st.rem; ec.error = st.error;
+    if (in.which & 1) {
+        SilkIndices ix;
+        for (int k = 0; k < 4; k++) { ix.GainsIndices[k] = in.GainsIndices[k]; ix.LTPIndex[k] = in.LTPIndex[k]; }
+        for (int k = 0; k <= SILK_MAX_LPC; k++) ix.NLSFIndices[k] = in.NLSFIndices[k];
+        ix.lagIndex = in.lagIndex; ix.contourIndex = in.contourIndex; ix.signalType = in.signalType; ix.quantOffsetType = in.quantOffsetType;
+        ix.NLSFInterpCoef_Q2 = in.NLSFInterpCoef_Q2; ix.PERIndex = in.PERIndex; ix.LTP_scaleIndex = in.LTP_scaleIndex; ix.Seed = in.Seed;
+        silk_encode_indices_dev(ec, ix, in.nb_subfr, in.fs_kHz, in.predictLPCOrder, in.condCoding, o.ec_prevSignalType, o.ec_prevLagIndex, &tables);
+    }
+    if (in.which & 2) {
+        u8 absq[OPUSGPU_SILK_MAX_FRAME];
+        silk_encode_pulses_dev(ec, in.signalType, in.quantOffsetType, (const i8 *)in.pulses, in.frame_length, absq);
+    }
+    st.end_offs = ec.end_offs; st.end_window = ec.end_window; st.nend_bits = ec.nend_bits; st.nbits_total = ec.nbits_total; st.offs = ec.offs;
+    st.rng = ec.rng; st.val = ec.val; st.ext = ec.ext; st.rem = ec.rem; st.error = ec.error;
+    outs[r] = o;
+}
+
+}  // namespace ca
+
+using namespace ca;
+
+extern "C" int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, opusgpu_ec_state *d_ec, opusgpu_silk_bits_out *d_out, int n, void *stream)
+{
+    if (n < 0) return OPUSGPU_BAD_ARG;
+    if (n == 0) return OPUSGPU_OK;
+    if (!d_in || !d_ec || !d_out) return OPUSGPU_BAD_ARG;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_ec, d_out, n, bad);
+    return opusgpu_check_launch();
+}

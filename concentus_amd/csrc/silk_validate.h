@@ -111,6 +111,34 @@ __device__ __forceinline__ bool find_pitch_lags_record_ok(const opusgpu_find_pit
     return true;
 }
 
+__device__ __forceinline__ bool silk_bits_record_ok(const opusgpu_silk_bits_in &in, const opusgpu_ec_state &ec)
+{
+    const int fs = in.fs_kHz, n = in.nb_subfr, D = in.predictLPCOrder;
+    if (!((fs == 8 || fs == 12 || fs == 16) && (n == 2 || n == 4) && (D == 10 || D == 16) && in.which >= 1 && in.which <= 3)) return false;
+    if (in.frame_length < 16 || in.frame_length > OPUSGPU_SILK_MAX_FRAME || (in.frame_length & 15)) return false;
+    if (ec.storage > OPUSGPU_EC_BUF || ec.offs > ec.storage || ec.end_offs > ec.storage || ec.rng <= 0x00800000u) return false;
+    if ((unsigned)in.signalType > 2u || (unsigned)in.quantOffsetType > 1u || (unsigned)in.condCoding > 2u || (unsigned)in.Seed > 3u) return false;
+    if (in.which & 1) {                                          // every symbol must lie inside its probability model
+        const int cond = in.condCoding == 2;
+        if (in.signalType == 0 && in.quantOffsetType > 1) return false;
+        if (in.GainsIndices[0] < 0 || in.GainsIndices[0] >= (cond ? 41 : 64)) return false;
+        for (int k = 1; k < n; k++)
+            if (in.GainsIndices[k] < 0 || in.GainsIndices[k] >= 41) return false;
+        if (in.NLSFIndices[0] < 0 || in.NLSFIndices[0] >= 32) return false;
+        for (int k = 1; k <= D; k++)
+            if (in.NLSFIndices[k] < -10 || in.NLSFIndices[k] > 10) return false;
+        if ((unsigned)in.NLSFInterpCoef_Q2 > 4u) return false;
+        if (in.signalType == 2) {
+            const int ncont = n == 4 ? (fs == 8 ? 11 : 34) : (fs == 8 ? 3 : 12);
+            if (in.lagIndex < 0 || in.lagIndex >= 16 * fs || in.contourIndex < 0 || in.contourIndex >= ncont) return false;
+            if ((unsigned)in.PERIndex > 2u || (unsigned)in.LTP_scaleIndex > 2u) return false;
+            for (int k = 0; k < n; k++)
+                if (in.LTPIndex[k] < 0 || in.LTPIndex[k] >= (8 << in.PERIndex)) return false;
+        }
+    }
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

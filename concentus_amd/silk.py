@@ -347,3 +347,46 @@ def silk_find_pitch_lags(pitch_in, pitch_out=None):
     (res int16[672], pitchL, lagIndex, contourIndex, LTPCorr_Q15, signalType, predGain_Q16, status)."""
     return _record_op("opusgpu_silk_find_pitch_lags_batch", pitch_in, pitch_out, SIZES["find_pitch_lags_in"], SIZES["find_pitch_lags_out"],
                       "pitch")
+
+
+class EcState(C.Structure):
+    """opusgpu_ec_state: the reference's ec_ctx (opus-fix/celt/entcode.h:63-94) as a record, buffer included."""
+    _fields_ = [("storage", C.c_uint32), ("end_offs", C.c_uint32), ("end_window", C.c_uint32), ("nend_bits", C.c_int32), ("nbits_total", C.c_int32),
+                ("offs", C.c_uint32), ("rng", C.c_uint32), ("val", C.c_uint32), ("ext", C.c_uint32), ("rem", C.c_int32), ("error", C.c_int32),
+                ("reserved", C.c_uint32), ("buf", C.c_uint8 * 1280)]
+
+
+class SilkBitsIn(C.Structure):
+    """opusgpu_silk_bits_in: one silk_encode_indices() and / or silk_encode_pulses() call (opus-fix/silk/encode_indices.c:36,
+    silk/encode_pulses.c:64)."""
+    _fields_ = [("pulses", C.c_int8 * 320), ("GainsIndices", C.c_int8 * 4), ("LTPIndex", C.c_int8 * 4), ("NLSFIndices", C.c_int8 * 17),
+                ("pad", C.c_int8 * 3)] + [(k, C.c_int32) for k in (
+                    "lagIndex", "contourIndex", "signalType", "quantOffsetType", "NLSFInterpCoef_Q2", "PERIndex", "LTP_scaleIndex", "Seed",
+                    "nb_subfr", "fs_kHz", "predictLPCOrder", "frame_length", "condCoding", "ec_prevSignalType", "ec_prevLagIndex", "which",
+                    "reserved")]
+
+
+class SilkBitsOut(C.Structure):
+    _fields_ = [("ec_prevSignalType", C.c_int32), ("ec_prevLagIndex", C.c_int32), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+SIZES["silk_bits_in"] = C.sizeof(SilkBitsIn)
+SIZES["ec_state"] = C.sizeof(EcState)
+SIZES["silk_bits_out"] = C.sizeof(SilkBitsOut)
+
+
+def silk_encode_bits(bits_in, ec_state, bits_out=None):
+    """silk_encode_indices() / silk_encode_pulses() over a batch of records: bits_in uint8 [N][416], ec_state uint8 [N][1328] (the range
+    coder of each frame, updated in place: fields and written bytes) -> uint8 [N][16] (ec_prevSignalType, ec_prevLagIndex, status)."""
+    import torch
+    _check(bits_in, SIZES["silk_bits_in"], "bits_in")
+    _check(ec_state, SIZES["ec_state"], "ec_state")
+    n = bits_in.shape[0]
+    if ec_state.shape[0] != n:
+        raise ValueError("ec_state: %d records for %d inputs" % (ec_state.shape[0], n))
+    if bits_out is None:
+        bits_out = torch.empty((n, SIZES["silk_bits_out"]), dtype=torch.uint8, device=bits_in.device)
+    _check(bits_out, SIZES["silk_bits_out"], "bits_out")
+    rc = _lib.load().opusgpu_silk_encode_bits_batch(bits_in.data_ptr(), ec_state.data_ptr(), bits_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_encode_bits_batch")
+    return bits_out

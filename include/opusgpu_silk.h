@@ -338,6 +338,42 @@ typedef struct opusgpu_find_pitch_lags_out {
 
 int opusgpu_silk_find_pitch_lags_batch(const opusgpu_find_pitch_lags_in *d_in, opusgpu_find_pitch_lags_out *d_out, int n, void *hip_stream);
 
+/* ---- silk_encode_indices + silk_encode_pulses, batched (eighth slice) -------------------------------------
+ * Replace silk_encode_indices(psEncC, psRangeEnc, FrameIndex, 0, condCoding) (opus-fix/silk/encode_indices.c:36-193) and
+ * silk_encode_pulses(psRangeEnc, signalType, quantOffsetType, pulses, frame_length) (silk/encode_pulses.c:64-206, with the shell
+ * and sign coders), the two calls silk_encode_frame_FIX makes after the quantiser (silk/fixed/encode_frame_FIX.c:328-336): the
+ * side information and the excitation of one frame onto the Opus range coder. The range coder travels as a record: the fields
+ * of the reference's ec_ctx (celt/entcode.h:63-94) and its buffer (head bytes [0, offs), tail bytes [storage - end_offs,
+ * storage)), updated in place. `which`: 1 = indices only, 2 = pulses only, 3 = both, in that order. frame_length a multiple of
+ * 16 (8 / 16 kHz). */
+#define OPUSGPU_EC_BUF 1280
+typedef struct opusgpu_ec_state {
+    uint32_t storage, end_offs, end_window;
+    int32_t nend_bits, nbits_total;
+    uint32_t offs, rng, val, ext;
+    int32_t rem, error;
+    uint32_t reserved;
+    uint8_t buf[OPUSGPU_EC_BUF];             /* storage <= OPUSGPU_EC_BUF */
+} opusgpu_ec_state;
+
+typedef struct opusgpu_silk_bits_in {
+    int8_t pulses[OPUSGPU_SILK_MAX_FRAME];
+    int8_t GainsIndices[4], LTPIndex[4], NLSFIndices[OPUSGPU_SILK_MAX_ORDER + 1], pad[3];
+    int32_t lagIndex, contourIndex, signalType, quantOffsetType;
+    int32_t NLSFInterpCoef_Q2, PERIndex, LTP_scaleIndex, Seed;
+    int32_t nb_subfr, fs_kHz, predictLPCOrder, frame_length;
+    int32_t condCoding, ec_prevSignalType, ec_prevLagIndex, which;
+    int32_t reserved;
+} opusgpu_silk_bits_in;
+
+typedef struct opusgpu_silk_bits_out {
+    int32_t ec_prevSignalType, ec_prevLagIndex;   /* psEncC->ec_prevSignalType / ec_prevLagIndex after silk_encode_indices */
+    int32_t status, reserved;
+} opusgpu_silk_bits_out;
+
+int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, opusgpu_ec_state *d_ec, opusgpu_silk_bits_out *d_out, int n,
+                                   void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX,--wrap=silk_encode_indices,--wrap=silk_encode_pulses into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -534,4 +534,73 @@ void refcap_start_chain(int max_records)
     refcap_start_shape(max_records); refcap_start_prefilter(max_records); refcap_start_pitch(max_records);
     g_frame = 0; g_fid_cap = max_records;
     for (int k = 0; k < FID_KINDS; k++) g_fid[k] = (int *)calloc(max_records, sizeof(int));
+}
+
+/* ---- silk_encode_indices / silk_encode_pulses (opus-fix/silk/encode_indices.c:36, encode_pulses.c:64): arguments, the fields read, and the
+ * range coder (every ec_ctx field + its buffer) before and after ---- */
+#include "entenc.h"
+static opusgpu_silk_bits_in *g_bi_in, *g_bp_in; static opusgpu_ec_state *g_bi_ec0, *g_bi_ec1, *g_bp_ec0, *g_bp_ec1;
+static opusgpu_silk_bits_out *g_bi_out, *g_bp_out; static int g_nbi, g_nbp, g_capbits;
+void refcap_start_bits(int max_records)
+{
+    g_capbits = max_records; g_nbi = g_nbp = 0; g_on = 1;
+    g_bi_in = (opusgpu_silk_bits_in *)calloc(max_records, sizeof(*g_bi_in)); g_bp_in = (opusgpu_silk_bits_in *)calloc(max_records, sizeof(*g_bp_in));
+    g_bi_ec0 = (opusgpu_ec_state *)calloc(max_records, sizeof(*g_bi_ec0)); g_bi_ec1 = (opusgpu_ec_state *)calloc(max_records, sizeof(*g_bi_ec1));
+    g_bp_ec0 = (opusgpu_ec_state *)calloc(max_records, sizeof(*g_bp_ec0)); g_bp_ec1 = (opusgpu_ec_state *)calloc(max_records, sizeof(*g_bp_ec1));
+    g_bi_out = (opusgpu_silk_bits_out *)calloc(max_records, sizeof(*g_bi_out)); g_bp_out = (opusgpu_silk_bits_out *)calloc(max_records, sizeof(*g_bp_out));
+}
+int refcap_count_bits(int which) { return which == 0 ? g_nbi : g_nbp; }
+int refcap_sizes_bits(int which) { return which == 0 ? sizeof(opusgpu_silk_bits_in) : which == 1 ? sizeof(opusgpu_ec_state) : sizeof(opusgpu_silk_bits_out); }
+void refcap_get_bits(int which, void *in, void *ec0, void *ec1, void *out)
+{
+    const int n = which == 0 ? g_nbi : g_nbp;
+    memcpy(in, which == 0 ? g_bi_in : g_bp_in, (size_t)n * sizeof(opusgpu_silk_bits_in));
+    memcpy(ec0, which == 0 ? g_bi_ec0 : g_bp_ec0, (size_t)n * sizeof(opusgpu_ec_state));
+    memcpy(ec1, which == 0 ? g_bi_ec1 : g_bp_ec1, (size_t)n * sizeof(opusgpu_ec_state));
+    memcpy(out, which == 0 ? g_bi_out : g_bp_out, (size_t)n * sizeof(opusgpu_silk_bits_out));
+}
+static void ec_snapshot(opusgpu_ec_state *d, const ec_enc *e)
+{
+    memset(d, 0, sizeof(*d));
+    d->storage = e->storage; d->end_offs = e->end_offs; d->end_window = e->end_window; d->nend_bits = e->nend_bits; d->nbits_total = e->nbits_total;
+    d->offs = e->offs; d->rng = e->rng; d->val = e->val; d->ext = e->ext; d->rem = e->rem; d->error = e->error;
+    memcpy(d->buf, e->buf, e->offs);                                                    /* head bytes */
+    memcpy(d->buf + e->storage - e->end_offs, e->buf + e->storage - e->end_offs, e->end_offs);   /* tail bytes */
+}
+
+void __real_silk_encode_indices(silk_encoder_state *psEncC, ec_enc *psRangeEnc, opus_int FrameIndex, opus_int encode_LBRR, opus_int condCoding);
+void __wrap_silk_encode_indices(silk_encoder_state *psEncC, ec_enc *psRangeEnc, opus_int FrameIndex, opus_int encode_LBRR, opus_int condCoding)
+{
+    int rec = (g_on && g_bi_in && g_nbi < g_capbits && !encode_LBRR && psRangeEnc->storage <= OPUSGPU_EC_BUF) ? g_nbi : -1;
+    if (rec >= 0) {
+        opusgpu_silk_bits_in *r = &g_bi_in[rec];
+        const SideInfoIndices *ix = &psEncC->indices;
+        memcpy(r->GainsIndices, ix->GainsIndices, 4); memcpy(r->LTPIndex, ix->LTPIndex, 4); memcpy(r->NLSFIndices, ix->NLSFIndices, MAX_LPC_ORDER + 1);
+        r->lagIndex = ix->lagIndex; r->contourIndex = ix->contourIndex; r->signalType = ix->signalType; r->quantOffsetType = ix->quantOffsetType;
+        r->NLSFInterpCoef_Q2 = ix->NLSFInterpCoef_Q2; r->PERIndex = ix->PERIndex; r->LTP_scaleIndex = ix->LTP_scaleIndex; r->Seed = ix->Seed;
+        r->nb_subfr = psEncC->nb_subfr; r->fs_kHz = psEncC->fs_kHz; r->predictLPCOrder = psEncC->predictLPCOrder; r->frame_length = psEncC->frame_length;
+        r->condCoding = condCoding; r->ec_prevSignalType = psEncC->ec_prevSignalType; r->ec_prevLagIndex = psEncC->ec_prevLagIndex; r->which = 1;
+        ec_snapshot(&g_bi_ec0[rec], psRangeEnc);
+    }
+    __real_silk_encode_indices(psEncC, psRangeEnc, FrameIndex, encode_LBRR, condCoding);
+    if (rec >= 0) {
+        ec_snapshot(&g_bi_ec1[rec], psRangeEnc);
+        g_bi_out[rec].ec_prevSignalType = psEncC->ec_prevSignalType; g_bi_out[rec].ec_prevLagIndex = psEncC->ec_prevLagIndex;
+        g_nbi++;
+    }
+}
+
+void __real_silk_encode_pulses(ec_enc *psRangeEnc, const opus_int signalType, const opus_int quantOffsetType, opus_int8 pulses[], const opus_int frame_length);
+void __wrap_silk_encode_pulses(ec_enc *psRangeEnc, const opus_int signalType, const opus_int quantOffsetType, opus_int8 pulses[], const opus_int frame_length)
+{
+    int rec = (g_on && g_bp_in && g_nbp < g_capbits && frame_length <= OPUSGPU_SILK_MAX_FRAME && psRangeEnc->storage <= OPUSGPU_EC_BUF) ? g_nbp : -1;
+    if (rec >= 0) {
+        opusgpu_silk_bits_in *r = &g_bp_in[rec];
+        memcpy(r->pulses, pulses, frame_length);
+        r->signalType = signalType; r->quantOffsetType = quantOffsetType; r->frame_length = frame_length; r->which = 2;
+        r->nb_subfr = 4; r->fs_kHz = 16; r->predictLPCOrder = 16;                       /* not read by silk_encode_pulses; valid placeholders */
+        ec_snapshot(&g_bp_ec0[rec], psRangeEnc);
+    }
+    __real_silk_encode_pulses(psRangeEnc, signalType, quantOffsetType, pulses, frame_length);
+    if (rec >= 0) { ec_snapshot(&g_bp_ec1[rec], psRangeEnc); g_nbp++; }
 }

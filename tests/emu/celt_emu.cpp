@@ -340,3 +340,32 @@ extern "C" void emu_silk_find_pitch_lags(const opusgpu_find_pitch_lags_in *in, o
         out[r].predGain_Q16 = o.predGain_Q16;
     }
 }
+
+// ---- silk_encode_indices / silk_encode_pulses, host build of concentus_amd/csrc/silk_bits_dev.h ----
+#include "../../concentus_amd/csrc/silk_bits_dev.h"
+extern "C" void emu_silk_encode_bits(const opusgpu_silk_bits_in *in, opusgpu_ec_state *ecs, opusgpu_silk_bits_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        const opusgpu_silk_bits_in &i = in[r];
+        opusgpu_ec_state &st = ecs[r];
+        ca::RangeEnc ec;
+        ec.buf = st.buf; ec.storage = st.storage; ec.end_offs = st.end_offs; ec.end_window = st.end_window; ec.nend_bits = st.nend_bits;
+        ec.nbits_total = st.nbits_total; ec.offs = st.offs; ec.rng = st.rng; ec.val = st.val; ec.ext = st.ext; ec.rem = st.rem; ec.error = st.error;
+        int pst = i.ec_prevSignalType, plag = i.ec_prevLagIndex;
+        if (i.which & 1) {
+            ca::SilkIndices ix;
+            for (int k = 0; k < 4; k++) { ix.GainsIndices[k] = i.GainsIndices[k]; ix.LTPIndex[k] = i.LTPIndex[k]; }
+            for (int k = 0; k <= 16; k++) ix.NLSFIndices[k] = i.NLSFIndices[k];
+            ix.lagIndex = i.lagIndex; ix.contourIndex = i.contourIndex; ix.signalType = i.signalType; ix.quantOffsetType = i.quantOffsetType;
+            ix.NLSFInterpCoef_Q2 = i.NLSFInterpCoef_Q2; ix.PERIndex = i.PERIndex; ix.LTP_scaleIndex = i.LTP_scaleIndex; ix.Seed = i.Seed;
+            ca::silk_encode_indices_dev(ec, ix, i.nb_subfr, i.fs_kHz, i.predictLPCOrder, i.condCoding, pst, plag);
+        }
+        if (i.which & 2) {
+            uint8_t absq[320];
+            ca::silk_encode_pulses_dev(ec, i.signalType, i.quantOffsetType, (const int8_t *)i.pulses, i.frame_length, absq);
+        }
+        st.end_offs = ec.end_offs; st.end_window = ec.end_window; st.nend_bits = ec.nend_bits; st.nbits_total = ec.nbits_total; st.offs = ec.offs;
+        st.rng = ec.rng; st.val = ec.val; st.ext = ec.ext; st.rem = ec.rem; st.error = ec.error;
+        out[r].ec_prevSignalType = pst; out[r].ec_prevLagIndex = plag; out[r].status = 0; out[r].reserved = 0;
+    }
+}

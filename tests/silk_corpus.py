@@ -23,7 +23,8 @@ ROOT = os.path.dirname(HERE)
 CAPLIB = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_silkcap.so")
 FS = 16000
 FRAME = 320
-VARIANTS = {"wb20": (16000, 320), "nb20": (8000, 160), "wb10": (16000, 160)}     # (input rate, samples per opus_encode call)
+# (input rate, samples per opus_encode call); "wb40": two SILK frames per packet, the second one coded conditionally
+VARIANTS = {"wb20": (16000, 320), "nb20": (8000, 160), "wb10": (16000, 160), "wb40": (16000, 640)}
 SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder each)
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
@@ -31,7 +32,7 @@ SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq
          "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40,
          "fpc_in": 2688, "fpc_out": 208, "gains_in": 112, "gains_out": 56,
          "shape_in": 1696, "shape_out": 384, "prefilter_in": 896, "prefilter_state": 1116, "prefilter_out": 1296,
-         "pitch_in": 1408, "pitch_out": 1392}
+         "pitch_in": 1408, "pitch_out": 1392, "bits_in": 416, "ec_state": 1328, "bits_out": 16}
 
 
 def available():
@@ -122,6 +123,8 @@ def _capture_segment(args):
         lib.refcap_start_prefilter(cap)
     elif kind == "pitch":
         lib.refcap_start_pitch(cap)
+    elif kind == "bits":
+        lib.refcap_start_bits(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -180,7 +183,17 @@ def _capture_segment(args):
         for f in files.values():
             f.flush()
         return take
-    if kind == "pitch":
+    if kind == "bits":
+        assert [lib.refcap_sizes_bits(k) for k in range(3)] == [SIZES["bits_in"], SIZES["ec_state"], SIZES["bits_out"]]
+        for which, tag in ((0, "idx"), (1, "pls")):
+            nb_ = lib.refcap_count_bits(which)
+            assert nb_ >= nfr, (which, nb_, nfr)
+            bufs = [np.zeros((nb_, SIZES["bits_in"]), np.uint8), np.zeros((nb_, SIZES["ec_state"]), np.uint8),
+                    np.zeros((nb_, SIZES["ec_state"]), np.uint8), np.zeros((nb_, SIZES["bits_out"]), np.uint8)]
+            lib.refcap_get_bits(which, *[_p(b) for b in bufs])
+            for name, b in zip(("bits_%s_in" % tag, "bits_%s_ec_in" % tag, "bits_%s_ec_out" % tag, "bits_%s_out" % tag), bufs):
+                files[name][row0:row0 + take] = b[WARMUP:WARMUP + take]
+    elif kind == "pitch":
         nt = lib.refcap_count_pitch()
         assert nt >= nfr, (nt, nfr)
         assert (lib.refcap_sizes_pitch(0), lib.refcap_sizes_pitch(1)) == (SIZES["pitch_in"], SIZES["pitch_out"])
@@ -276,6 +289,8 @@ _LAYOUT = {
     "gains": (("gains_in", "gains_in"), ("gains_out", "gains_out")),
     "shape": (("shape_in", "shape_in"), ("shape_out", "shape_out")),
     "pitch": (("pitch_in", "pitch_in"), ("pitch_out", "pitch_out")),
+    "bits": (("bits_idx_in", "bits_in"), ("bits_idx_ec_in", "ec_state"), ("bits_idx_ec_out", "ec_state"), ("bits_idx_out", "bits_out"),
+             ("bits_pls_in", "bits_in"), ("bits_pls_ec_in", "ec_state"), ("bits_pls_ec_out", "ec_state"), ("bits_pls_out", "bits_out")),
     # aligned capture of ONE encoder run: row r of every array belongs to the same frame (first call of the frame)
     "chain_nsq": _CHAIN_LAYOUT + (("c_q_in", "nsq_in"), ("c_q_out", "nsq_out")),
     "chain_dd": _CHAIN_LAYOUT + (("c_q_in", "dd_in"), ("c_q_out", "dd_out")),
@@ -318,7 +333,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "bits": 160481183, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
                          row, take, n, variant))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

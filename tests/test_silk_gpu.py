@@ -501,3 +501,39 @@ def test_analysis_kernels_at_8_kHz_and_with_10_ms_frames(ca, variant):
     assert np.array_equal(out[:, :1280], np.asarray(rec["prefilter_out"])[:, :1280])
     assert np.array_equal(st.cpu().numpy(), np.asarray(rec["prefilter_state_out"]))
     assert ca.silk.bad_records() == 0
+
+
+@pytest.mark.parametrize("variant", ["wb20", "wb40", "nb20", "wb10"])
+def test_encode_indices_and_pulses_vs_the_reference_range_coder(ca, variant):
+    """silk_encode_indices / silk_encode_pulses on the GPU against the range coder of the unmodified reference captured before and
+    after each call (tests/silk_corpus.py kind "bits"): every ec_ctx field and every byte written; then both calls of a frame in
+    ONE launch (which = 3) from the coder as it was before silk_encode_indices to the coder after silk_encode_pulses."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    n = 16384 if variant == "wb20" else 4096
+    rec = silk_corpus.corpus(n, "bits", variant=variant, complexities=(3, 8))
+    ca.silk.bad_records()
+    for tag in ("idx", "pls"):
+        ec = _dev(rec["bits_%s_ec_in" % tag])
+        out = ca.silk_encode_bits(_dev(rec["bits_%s_in" % tag]), ec)
+        torch.cuda.synchronize()
+        got, want = ec.cpu().numpy(), np.asarray(rec["bits_%s_ec_out" % tag])
+        bad = np.nonzero((got != want).any(1))[0]
+        assert bad.size == 0, (tag, variant, bad.size, bad[:6], np.nonzero(got[bad[0]] != want[bad[0]])[0][:12])
+        if tag == "idx":
+            assert np.array_equal(out.cpu().numpy()[:, :8], np.asarray(rec["bits_idx_out"])[:, :8])
+    both = np.array(rec["bits_idx_in"])
+    both[:, :320] = np.asarray(rec["bits_pls_in"])[:, :320]                      # the frame's pulses
+    both[:, 348 + 60:348 + 64].view(np.int32)[:, 0] = 3                           # which
+    ec = _dev(rec["bits_idx_ec_in"])
+    ca.silk_encode_bits(_dev(both), ec)
+    assert np.array_equal(ec.cpu().numpy(), np.asarray(rec["bits_pls_ec_out"]))
+    assert ca.silk.bad_records() == 0
+    bad_in = np.array(rec["bits_idx_in"][:64])
+    bad_in[5, 320] = 99                                                           # GainsIndices[0] outside its model
+    ec2 = _dev(rec["bits_idx_ec_in"][:64])
+    o2 = ca.silk_encode_bits(_dev(bad_in), ec2).cpu().numpy()
+    assert ca.silk.bad_records() == 1 and o2[5, 8:12].view(np.int32)[0] == -1
+    assert np.array_equal(ec2.cpu().numpy()[5], np.asarray(rec["bits_idx_ec_in"])[5]), "a skipped record leaves its coder untouched"

@@ -23,7 +23,7 @@ CASES = {      # kind -> (input key(s), output key, bytes compared, emu entry, o
 
 
 @pytest.mark.ref
-@pytest.mark.parametrize("variant", ["nb20", "wb10"])
+@pytest.mark.parametrize("variant", ["nb20", "wb10", "wb40"])
 @pytest.mark.parametrize("kind", sorted(CASES))
 def test_analysis_sources_match_the_reference_at_other_rates_and_frame_sizes(kind, variant):
     if not silk_corpus.available():
@@ -49,6 +49,8 @@ def test_analysis_sources_match_the_reference_at_other_rates_and_frame_sizes(kin
         if kind == "pitch":
             hdr = rin[:, 1344:1408].view(np.int32)
             assert (hdr[:, 0] == (8 if variant == "nb20" else 16)).all() and (hdr[:, 1] == (2 if variant == "wb10" else 4)).all()
+        if kind == "gains" and variant == "wb40":
+            assert (rin[:, 48:112].view(np.int32)[:, 6] == 2).sum() > 500, "conditionally coded frames (delta gain indices)"
         if kind == "fpc":
             hdr = rin[:, 2624:2688].view(np.int32)
             assert (hdr[:, 2] == (10 if variant == "nb20" else 16)).all() and (hdr[:, 0] == (2 if variant == "wb10" else 4)).all()

@@ -67,6 +67,43 @@ def ltp_tables():
     return out
 
 
+ENTROPY_TABLES = (   # (symbol in the reference, entries): the iCDF / code-length tables silk_encode_indices and silk_encode_pulses use
+    ("silk_gain_iCDF", 24), ("silk_delta_gain_iCDF", 41), ("silk_pitch_lag_iCDF", 32), ("silk_pitch_delta_iCDF", 21),
+    ("silk_pitch_contour_iCDF", 34), ("silk_pitch_contour_NB_iCDF", 11), ("silk_pitch_contour_10_ms_iCDF", 12),
+    ("silk_pitch_contour_10_ms_NB_iCDF", 3), ("silk_type_offset_VAD_iCDF", 4), ("silk_type_offset_no_VAD_iCDF", 2),
+    ("silk_NLSF_interpolation_factor_iCDF", 5), ("silk_NLSF_EXT_iCDF", 7), ("silk_uniform3_iCDF", 3), ("silk_uniform4_iCDF", 4),
+    ("silk_uniform5_iCDF", 5), ("silk_uniform6_iCDF", 6), ("silk_uniform8_iCDF", 8), ("silk_LTP_per_index_iCDF", 3),
+    ("silk_LTPscale_iCDF", 3), ("silk_lsb_iCDF", 2), ("silk_max_pulses_table", 4), ("silk_pulses_per_block_iCDF", 180),
+    ("silk_pulses_per_block_BITS_Q5", 162), ("silk_rate_levels_iCDF", 18), ("silk_rate_levels_BITS_Q5", 18),
+    ("silk_shell_code_table0", 152), ("silk_shell_code_table1", 152), ("silk_shell_code_table2", 152), ("silk_shell_code_table3", 152),
+    ("silk_shell_code_table_offsets", 17), ("silk_sign_iCDF", 42),
+)
+
+
+def entropy_tables():
+    """name -> list, plus the three LTP gain iCDFs (behind silk_LTP_gain_iCDF_ptrs) flattened as 'silk_LTP_gain_iCDF' (8 + 16 + 32)."""
+    lib = C.CDLL(REFLIB)
+    out = {name: list((C.c_uint8 * n).in_dll(lib, name)) for name, n in ENTROPY_TABLES}
+    ptrs = (C.POINTER(C.c_uint8) * 3).in_dll(lib, "silk_LTP_gain_iCDF_ptrs")
+    out["silk_LTP_gain_iCDF"] = [ptrs[k][i] for k in range(3) for i in range(8 << k)]
+    return out
+
+
+def emit_entropy(path):
+    t = entropy_tables()
+    o = ["// silk_entropy_tables.h -- GENERATED by tools/gen_silk_tables.py; do not edit.",
+         "// The probability models (iCDFs) and code-length tables of the SILK side information and excitation coding, constants of the",
+         "// Opus specification (RFC 6716 sections 4.2.7.3 - 4.2.7.8; opus-fix/silk/tables_gain.c, tables_pitch_lag.c, tables_other.c,",
+         "// tables_LTP.c, tables_pulses_per_block.c), read out of the compiled reference; tests/test_tables.py compares every array.",
+         "#pragma once", '#include "wave.h"', "", "namespace ca {", ""]
+    for name, vals in t.items():
+        o.append(_arr("u8", "SILK_" + name[5:], vals, 18 if "per_block" in name else 19 if "shell_code_table" in name and "offsets" not in name else 16))
+    o += ["", "}  // namespace ca", ""]
+    with open(path, "w") as f:
+        f.write("\n".join(o))
+    print("wrote", path)
+
+
 def _arr(ctype, name, vals, per_line):
     lines = ["CA_DEVICE_CONST %s %s[%d] = {" % (ctype, name, len(vals))]
     for i in range(0, len(vals), per_line):
@@ -115,3 +152,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    emit_entropy(os.path.join(os.path.dirname(OUT), "silk_entropy_tables.h"))
