@@ -16,7 +16,7 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
                   (16 kHz mono, order 16, 4 x 80-sample subframes; records captured from the reference encoder).
   silk_deldec     the same for silk_NSQ_del_dec (the quantiser of complexity >= 4).
   silk_frames     65 536 frames through the WHOLE chain on the device: pitch buffer -> find_pitch_lags -> noise_shape_analysis ->
-                  find_pred_coefs -> process_gains -> prefilter -> NSQ_del_dec -> pulses (records between the kernels filled on the
+                  find_pred_coefs -> process_gains -> prefilter -> NSQ_del_dec -> encode_indices + encode_pulses -> range-coder bytes (records between the kernels filled on the
                   device, concentus_amd/silk_chain.py); parity per frame against the reference's own results.
   silk_analysis   the five analysis calls of silk_encode_frame_FIX between the VAD and the quantiser (silk_find_pitch_lags_FIX,
                   silk_noise_shape_analysis_FIX, silk_find_pred_coefs_FIX, silk_process_gains_FIX, silk_prefilter_FIX), 65 536
@@ -736,22 +736,23 @@ def main(argv=None):
             raise SystemExit("silk_frames needs oracle/_ref/libopus_ref_silkcap.so (frames are captured from the reference encoder)")
         rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "chain_dd", seed=20260401 + 1000003 * rank).items()}
         names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in",
-                 "prefilter_in": "c_prefilter_in", "q_in": "c_q_in"}
+                 "prefilter_in": "c_prefilter_in", "q_in": "c_q_in", "bits_in": "c_bits_in"}
         host_in = {k: rec[v].copy() for k, v in names.items()}
         for name, (cls, fields) in CHAIN_FED_FIELDS.items():              # what the chain has to produce itself starts out as zero
             for f in fields:
                 d = getattr(cls, f)
                 host_in[name][:, d.offset:d.offset + d.size] = 0
         d_in = {k: torch.from_numpy(v).to(dev) for k, v in host_in.items()}
-        pf0, nsq0 = torch.from_numpy(rec["c_prefilter_state_in"]).to(dev), torch.from_numpy(rec["c_q_state_in"]).to(dev)
-        pf_st, nsq_st = pf0.clone(), nsq0.clone()
+        pf0, nsq0, ec0 = (torch.from_numpy(rec[k]).to(dev) for k in ("c_prefilter_state_in", "c_q_state_in", "c_ec_in"))
+        pf_st, nsq_st, ec_st = pf0.clone(), nsq0.clone(), ec0.clone()
         chain = SilkAnalysisChain(16, 4)
 
         def one_step():
             pf_st.copy_(pf0)
             nsq_st.copy_(nsq0)
+            ec_st.copy_(ec0)
             return chain.run(d_in["pitch_in"], d_in["shape_in"], d_in["fpc_in"], d_in["gains_in"], d_in["prefilter_in"], pf_st, d_in["q_in"],
-                             nsq_st, True)
+                             nsq_st, True, bits_in=d_in["bits_in"], ec_state=ec_st)
         for _ in range(warm):
             one_step()
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
@@ -766,15 +767,15 @@ def main(argv=None):
         barrier()
         kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
         kname = "silk_find_pred_coefs_kernel"
-        kbytes = F * (1408 + 324 + 4380 + 1116)        # per frame: pitch buffer in, pulses + Seed out, the two carried states rewritten
+        kbytes = F * (1408 + 324 + 4380 + 1116 + 1328)  # per frame: pitch buffer in, pulses + Seed out, the carried states and the coder rewritten
         limiter = "latency / VALU issue (seven lane-per-frame kernels of serial fixed-point recurrences; whole step timed, kernel = the longest)"
-        metric = "SILK 16kHz mono 20ms frames/sec (analysis chain + silk_NSQ_del_dec, pitch buffer -> pulses)"
+        metric = "SILK 16kHz mono 20ms frames/sec (analysis chain + silk_NSQ_del_dec + entropy coding, pitch buffer -> range-coder bytes)"
         workload = ("%d frames per GPU, each with the records of ONE frame captured from the reference encoder (synthetic 16 kHz mono "
                     "speech, 32 kb/s VOIP, complexity 5/7/10 in turn); the seven kernels run back to back (find_pitch_lags, "
-                    "noise_shape_analysis, find_pred_coefs, process_gains, prefilter, NSQ_del_dec), records between them filled on "
+                    "noise_shape_analysis, find_pred_coefs, process_gains, prefilter, NSQ_del_dec, encode_indices + encode_pulses), records between them filled on "
                     "the device; bit-exact vs FIXED_POINT" % F)
         dtype = "int16/int32/int64 fixed-point"
-        extra = {"note": "avg_launch_ms is the whole seven-kernel step (incl. the device-side record moves and the reset of the two carried states)"}
+        extra = {"note": "avg_launch_ms is the whole eight-kernel step (incl. the device-side record moves and the reset of the carried states and the coder)"}
         m_cpu = min(F, 2048)
 
         def cpu():
@@ -791,11 +792,12 @@ def main(argv=None):
                     raise SystemExit("PARITY FAILURE (silk_frames: %s)" % key)
             ok = (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), rec["c_q_out"][:, :320])
                   and np.array_equal(res["Seed"].cpu().numpy(), rec["c_q_out"][:, 320:324].copy().view(np.int32)[:, 0])
-                  and np.array_equal(nsq_st.cpu().numpy(), rec["c_q_state_out"]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"]))
+                  and np.array_equal(nsq_st.cpu().numpy(), rec["c_q_state_out"]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"])
+                  and np.array_equal(ec_st.cpu().numpy(), rec["c_ec_out"]))
             if not ok:
-                raise SystemExit("PARITY FAILURE (silk_frames: pulses / Seed / silk_nsq_state / prefilter state)")
-            parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX "
-                                           "vs what the reference computed for the same frame"}
+                raise SystemExit("PARITY FAILURE (silk_frames: pulses / Seed / silk_nsq_state / prefilter state / range coder)")
+            parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX, "
+                                           "and the range coder (every field, every byte written) vs what the reference computed for the same frame"}
     elif a.workload == "silk_analysis":
         F = a.frames or 65536
         steps = a.steps or 5

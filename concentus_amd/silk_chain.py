@@ -1,7 +1,7 @@
 """The SILK analysis chain of one frame, end to end on the device:
 
     silk_find_pitch_lags_FIX -> silk_noise_shape_analysis_FIX -> silk_find_pred_coefs_FIX -> silk_process_gains_FIX
-        -> silk_prefilter_FIX -> silk_NSQ / silk_NSQ_del_dec
+        -> silk_prefilter_FIX -> silk_NSQ / silk_NSQ_del_dec -> silk_encode_indices + silk_encode_pulses
 
 i.e. what silk_encode_frame_FIX (opus-fix/silk/fixed/encode_frame_FIX.c:176-317) runs between the VAD and the range coder for
 the first pass of a frame. Every stage is one batched kernel of libopusgpu.so driven from a flat record; this module is the
@@ -46,11 +46,13 @@ class SilkAnalysisChain:
         v = src[:, so:so + 1].contiguous().view(torch.int8).to(torch.int32)
         dst[:, do:do + 4] = v.view(torch.uint8)
 
-    def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec):
+    def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec, bits_in=None, ec_state=None):
         """All arguments are uint8 CUDA tensors [N][record bytes]. shape_in / fpc_in / gains_in / prefilter_in / q_in are
         completed in place from the outputs of the earlier stages; prefilter_state and nsq_state are updated in place.
-        q_in is opusgpu_nsq_dd_in when del_dec else opusgpu_nsq_in. Returns a dict of the stage outputs; "pulses" is
-        int8 [N][320] (and "Seed" int32 [N] for the delayed-decision quantiser)."""
+        q_in is opusgpu_nsq_dd_in when del_dec else opusgpu_nsq_in. With bits_in / ec_state (opusgpu_silk_bits_in with which = 3, the
+        frame's range coder) the side information and the excitation are entropy-coded as well (silk_encode_indices +
+        silk_encode_pulses): ec_state is updated in place. Returns a dict of the stage outputs; "pulses" is int8 [N][320] (and
+        "Seed" int32 [N] for the delayed-decision quantiser)."""
         import torch
         mv, fl, ltp = self._move, self.frame_length, self.ltp_mem_length
         PO, SI, SO, FI, FO, GI, GO, XI, XO, Q = (S.FindPitchLagsOut, S.NoiseShapeIn, S.NoiseShapeOut, S.FindPredCoefsIn, S.FindPredCoefsOut,
@@ -100,6 +102,22 @@ class SilkAnalysisChain:
             out["Seed"] = dd_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
         else:
             out["pulses"] = S.silk_NSQ(q_in, nsq_state)
+        if bits_in is not None:
+            B, i8to32 = S.SilkBitsIn, self._move_i8_to_i32
+            do, _ = _off(B, "pulses")
+            bits_in[:, do:do + 320] = out["pulses"].view(torch.uint8)
+            mv(bits_in, B, "GainsIndices", gains_out, GO, "GainsIndices")
+            mv(bits_in, B, "NLSFIndices", fpc_out, FO, "NLSFIndices")
+            mv(bits_in, B, "LTPIndex", fpc_out, FO, "LTPIndex")
+            for name in ("NLSFInterpCoef_Q2", "PERIndex", "LTP_scaleIndex"):
+                i8to32(bits_in, B, name, fpc_out, FO, name)
+            for name in ("lagIndex", "contourIndex", "signalType"):
+                mv(bits_in, B, name, pitch_out, PO, name)
+            mv(bits_in, B, "quantOffsetType", gains_out, GO, "quantOffsetType")
+            if del_dec:                                   # silk_NSQ_del_dec rewrites psIndices->Seed (NSQ_del_dec.c:297)
+                so, _ = _off(B, "Seed")
+                bits_in[:, so:so + 4] = dd_out[:, 320:324]
+            out["bits_out"] = S.silk_encode_bits(bits_in, ec_state)
         return out
 
 
@@ -112,4 +130,6 @@ CHAIN_FED_FIELDS = {       # the record fields run() fills: a caller (and the te
                                      "coding_quality_Q14", "pitchL", "signalType")),
     "q_in": (S.NsqIn, ("x_Q3", "PredCoef_Q12", "LTPCoef_Q14", "LTP_scale_Q14", "NLSFInterpCoef_Q2", "AR2_Q13", "HarmShapeGain_Q14", "Tilt_Q14",
                        "LF_shp_Q14", "Gains_Q16", "Lambda_Q10", "quantOffsetType", "pitchL", "signalType")),
+    "bits_in": (S.SilkBitsIn, ("pulses", "GainsIndices", "NLSFIndices", "LTPIndex", "NLSFInterpCoef_Q2", "PERIndex", "LTP_scaleIndex", "lagIndex",
+                               "contourIndex", "signalType", "quantOffsetType")),
 }

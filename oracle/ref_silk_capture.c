@@ -13,7 +13,7 @@ typedef char nsq_state_layout_check[sizeof(silk_nsq_state) == sizeof(opusgpu_nsq
 
 /* Frame bookkeeping for the aligned ("chain") capture: g_frame counts calls of silk_find_pitch_lags_FIX (one per encoded frame);
  * every wrap notes the frame its record belongs to, so that the records of one frame can be matched across functions. */
-enum { FID_PITCH, FID_SHAPE, FID_FPC, FID_GAINS, FID_PREFILTER, FID_NSQ, FID_DD, FID_KINDS };
+enum { FID_PITCH, FID_SHAPE, FID_FPC, FID_GAINS, FID_PREFILTER, FID_NSQ, FID_DD, FID_BITS_IDX, FID_BITS_PLS, FID_KINDS };
 static int g_frame, *g_fid[FID_KINDS], g_fid_cap;
 static void fid_note(int kind, int rec) { if (g_fid[kind] && rec >= 0 && rec < g_fid_cap) g_fid[kind][rec] = g_frame; }
 void refcap_get_frame_ids(int kind, int *out, int n) { if (g_fid[kind]) memcpy(out, g_fid[kind], sizeof(int) * (size_t)n); }
@@ -528,9 +528,10 @@ void __wrap_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
 
 /* Aligned capture of one encoder run: every analysis function and both quantisers record at once. */
 void refcap_start_dd(int max_records);
+void refcap_start_bits(int max_records);
 void refcap_start_chain(int max_records)
 {
-    refcap_start(max_records); refcap_start_dd(max_records); refcap_start_fpc(max_records); refcap_start_gains(max_records);
+    refcap_start(max_records); refcap_start_dd(max_records); refcap_start_bits(max_records); refcap_start_fpc(max_records); refcap_start_gains(max_records);
     refcap_start_shape(max_records); refcap_start_prefilter(max_records); refcap_start_pitch(max_records);
     g_frame = 0; g_fid_cap = max_records;
     for (int k = 0; k < FID_KINDS; k++) g_fid[k] = (int *)calloc(max_records, sizeof(int));
@@ -572,6 +573,7 @@ void __real_silk_encode_indices(silk_encoder_state *psEncC, ec_enc *psRangeEnc, 
 void __wrap_silk_encode_indices(silk_encoder_state *psEncC, ec_enc *psRangeEnc, opus_int FrameIndex, opus_int encode_LBRR, opus_int condCoding)
 {
     int rec = (g_on && g_bi_in && g_nbi < g_capbits && !encode_LBRR && psRangeEnc->storage <= OPUSGPU_EC_BUF) ? g_nbi : -1;
+    fid_note(FID_BITS_IDX, rec);
     if (rec >= 0) {
         opusgpu_silk_bits_in *r = &g_bi_in[rec];
         const SideInfoIndices *ix = &psEncC->indices;
@@ -594,6 +596,7 @@ void __real_silk_encode_pulses(ec_enc *psRangeEnc, const opus_int signalType, co
 void __wrap_silk_encode_pulses(ec_enc *psRangeEnc, const opus_int signalType, const opus_int quantOffsetType, opus_int8 pulses[], const opus_int frame_length)
 {
     int rec = (g_on && g_bp_in && g_nbp < g_capbits && frame_length <= OPUSGPU_SILK_MAX_FRAME && psRangeEnc->storage <= OPUSGPU_EC_BUF) ? g_nbp : -1;
+    fid_note(FID_BITS_PLS, rec);
     if (rec >= 0) {
         opusgpu_silk_bits_in *r = &g_bp_in[rec];
         memcpy(r->pulses, pulses, frame_length);

@@ -164,6 +164,15 @@ def _capture_segment(args):
             q = [np.zeros((n, SIZES[z]), np.uint8) for z in ("nsq_in", "nsq_state", "nsq_state", "nsq_out")]
             lib.refcap_get(*[_p(a) for a in b + q])
             got["q"] = (q, fids(5, n))
+        # the frame's two entropy-coding calls as ONE record: the indices record with the pulses of the pulses record, which = 3;
+        # coder before silk_encode_indices -> coder after silk_encode_pulses
+        ni, npl = lib.refcap_count_bits(0), lib.refcap_count_bits(1)
+        bi = [np.zeros((ni, SIZES[z]), np.uint8) for z in ("bits_in", "ec_state", "ec_state", "bits_out")]
+        bp = [np.zeros((npl, SIZES[z]), np.uint8) for z in ("bits_in", "ec_state", "ec_state", "bits_out")]
+        lib.refcap_get_bits(0, *[_p(b) for b in bi])
+        lib.refcap_get_bits(1, *[_p(b) for b in bp])
+        got["bits_idx"] = (bi, fids(7, ni))
+        got["bits_pls"] = (bp, fids(8, npl))
         first = {}
         for key, (_, fid) in got.items():
             # index of the first record of every frame number (frame numbers start at 1)
@@ -177,9 +186,21 @@ def _capture_segment(args):
                  "prefilter": ("c_prefilter_in", "c_prefilter_state_in", "c_prefilter_state_out", "c_prefilter_out"),
                  "q": ("c_q_in", "c_q_state_in", "c_q_state_out", "c_q_out")}
         for key, (bufs, _) in got.items():
+            if key.startswith("bits"):
+                continue
             sel = np.array([first[key][f] for f in frames])
             for name, b in zip(names[key], bufs):
                 files[name][row0:row0 + take] = b[sel]
+        si = np.array([first["bits_idx"][f] for f in frames])
+        sp = np.array([first["bits_pls"][f] for f in frames])
+        both = bi[0][si].copy()
+        both[:, :320] = bp[0][sp][:, :320]
+        both[:, 348 + 60:348 + 64].view(np.int32)[:, 0] = 3
+        assert np.array_equal(bi[2][si], bp[1][sp]), "indices-out must be pulses-in on the same coder"
+        files["c_bits_in"][row0:row0 + take] = both
+        files["c_ec_in"][row0:row0 + take] = bi[1][si]
+        files["c_ec_out"][row0:row0 + take] = bp[2][sp]
+        files["c_bits_out"][row0:row0 + take] = bi[3][si]
         for f in files.values():
             f.flush()
         return take
@@ -279,7 +300,8 @@ def _capture_segment(args):
 _CHAIN_LAYOUT = (("c_pitch_in", "pitch_in"), ("c_pitch_out", "pitch_out"), ("c_shape_in", "shape_in"), ("c_shape_out", "shape_out"),
                  ("c_fpc_in", "fpc_in"), ("c_fpc_out", "fpc_out"), ("c_gains_in", "gains_in"), ("c_gains_out", "gains_out"),
                  ("c_prefilter_in", "prefilter_in"), ("c_prefilter_state_in", "prefilter_state"), ("c_prefilter_state_out", "prefilter_state"),
-                 ("c_prefilter_out", "prefilter_out"), ("c_q_state_in", "nsq_state"), ("c_q_state_out", "nsq_state"))
+                 ("c_prefilter_out", "prefilter_out"), ("c_q_state_in", "nsq_state"), ("c_q_state_out", "nsq_state"),
+                 ("c_bits_in", "bits_in"), ("c_ec_in", "ec_state"), ("c_ec_out", "ec_state"), ("c_bits_out", "bits_out"))
 _LAYOUT = {
     "nsq": (("burg_in", "burg_in"), ("burg_out", "burg_out"), ("nsq_in", "nsq_in"), ("nsq_state_in", "nsq_state"),
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),

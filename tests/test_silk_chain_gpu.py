@@ -65,3 +65,39 @@ def test_chain_from_pitch_buffer_to_pulses(complexity, variant):
     assert np.array_equal(nsq_state.cpu().numpy(), _bytes(qst1[sel["q"]])), "silk_nsq_state"
     voiced = (pout[sel["p"]]["signalType"] == 2).sum()
     assert n > 600 and 50 < voiced < n
+
+
+@pytest.mark.parametrize("kind,variant", [("chain_dd", "wb20"), ("chain_nsq", "wb20"), ("chain_dd", "wb40"), ("chain_dd", "nb20"), ("chain_dd", "wb10")])
+def test_chain_from_pitch_buffer_to_range_coder_bytes(kind, variant):
+    """The same chain one stage further: silk_encode_indices + silk_encode_pulses on the frame's range coder (tests/silk_corpus.py
+    aligned corpus, 4 096 frames): from the pitch buffer and the coder as it was when the reference reached silk_encode_indices, to
+    the coder after silk_encode_pulses -- every ec_ctx field and every byte written -- with all chain-fed record fields zeroed."""
+    import torch
+    import concentus_amd as ca
+    from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = {k: np.array(v) for k, v in silk_corpus.corpus(4096, kind, variant=variant).items()}
+    names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in", "prefilter_in": "c_prefilter_in",
+             "q_in": "c_q_in", "bits_in": "c_bits_in"}
+    host = {k: rec[v].copy() for k, v in names.items()}
+    for name, (cls, fields) in CHAIN_FED_FIELDS.items():
+        for f in fields:
+            d = getattr(cls, f)
+            host[name][:, d.offset:d.offset + d.size] = 0
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    pf, nsq, ec = (torch.from_numpy(rec[k]).cuda() for k in ("c_prefilter_state_in", "c_q_state_in", "c_ec_in"))
+    ca.silk.bad_records()
+    out = SilkAnalysisChain(8 if variant == "nb20" else 16, 2 if variant == "wb10" else 4).run(
+        dev["pitch_in"], dev["shape_in"], dev["fpc_in"], dev["gains_in"], dev["prefilter_in"], pf, dev["q_in"], nsq, kind == "chain_dd",
+        bits_in=dev["bits_in"], ec_state=ec)
+    torch.cuda.synchronize()
+    assert ca.silk.bad_records() == 0
+    assert np.array_equal(out["pulses"].cpu().numpy().view(np.uint8), rec["c_q_out"][:, :320])
+    assert np.array_equal(nsq.cpu().numpy(), rec["c_q_state_out"]) and np.array_equal(pf.cpu().numpy(), rec["c_prefilter_state_out"])
+    got = ec.cpu().numpy()
+    bad = np.nonzero((got != rec["c_ec_out"]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:6], np.nonzero(got[bad[0]] != rec["c_ec_out"][bad[0]])[0][:12])
+    assert np.array_equal(out["bits_out"].cpu().numpy()[:, :8], rec["c_bits_out"][:, :8])
+    written = rec["c_ec_out"][:, 20:24].copy().view(np.uint32)[:, 0] - rec["c_ec_in"][:, 20:24].copy().view(np.uint32)[:, 0]
+    assert written.mean() > 20, "the frames' payload bytes"
