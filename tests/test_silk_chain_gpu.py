@@ -41,6 +41,8 @@ def test_chain_from_pitch_buffer_to_pulses(complexity, variant):
            "prefilter_in": _bytes(xin[sel["x"]]), "q_in": _bytes(qin[sel["q"]])}
     # zero every field the chain fills
     for name, (cls, fields) in CHAIN_FED_FIELDS.items():
+        if name not in rec:                                   # (the entropy-coding stage has its own test below)
+            continue
         for f in fields:
             d = getattr(cls, f)
             rec[name][:, d.offset:d.offset + d.size] = 0
