@@ -218,3 +218,28 @@ extern "C" void opusgpu_silk_prefilter_FIX(void *psEnc, const void *psEncCtrl, i
     }
     free(in); free(out); free(st);
 }
+
+extern "C" int opusgpu_silk_VAD_GetSA_Q8_c(void *psEncC, const int16_t pIn[])
+{
+    if (!psEncC || !pIn) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return -1; }
+    static_assert(sizeof(opusgpu_vad_state) == OPUSGPU_REF_SIZEOF_SILK_VAD_STATE, "state record = silk_VAD_state");
+    char *sCmn = (char *)psEncC;
+    opusgpu_vad_in in;
+    opusgpu_vad_out out;
+    opusgpu_vad_state st;
+    memset(&in, 0, sizeof(in));
+    in.frame_length = rd_int(sCmn, OPUSGPU_REF_OFF_FRAME_LENGTH); in.fs_kHz = rd_int(sCmn, OPUSGPU_REF_OFF_FS_KHZ);
+    if (in.frame_length < 8 || in.frame_length > OPUSGPU_SILK_MAX_FRAME) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return -1; }
+    memcpy(in.pIn, pIn, sizeof(int16_t) * (size_t)in.frame_length);
+    memcpy(&st, sCmn + OPUSGPU_REF_OFF_SVAD, sizeof(st));
+    const int rc = run_record(&in, &out, &st, [](const opusgpu_vad_in *i, opusgpu_vad_state *s, opusgpu_vad_out *o) {
+        return opusgpu_silk_vad_batch(i, s, o, 1, nullptr);
+    });
+    opusgpu_set_last_error(rc);
+    if (rc != OPUSGPU_OK) return -1;
+    memcpy(sCmn + OPUSGPU_REF_OFF_SVAD, &st, sizeof(st));
+    wr_int(sCmn, OPUSGPU_REF_OFF_SPEECH_ACTIVITY_Q8, out.speech_activity_Q8);
+    wr_int(sCmn, OPUSGPU_REF_OFF_INPUT_TILT_Q15, out.input_tilt_Q15);
+    for (int k = 0; k < 4; k++) wr_int(sCmn, OPUSGPU_REF_OFF_INPUT_QUALITY_BANDS_Q15 + 4 * k, out.input_quality_bands_Q15[k]);
+    return 0;
+}

@@ -139,6 +139,16 @@ __device__ __forceinline__ bool silk_bits_record_ok(const opusgpu_silk_bits_in &
     return true;
 }
 
+__device__ __forceinline__ bool vad_record_ok(const opusgpu_vad_in &in, const opusgpu_vad_state &st)
+{
+    const int fl = in.frame_length, fs = in.fs_kHz;
+    if (!((fs == 8 || fs == 12 || fs == 16) && (fl == 10 * fs || fl == 20 * fs) && fl <= OPUSGPU_SILK_MAX_FRAME && !(fl & 7))) return false;
+    if (st.counter < 0) return false;
+    for (int k = 0; k < 4; k++)
+        if (st.NL[k] < 0 || st.inv_NL[k] <= 0 || st.NoiseLevelBias[k] < 1 || st.XnrgSubfr[k] < 0) return false;     // divisors / saturating sums
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

@@ -390,3 +390,41 @@ def silk_encode_bits(bits_in, ec_state, bits_out=None):
     rc = _lib.load().opusgpu_silk_encode_bits_batch(bits_in.data_ptr(), ec_state.data_ptr(), bits_out.data_ptr(), n, _lib.current_stream_handle())
     _lib.check(rc, "opusgpu_silk_encode_bits_batch")
     return bits_out
+
+
+class VadState(C.Structure):
+    """opusgpu_vad_state == silk_VAD_state (opus-fix/silk/structs.h:60-73)."""
+    _fields_ = [("AnaState", C.c_int32 * 2), ("AnaState1", C.c_int32 * 2), ("AnaState2", C.c_int32 * 2), ("XnrgSubfr", C.c_int32 * 4),
+                ("NrgRatioSmth_Q8", C.c_int32 * 4), ("HPstate", C.c_int16), ("pad", C.c_int16), ("NL", C.c_int32 * 4), ("inv_NL", C.c_int32 * 4),
+                ("NoiseLevelBias", C.c_int32 * 4), ("counter", C.c_int32)]
+
+
+class VadIn(C.Structure):
+    _fields_ = [("pIn", C.c_int16 * 320), ("frame_length", C.c_int32), ("fs_kHz", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class VadOut(C.Structure):
+    _fields_ = [("speech_activity_Q8", C.c_int32), ("input_tilt_Q15", C.c_int32), ("input_quality_bands_Q15", C.c_int32 * 4),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+SIZES["vad_in"] = C.sizeof(VadIn)
+SIZES["vad_state"] = C.sizeof(VadState)
+SIZES["vad_out"] = C.sizeof(VadOut)
+
+
+def silk_VAD_GetSA_Q8(vad_in, vad_state, vad_out=None):
+    """silk_VAD_GetSA_Q8_c() over a batch of records: vad_in uint8 [N][656], vad_state uint8 [N][112] (silk_VAD_state, updated in place)
+    -> uint8 [N][32] (speech_activity_Q8, input_tilt_Q15, input_quality_bands_Q15[4], status)."""
+    import torch
+    _check(vad_in, SIZES["vad_in"], "vad_in")
+    _check(vad_state, SIZES["vad_state"], "vad_state")
+    n = vad_in.shape[0]
+    if vad_state.shape[0] != n:
+        raise ValueError("vad_state: %d records for %d inputs" % (vad_state.shape[0], n))
+    if vad_out is None:
+        vad_out = torch.empty((n, SIZES["vad_out"]), dtype=torch.uint8, device=vad_in.device)
+    _check(vad_out, SIZES["vad_out"], "vad_out")
+    rc = _lib.load().opusgpu_silk_vad_batch(vad_in.data_ptr(), vad_state.data_ptr(), vad_out.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_vad_batch")
+    return vad_out

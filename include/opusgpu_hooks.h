@@ -182,6 +182,12 @@ void opusgpu_silk_find_pred_coefs_FIX(void *psEnc, void *psEncCtrl, const int16_
 #define OPUSGPU_REF_OFF_CTRL_LAST_GAIN_INDEX_PREV 548                /* silk_encoder_control_FIX.lastGainIndexPrev */
 #define OPUSGPU_REF_SIZEOF_SILK_PREFILTER_STATE_FIX 1116
 #define OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE_FIX 9800
+#define OPUSGPU_REF_OFF_SVAD 32                          /* silk_encoder_state.sVAD (silk_VAD_state, 112 bytes) */
+#define OPUSGPU_REF_SIZEOF_SILK_VAD_STATE 112
+/* silk_VAD_GetSA_Q8_c(psEncC, pIn) -- opus-fix/silk/VAD.c:82-312 (macro silk_VAD_GetSA_Q8, silk/main.h:305-312, guard
+ * OVERRIDE_silk_VAD_GetSA_Q8; called at silk/fixed/encode_frame_FIX.c:58): reads psEncC->frame_length / fs_kHz / sVAD, writes sVAD,
+ * speech_activity_Q8, input_tilt_Q15, input_quality_bands_Q15[4]; returns 0. */
+int opusgpu_silk_VAD_GetSA_Q8_c(void *psEncC, const int16_t pIn[]);
 void opusgpu_silk_find_pitch_lags_FIX(void *psEnc, void *psEncCtrl, int16_t res[], const int16_t x[], int arch);
 void opusgpu_silk_noise_shape_analysis_FIX(void *psEnc, void *psEncCtrl, const int16_t *pitch_res, const int16_t *x, int arch);
 void opusgpu_silk_process_gains_FIX(void *psEnc, void *psEncCtrl, int condCoding);

@@ -374,6 +374,30 @@ typedef struct opusgpu_silk_bits_out {
 int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, opusgpu_ec_state *d_ec, opusgpu_silk_bits_out *d_out, int n,
                                    void *hip_stream);
 
+/* ---- silk_VAD_GetSA_Q8, batched (ninth slice) -----------------------------------------------------------
+ * Replaces silk_VAD_GetSA_Q8_c(psEncC, pIn) (opus-fix/silk/VAD.c:82-312; macro silk_VAD_GetSA_Q8, silk/main.h:305-312, called at
+ * silk/fixed/encode_frame_FIX.c:58): three-stage analysis filter bank, band energies, noise-level tracking, speech activity,
+ * spectral tilt and the per-band input quality -- what the analysis chain reads as speech_activity_Q8 / input_tilt_Q15 /
+ * input_quality_bands_Q15. The state record has the layout of silk_VAD_state (silk/structs.h:60-73) and is updated in place. */
+typedef struct opusgpu_vad_state {
+    int32_t AnaState[2], AnaState1[2], AnaState2[2], XnrgSubfr[4], NrgRatioSmth_Q8[4];
+    int16_t HPstate, pad;
+    int32_t NL[4], inv_NL[4], NoiseLevelBias[4], counter;
+} opusgpu_vad_state;
+
+typedef struct opusgpu_vad_in {
+    int16_t pIn[OPUSGPU_SILK_MAX_FRAME];     /* psEncC->inputBuf + 1: frame_length samples */
+    int32_t frame_length, fs_kHz, reserved[2];
+} opusgpu_vad_in;
+
+typedef struct opusgpu_vad_out {
+    int32_t speech_activity_Q8, input_tilt_Q15;
+    int32_t input_quality_bands_Q15[4];
+    int32_t status, reserved;
+} opusgpu_vad_out;
+
+int opusgpu_silk_vad_batch(const opusgpu_vad_in *d_in, opusgpu_vad_state *d_state, opusgpu_vad_out *d_out, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,11 +61,12 @@ int main(void)
     F(silk_encoder_control_FIX, predGain_Q16);
     F(silk_encoder_control_FIX, GainsUnq_Q16);
     F(silk_encoder_control_FIX, lastGainIndexPrev);
+    F(silk_encoder_state, sVAD);
     F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
     F(SideInfoIndices, Seed); F(SideInfoIndices, NLSFIndices);
     F(SideInfoIndices, LTPIndex); F(SideInfoIndices, PERIndex); F(SideInfoIndices, LTP_scaleIndex);
-    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu,\n  \"sizeof.silk_prefilter_state_FIX\": %zu,\n  \"sizeof.silk_encoder_state_FIX\": %zu\n}\n",
+    printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu,\n  \"sizeof.silk_prefilter_state_FIX\": %zu,\n  \"sizeof.silk_encoder_state_FIX\": %zu,\n  \"sizeof.silk_VAD_state\": %zu\n}\n",
            sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state), sizeof(silk_encoder_control_FIX),
-           sizeof(silk_prefilter_state_FIX), sizeof(silk_encoder_state_FIX));
+           sizeof(silk_prefilter_state_FIX), sizeof(silk_encoder_state_FIX), sizeof(silk_VAD_state));
     return 0;
 }

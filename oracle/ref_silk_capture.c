@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX,--wrap=silk_encode_indices,--wrap=silk_encode_pulses into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX,--wrap=silk_encode_indices,--wrap=silk_encode_pulses,--wrap=silk_VAD_GetSA_Q8_c into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -606,4 +606,39 @@ void __wrap_silk_encode_pulses(ec_enc *psRangeEnc, const opus_int signalType, co
     }
     __real_silk_encode_pulses(psRangeEnc, signalType, quantOffsetType, pulses, frame_length);
     if (rec >= 0) { ec_snapshot(&g_bp_ec1[rec], psRangeEnc); g_nbp++; }
+}
+
+/* ---- silk_VAD_GetSA_Q8_c (opus-fix/silk/VAD.c:82): the input frame and silk_VAD_state before / after -> speech activity, tilt, input quality ---- */
+static opusgpu_vad_in *g_vin; static opusgpu_vad_state *g_vst0, *g_vst1; static opusgpu_vad_out *g_vout; static int g_nv, g_capv;
+void refcap_start_vad(int max_records)
+{
+    g_capv = max_records; g_nv = 0; g_on = 1;
+    g_vin = (opusgpu_vad_in *)calloc(max_records, sizeof(*g_vin)); g_vst0 = (opusgpu_vad_state *)calloc(max_records, sizeof(*g_vst0));
+    g_vst1 = (opusgpu_vad_state *)calloc(max_records, sizeof(*g_vst1)); g_vout = (opusgpu_vad_out *)calloc(max_records, sizeof(*g_vout));
+}
+int refcap_count_vad(void) { return g_nv; }
+int refcap_sizes_vad(int which) { return which == 0 ? sizeof(opusgpu_vad_in) : which == 1 ? sizeof(opusgpu_vad_state) : which == 2 ? sizeof(opusgpu_vad_out) : (int)sizeof(silk_VAD_state); }
+void refcap_get_vad(void *vin, void *st0, void *st1, void *vout)
+{
+    memcpy(vin, g_vin, (size_t)g_nv * sizeof(*g_vin)); memcpy(st0, g_vst0, (size_t)g_nv * sizeof(*g_vst0));
+    memcpy(st1, g_vst1, (size_t)g_nv * sizeof(*g_vst1)); memcpy(vout, g_vout, (size_t)g_nv * sizeof(*g_vout));
+}
+opus_int __real_silk_VAD_GetSA_Q8_c(silk_encoder_state *psEncC, const opus_int16 pIn[]);
+opus_int __wrap_silk_VAD_GetSA_Q8_c(silk_encoder_state *psEncC, const opus_int16 pIn[])
+{
+    typedef char vad_state_layout[sizeof(opusgpu_vad_state) == sizeof(silk_VAD_state) ? 1 : -1];
+    int rec = (g_on && g_vin && g_nv < g_capv && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nv : -1;
+    if (rec >= 0) {
+        memcpy(g_vin[rec].pIn, pIn, sizeof(opus_int16) * psEncC->frame_length);
+        g_vin[rec].frame_length = psEncC->frame_length; g_vin[rec].fs_kHz = psEncC->fs_kHz;
+        memcpy(&g_vst0[rec], &psEncC->sVAD, sizeof(g_vst0[rec]));
+    }
+    const opus_int ret = __real_silk_VAD_GetSA_Q8_c(psEncC, pIn);
+    if (rec >= 0) {
+        memcpy(&g_vst1[rec], &psEncC->sVAD, sizeof(g_vst1[rec]));
+        g_vout[rec].speech_activity_Q8 = psEncC->speech_activity_Q8; g_vout[rec].input_tilt_Q15 = psEncC->input_tilt_Q15;
+        for (int k = 0; k < VAD_N_BANDS; k++) g_vout[rec].input_quality_bands_Q15[k] = psEncC->input_quality_bands_Q15[k];
+        g_nv++;
+    }
+    return ret;
 }

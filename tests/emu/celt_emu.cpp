@@ -369,3 +369,27 @@ extern "C" void emu_silk_encode_bits(const opusgpu_silk_bits_in *in, opusgpu_ec_
         out[r].ec_prevSignalType = pst; out[r].ec_prevLagIndex = plag; out[r].status = 0; out[r].reserved = 0;
     }
 }
+
+// ---- silk_VAD_GetSA_Q8_c, host build of concentus_amd/csrc/silk_vad_dev.h ----
+#include "../../concentus_amd/csrc/silk_vad_dev.h"
+extern "C" void emu_silk_vad(const opusgpu_vad_in *in, opusgpu_vad_state *st, opusgpu_vad_out *out, long n)
+{
+    for (long r = 0; r < n; r++) {
+        ca::VadState V;
+        for (int k = 0; k < 2; k++) { V.AnaState[k] = st[r].AnaState[k]; V.AnaState1[k] = st[r].AnaState1[k]; V.AnaState2[k] = st[r].AnaState2[k]; }
+        for (int k = 0; k < 4; k++) {
+            V.XnrgSubfr[k] = st[r].XnrgSubfr[k]; V.NrgRatioSmth_Q8[k] = st[r].NrgRatioSmth_Q8[k]; V.NL[k] = st[r].NL[k]; V.inv_NL[k] = st[r].inv_NL[k];
+            V.NoiseLevelBias[k] = st[r].NoiseLevelBias[k];
+        }
+        V.HPstate = st[r].HPstate; V.counter = st[r].counter;
+        ca::VadOut o;
+        int16_t X[400];
+        ca::silk_VAD_GetSA_Q8_dev(V, o, (const int16_t *)in[r].pIn, (int16_t *)X, in[r].frame_length, in[r].fs_kHz);
+        for (int k = 0; k < 2; k++) { st[r].AnaState[k] = V.AnaState[k]; st[r].AnaState1[k] = V.AnaState1[k]; st[r].AnaState2[k] = V.AnaState2[k]; }
+        for (int k = 0; k < 4; k++) { st[r].XnrgSubfr[k] = V.XnrgSubfr[k]; st[r].NrgRatioSmth_Q8[k] = V.NrgRatioSmth_Q8[k]; st[r].NL[k] = V.NL[k]; st[r].inv_NL[k] = V.inv_NL[k]; }
+        st[r].HPstate = V.HPstate; st[r].counter = V.counter;
+        memset(&out[r], 0, sizeof(out[r]));
+        out[r].speech_activity_Q8 = o.speech_activity_Q8; out[r].input_tilt_Q15 = o.input_tilt_Q15;
+        for (int k = 0; k < 4; k++) out[r].input_quality_bands_Q15[k] = o.input_quality_bands_Q15[k];
+    }
+}

@@ -32,7 +32,8 @@ SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq
          "lpc_in": 832, "lpc_out": 40, "nlsf_in": 96, "nlsf_out": 120, "resnrg_in": 864, "resnrg_out": 40,
          "fpc_in": 2688, "fpc_out": 208, "gains_in": 112, "gains_out": 56,
          "shape_in": 1696, "shape_out": 384, "prefilter_in": 896, "prefilter_state": 1116, "prefilter_out": 1296,
-         "pitch_in": 1408, "pitch_out": 1392, "bits_in": 416, "ec_state": 1328, "bits_out": 16}
+         "pitch_in": 1408, "pitch_out": 1392, "bits_in": 416, "ec_state": 1328, "bits_out": 16,
+         "vad_in": 656, "vad_state": 112, "vad_out": 32}
 
 
 def available():
@@ -125,6 +126,8 @@ def _capture_segment(args):
         lib.refcap_start_pitch(cap)
     elif kind == "bits":
         lib.refcap_start_bits(cap)
+    elif kind == "vad":
+        lib.refcap_start_vad(cap)
     else:
         lib.refcap_start(cap)
     err = C.c_int()
@@ -204,7 +207,16 @@ def _capture_segment(args):
         for f in files.values():
             f.flush()
         return take
-    if kind == "bits":
+    if kind == "vad":
+        nv = lib.refcap_count_vad()
+        assert nv >= nfr, (nv, nfr)
+        assert [lib.refcap_sizes_vad(k) for k in range(4)] == [SIZES["vad_in"], SIZES["vad_state"], SIZES["vad_out"], SIZES["vad_state"]]
+        bufs = [np.zeros((nv, SIZES["vad_in"]), np.uint8), np.zeros((nv, SIZES["vad_state"]), np.uint8),
+                np.zeros((nv, SIZES["vad_state"]), np.uint8), np.zeros((nv, SIZES["vad_out"]), np.uint8)]
+        lib.refcap_get_vad(*[_p(b) for b in bufs])
+        for name, b in zip(("vad_in", "vad_state_in", "vad_state_out", "vad_out"), bufs):
+            files[name][row0:row0 + take] = b[:take]          # from the first frame: the start-up of the noise-level tracker counts
+    elif kind == "bits":
         assert [lib.refcap_sizes_bits(k) for k in range(3)] == [SIZES["bits_in"], SIZES["ec_state"], SIZES["bits_out"]]
         for which, tag in ((0, "idx"), (1, "pls")):
             nb_ = lib.refcap_count_bits(which)
@@ -311,6 +323,7 @@ _LAYOUT = {
     "gains": (("gains_in", "gains_in"), ("gains_out", "gains_out")),
     "shape": (("shape_in", "shape_in"), ("shape_out", "shape_out")),
     "pitch": (("pitch_in", "pitch_in"), ("pitch_out", "pitch_out")),
+    "vad": (("vad_in", "vad_in"), ("vad_state_in", "vad_state"), ("vad_state_out", "vad_state"), ("vad_out", "vad_out")),
     "bits": (("bits_idx_in", "bits_in"), ("bits_idx_ec_in", "ec_state"), ("bits_idx_ec_out", "ec_state"), ("bits_idx_out", "bits_out"),
              ("bits_pls_in", "bits_in"), ("bits_pls_ec_in", "ec_state"), ("bits_pls_ec_out", "ec_state"), ("bits_pls_out", "bits_out")),
     # aligned capture of ONE encoder run: row r of every array belongs to the same frame (first call of the frame)
@@ -355,7 +368,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
         while row < n:
             take = min(SEG_FRAMES, n - row)
             k = len(jobs)
-            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "bits": 160481183, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
+            jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "bits": 160481183, "vad": 179424673, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
                          row, take, n, variant))
             row += take
         workers = workers or max(1, min(len(jobs), len(os.sched_getaffinity(0)), 16))

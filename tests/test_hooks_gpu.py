@@ -430,6 +430,34 @@ def test_the_four_frame_analysis_hooks_with_the_reference_argument_lists(L, ref)
         both(r.silk_prefilter_FIX, L.opusgpu_silk_prefilter_FIX, mk)
 
 
+def test_silk_VAD_hook_with_the_reference_argument_list(L, ref):
+    """opusgpu_silk_VAD_GetSA_Q8_c(psEncC, pIn) beside silk_VAD_GetSA_Q8_c of the compiled reference on identical silk_encoder_state
+    images (zero except frame_length, fs_kHz and sVAD): every byte of the structure compared afterwards."""
+    import silk_corpus
+    from concentus_amd import silk as S
+    r, _ = ref
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    d = header_defines()
+    c = silk_corpus.corpus(4096, "vad", complexities=(5,))
+    vin, vst = np.asarray(c["vad_in"]), np.asarray(c["vad_state_in"])
+    for k in list(range(0, 40)) + list(range(40, 4096, 157)):
+        R = np.frombuffer(np.ascontiguousarray(vin[k]).tobytes(), np.dtype(S.VadIn))[0]
+        imgs = []
+        for fn in (r.silk_VAD_GetSA_Q8_c, L.opusgpu_silk_VAD_GetSA_Q8_c):
+            enc = np.zeros(d["OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE"], np.uint8)
+            for name, f in (("FRAME_LENGTH", "frame_length"), ("FS_KHZ", "fs_kHz")):
+                o = d["OPUSGPU_REF_OFF_" + name]
+                enc[o:o + 4].view(np.int32)[0] = int(R[f])
+            enc[d["OPUSGPU_REF_OFF_SVAD"]:][:112] = vst[k]
+            pin = np.ascontiguousarray(R["pIn"]).astype(np.int16)
+            fn.restype = C.c_int
+            assert fn(p(enc), p(pin)) == 0
+            imgs.append(enc)
+        assert L.opusgpu_get_last_error() == 0
+        assert np.array_equal(imgs[0], imgs[1]), (k, np.nonzero(imgs[0] != imgs[1])[0][:8])
+
+
 def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
     """opusgpu_quant_all_bands with the tree's 21-argument list and its ec_ctx (EC_DIFF included) against quant_all_bands of the
     compiled reference ON THE CALLS THE REFERENCE ENCODER ITSELF MAKES: oracle/_ref/libopus_ref_celtcap.so (--wrap=quant_all_bands,

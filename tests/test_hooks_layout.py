@@ -90,6 +90,8 @@ PAIRS = {
     "OPUSGPU_REF_OFF_CTRL_LAST_GAIN_INDEX_PREV": "silk_encoder_control_FIX.lastGainIndexPrev",
     "OPUSGPU_REF_SIZEOF_SILK_PREFILTER_STATE_FIX": "sizeof.silk_prefilter_state_FIX",
     "OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE_FIX": "sizeof.silk_encoder_state_FIX",
+    "OPUSGPU_REF_OFF_SVAD": "silk_encoder_state.sVAD",
+    "OPUSGPU_REF_SIZEOF_SILK_VAD_STATE": "sizeof.silk_VAD_state",
 }
 
 

@@ -537,3 +537,24 @@ def test_encode_indices_and_pulses_vs_the_reference_range_coder(ca, variant):
     o2 = ca.silk_encode_bits(_dev(bad_in), ec2).cpu().numpy()
     assert ca.silk.bad_records() == 1 and o2[5, 8:12].view(np.int32)[0] == -1
     assert np.array_equal(ec2.cpu().numpy()[5], np.asarray(rec["bits_idx_ec_in"])[5]), "a skipped record leaves its coder untouched"
+
+
+@pytest.mark.parametrize("variant", ["wb20", "nb20", "wb10"])
+def test_vad_vs_reference_outputs(ca, variant):
+    """silk_VAD_GetSA_Q8_c on the GPU against the unmodified reference (tests/silk_corpus.py kind "vad", from the first frame of every
+    encoder so that the start-up of the noise-level tracker is covered): speech_activity_Q8, input_tilt_Q15,
+    input_quality_bands_Q15[4] and every byte of silk_VAD_state after the call."""
+    import torch
+    import silk_corpus
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    rec = silk_corpus.corpus(16384 if variant == "wb20" else 4096, "vad", variant=variant, complexities=(5,))
+    st = _dev(rec["vad_state_in"])
+    out = ca.silk_VAD_GetSA_Q8(_dev(rec["vad_in"]), st)
+    torch.cuda.synchronize()
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    assert np.array_equal(out[:, :24], np.asarray(rec["vad_out"])[:, :24]) and (out[:, 24:28].view(np.int32) == 0).all()
+    bad = np.nonzero((st != np.asarray(rec["vad_state_out"])).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:6])
+    sa = np.asarray(rec["vad_out"])[:, :4].view(np.int32)[:, 0]
+    assert (sa > 200).sum() > 500 and (sa < 30).sum() > 200, "active speech and pauses"

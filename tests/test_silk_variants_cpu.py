@@ -19,11 +19,12 @@ CASES = {      # kind -> (input key(s), output key, bytes compared, emu entry, o
     "shape": ("shape_in", "shape_out", 380, "emu_silk_noise_shape_analysis", None),
     "prefilter": ("prefilter_in", "prefilter_out", 1280, "emu_silk_prefilter", ("prefilter_state_in", "prefilter_state_out")),
     "pitch": ("pitch_in", "pitch_out", 1380, "emu_silk_find_pitch_lags", None),
+    "vad": ("vad_in", "vad_out", 24, "emu_silk_vad", ("vad_state_in", "vad_state_out")),
 }
 
 
 @pytest.mark.ref
-@pytest.mark.parametrize("variant", ["nb20", "wb10", "wb40"])
+@pytest.mark.parametrize("variant", ["wb20", "nb20", "wb10", "wb40"])
 @pytest.mark.parametrize("kind", sorted(CASES))
 def test_analysis_sources_match_the_reference_at_other_rates_and_frame_sizes(kind, variant):
     if not silk_corpus.available():
