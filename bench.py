@@ -370,6 +370,24 @@ def cpu_baseline_silk_analysis(recs):
                       % (n, cores, one)}
 
 
+def cpu_baseline_silk_bits(bin_, ec0):
+    """CPU baseline for silk_encode_indices + silk_encode_pulses records: the kernel sources compiled for the host (tests/emu, "port")."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import emulib
+    emu = emulib.lib()
+    cores = host_threads()
+    n = bin_.shape[0]
+    out = np.zeros((n, 16), np.uint8)
+
+    def work(lo, hi):
+        ec = ec0[lo:hi].copy()
+        emu.emu_silk_encode_bits(C.c_void_p(bin_.ctypes.data + lo * 416), _p(ec), C.c_void_p(out.ctypes.data + lo * 16), C.c_long(hi - lo))
+    one, multi = _time_cpu(_pool_run(work, n), n, cores)
+    return {"value": round(multi, 1), "unit": "frames/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "sample": "%d (silk_encode_indices + silk_encode_pulses) records per pass through the host build of "
+                      "concentus_amd/csrc/silk_bits_dev.h, repeated ~8 s on %d thread(s); 1 thread: %.0f frames/s" % (n, cores, one)}
+
+
 def cpu_baseline_silk_pred(fin):
     """CPU baseline for silk_find_pred_coefs_FIX records: the kernel sources compiled for the host (tests/emu, kind "port")."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -782,9 +800,11 @@ def main(argv=None):
             sub = {k[2:]: np.ascontiguousarray(v[:m_cpu]) for k, v in rec.items() if k.startswith("c_") and not k.startswith("c_q")}
             a_ = cpu_baseline_silk_analysis(sub)
             b_ = cpu_baseline_silk_dd(np.ascontiguousarray(rec["c_q_in"][:m_cpu]), np.ascontiguousarray(rec["c_q_state_in"][:m_cpu]))
-            v = 1.0 / (1.0 / a_["value"] + 1.0 / b_["value"])
+            c_ = cpu_baseline_silk_bits(np.ascontiguousarray(rec["c_bits_in"][:m_cpu]), np.ascontiguousarray(rec["c_ec_in"][:m_cpu]))
+            v = 1.0 / (1.0 / a_["value"] + 1.0 / b_["value"] + 1.0 / c_["value"])
             return {"value": round(v, 1), "unit": "frames/s", "cores": a_["cores"], "kind": "port", "cpu": a_["cpu"],
-                    "sample": "analysis: " + a_["sample"] + "; quantiser: " + b_["sample"] + "; combined as 1 / (1/a + 1/b)"}
+                    "sample": "analysis: " + a_["sample"] + "; quantiser: " + b_["sample"] + "; entropy coding: " + c_["sample"]
+                              + "; combined as 1 / (1/a + 1/b + 1/c)"}
         if not a.no_parity and rank == 0:
             for key, want, nb in (("pitch_out", "c_pitch_out", 1380), ("shape_out", "c_shape_out", 380), ("fpc_out", "c_fpc_out", 204),
                                   ("gains_out", "c_gains_out", 52), ("prefilter_out", "c_prefilter_out", 1280)):
