@@ -35,7 +35,7 @@ traffic = {}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 if os.path.exists(tp):
     traffic = json.load(open(tp))
-for name in ("traffic_celt.json", "traffic_mdct.json", "traffic_decode.json"):
+for name in ("traffic_celt.json", "traffic_mdct.json", "traffic_decode.json", "traffic_silk_frames.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         for k, v in json.load(open(p)).items():

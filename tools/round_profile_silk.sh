@@ -10,3 +10,7 @@ for w in silk_frames silk_analysis silk_pred silk_nlsf; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > $O/bench_prof_$w.json 2> $O/prof_$w.err
   echo "$w rc=$?"; cut -c1-200 $O/bench_prof_$w.json
 done
+w=silk_frames
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${w}_pmc_fetch -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof_pmc_$w.err &&
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${w}_pmc_write -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof_pmc_$w.err &&
+python3 $R/tools/pmc_traffic.py $O/${w}_pmc_fetch $O/${w}_pmc_write $O/traffic_$w.json > /dev/null
