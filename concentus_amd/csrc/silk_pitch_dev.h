@@ -102,29 +102,18 @@ CA_DEV i32 pe_inner_prod(XA x, YA y, int len)                                   
     return s;
 }
 
-// pitch_analysis_core_FIX.c:598-746: correlations and energies of every subframe against the lags the stage-3 code books
-// can reach; `frame` is the (possibly down-shifted) full-rate signal.
+// pitch_analysis_core_FIX.c:598-746: correlations and energies of every subframe against the lags the stage-3 code books can
+// reach; `frame` is the (possibly down-shifted) full-rate signal. The reference expands both into [subframe][code book vector][5]
+// arrays (2 x 2.7 KB); kept here as the per-subframe lag tables they are copied from (2 x 4 x 22 values) -- the search below
+// indexes them with the same `Lag_CB - lag_low + lag_counter` the copy loop used.
 template <class XA>
-CA_DEV void pe_calc_corr_energy_st3(i32 (*cross_corr_st3)[PE_NB_STAGE3_LAGS], i32 (*energies_st3)[PE_NB_STAGE3_LAGS], XA frame, int start_lag,
-                                    int sf_length, int nb_subfr, int complexity)
+CA_DEV void pe_calc_corr_energy_st3(i32 *corr /*[4][PE_SCRATCH_SIZE]*/, i32 *nrg /*[4][PE_SCRATCH_SIZE]*/, XA frame, int start_lag, int sf_length,
+                                    int nb_subfr, const i8 *Lag_range_ptr)
 {
-    const i8 *Lag_range_ptr, *Lag_CB_ptr;
-    int nb_cbk_search, cbk_size;
-    if (nb_subfr == PE_MAX_NB_SUBFR) {
-        Lag_range_ptr = &SILK_Lag_range_stage3[complexity * 8];
-        Lag_CB_ptr = SILK_CB_lags_stage3;
-        nb_cbk_search = SILK_nb_cbk_searchs_stage3[complexity];
-        cbk_size = PE_NB_CBKS_STAGE3_MAX;
-    } else {
-        Lag_range_ptr = SILK_Lag_range_stage3_10_ms;
-        Lag_CB_ptr = SILK_CB_lags_stage3_10_ms;
-        nb_cbk_search = PE_NB_CBKS_STAGE3_10MS;
-        cbk_size = PE_NB_CBKS_STAGE3_10MS;
-    }
-    i32 scratch_c[PE_SCRATCH_SIZE], scratch_e[PE_SCRATCH_SIZE];
     for (int k = 0; k < nb_subfr; k++) {
         const int t0 = 4 * sf_length + k * sf_length;                                       // target_ptr
         const int lag_low = Lag_range_ptr[k * 2], lag_high = Lag_range_ptr[k * 2 + 1];
+        i32 *scratch_c = corr + k * PE_SCRATCH_SIZE, *scratch_e = nrg + k * PE_SCRATCH_SIZE;
         // correlations: scratch[j - lag_low] = <target, target - start_lag - j>, j = lag_low .. lag_high
         for (int j = lag_low; j <= lag_high; j++) scratch_c[j - lag_low] = pe_inner_prod(frame + t0, frame + (t0 - start_lag - j), sf_length);
         // energies, recursively from the first lag (:713-727)
@@ -137,13 +126,6 @@ CA_DEV void pe_calc_corr_energy_st3(i32 (*cross_corr_st3)[PE_NB_STAGE3_LAGS], i3
             energy -= __mul24(a, a);
             energy = s_add_sat32(energy, __mul24(b, b));
             scratch_e[i] = energy;
-        }
-        for (int i = 0; i < nb_cbk_search; i++) {
-            const int idx = Lag_CB_ptr[k * cbk_size + i] - lag_low;
-            for (int j = 0; j < PE_NB_STAGE3_LAGS; j++) {
-                cross_corr_st3[k * nb_cbk_search + i][j] = scratch_c[idx + j];
-                energies_st3[k * nb_cbk_search + i][j] = scratch_e[idx + j];
-            }
         }
     }
 }
@@ -330,17 +312,20 @@ CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *
         CBimax = 0;
         CCmax = (i32)0x80000000;
         for (int k = 0; k < nb_subfr; k++) pitch_out[k] = lag + 2 * SILK_CB_lags_stage2[k * PE_NB_CBKS_STAGE2_EXT + CBimax_old];
+        const i8 *Lag_range_ptr;
         if (nb_subfr == PE_MAX_NB_SUBFR) {
             nb_cbk_search = SILK_nb_cbk_searchs_stage3[complexity];
             cbk_size = PE_NB_CBKS_STAGE3_MAX;
             Lag_CB_ptr = SILK_CB_lags_stage3;
+            Lag_range_ptr = &SILK_Lag_range_stage3[complexity * 8];
         } else {
             nb_cbk_search = PE_NB_CBKS_STAGE3_10MS;
             cbk_size = PE_NB_CBKS_STAGE3_10MS;
             Lag_CB_ptr = SILK_CB_lags_stage3_10_ms;
+            Lag_range_ptr = SILK_Lag_range_stage3_10_ms;
         }
-        i32 energies_st3[PE_MAX_NB_SUBFR * PE_NB_CBKS_STAGE3_MAX][PE_NB_STAGE3_LAGS], cross_corr_st3[PE_MAX_NB_SUBFR * PE_NB_CBKS_STAGE3_MAX][PE_NB_STAGE3_LAGS];
-        pe_calc_corr_energy_st3(cross_corr_st3, energies_st3, scr, start_lag, sf_length, nb_subfr, complexity);
+        i32 corr_st3[PE_MAX_NB_SUBFR * PE_SCRATCH_SIZE], nrg_st3[PE_MAX_NB_SUBFR * PE_SCRATCH_SIZE];
+        pe_calc_corr_energy_st3(corr_st3, nrg_st3, scr, start_lag, sf_length, nb_subfr, Lag_range_ptr);
         int lag_counter = 0;
         const i32 contour_bias_Q15 = 1638 / lag;                                           // PE_FLATCONTOUR_BIAS Q15
         const i32 energy_target = s_addw(pe_inner_prod(scr + PE_LTP_MEM_LENGTH_MS * Fs_kHz, scr + PE_LTP_MEM_LENGTH_MS * Fs_kHz, nb_subfr * sf_length), 1);
@@ -349,8 +334,9 @@ CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *
                 i32 cross_corr = 0;
                 energy = energy_target;
                 for (int k = 0; k < nb_subfr; k++) {
-                    cross_corr = s_addw(cross_corr, cross_corr_st3[k * nb_cbk_search + j][lag_counter]);
-                    energy = s_addw(energy, energies_st3[k * nb_cbk_search + j][lag_counter]);
+                    const int idx = k * PE_SCRATCH_SIZE + Lag_CB_ptr[k * cbk_size + j] - Lag_range_ptr[k * 2] + lag_counter;
+                    cross_corr = s_addw(cross_corr, corr_st3[idx]);
+                    energy = s_addw(energy, nrg_st3[idx]);
                 }
                 i32 CCmax_new = 0;
                 if (cross_corr > 0) {
