@@ -149,6 +149,15 @@ __device__ __forceinline__ bool vad_record_ok(const opusgpu_vad_in &in, const op
     return true;
 }
 
+__device__ __forceinline__ bool rate_ctl_record_ok(const opusgpu_silk_rate_ctl &c, unsigned rng)
+{
+    if (!((c.nb_subfr == 2 || c.nb_subfr == 4) && c.frame_length >= 80 && c.frame_length <= OPUSGPU_SILK_MAX_FRAME)) return false;   // a divisor
+    if ((unsigned)c.condCoding > 2u || (unsigned)c.useCBR > 1u || c.maxBits < 0 || rng == 0) return false;
+    if (c.LastGainIndex < -128 || c.LastGainIndex > 127 || c.lastGainIndexPrev < -128 || c.lastGainIndexPrev > 127) return false;    // opus_int8 fields
+    if (c.started && ((unsigned)c.iter > 6u || c.gainMult_Q8 < -32768 || c.gainMult_Q8 > 32767)) return false;
+    return true;
+}
+
 __device__ __forceinline__ bool nsq_record_ok(const opusgpu_nsq_in &in, int lagPrev)
 {
     const int n = in.nb_subfr, L = in.subfr_length, ltp = in.ltp_mem_length, po = in.predictLPCOrder, so = in.shapingLPCOrder;

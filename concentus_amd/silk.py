@@ -392,6 +392,32 @@ def silk_encode_bits(bits_in, ec_state, bits_out=None):
     return bits_out
 
 
+class RateCtl(C.Structure):
+    """opusgpu_silk_rate_ctl: the locals of silk_encode_frame_FIX's bitrate loop for one frame (opus-fix/silk/fixed/encode_frame_FIX.c:263-423)."""
+    _fields_ = [(k, C.c_int32) for k in ("maxBits", "useCBR", "condCoding", "nb_subfr", "frame_length", "started")] + [
+        ("reserved0", C.c_int32 * 2), ("GainsUnq_Q16", C.c_int32 * 4), ("Gains_Q16", C.c_int32 * 4), ("lastGainIndexPrev", C.c_int32),
+        ("LastGainIndex", C.c_int32), ("Lambda_Q10", C.c_int32), ("GainsIndices", C.c_int8 * 4)] + [(k, C.c_int32) for k in (
+            "iter", "gainMult_Q8", "found_lower", "found_upper", "nBits_lower", "nBits_upper", "gainMult_lower", "gainMult_upper",
+            "gainsID", "gainsID_lower", "gainsID_upper", "LastGainIndex_copy2", "done", "recode", "save2", "restore2", "nBits", "passes",
+            "status", "reserved1")]
+
+
+SIZES["silk_rate_ctl"] = C.sizeof(RateCtl)
+
+
+def silk_rate_control(rate_ctl, ec_state):
+    """One step of silk_encode_frame_FIX's bitrate loop over a batch: rate_ctl uint8 [N][160] (opusgpu_silk_rate_ctl, updated in place),
+    ec_state uint8 [N][1328] (the coder after the pass just coded; read only). Sets done / recode / save2 / restore2 per frame."""
+    _check(rate_ctl, SIZES["silk_rate_ctl"], "rate_ctl")
+    _check(ec_state, SIZES["ec_state"], "ec_state")
+    n = rate_ctl.shape[0]
+    if ec_state.shape[0] != n:
+        raise ValueError("ec_state: %d records for %d frames" % (ec_state.shape[0], n))
+    rc = _lib.load().opusgpu_silk_rate_control_batch(rate_ctl.data_ptr(), ec_state.data_ptr(), n, _lib.current_stream_handle())
+    _lib.check(rc, "opusgpu_silk_rate_control_batch")
+    return rate_ctl
+
+
 class VadState(C.Structure):
     """opusgpu_vad_state == silk_VAD_state (opus-fix/silk/structs.h:60-73)."""
     _fields_ = [("AnaState", C.c_int32 * 2), ("AnaState1", C.c_int32 * 2), ("AnaState2", C.c_int32 * 2), ("XnrgSubfr", C.c_int32 * 4),

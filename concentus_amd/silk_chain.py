@@ -46,13 +46,18 @@ class SilkAnalysisChain:
         v = src[:, so:so + 1].contiguous().view(torch.int8).to(torch.int32)
         dst[:, do:do + 4] = v.view(torch.uint8)
 
-    def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec, bits_in=None, ec_state=None):
+    def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec, bits_in=None, ec_state=None,
+            rate_ctl=None):
         """All arguments are uint8 CUDA tensors [N][record bytes]. shape_in / fpc_in / gains_in / prefilter_in / q_in are
         completed in place from the outputs of the earlier stages; prefilter_state and nsq_state are updated in place.
         q_in is opusgpu_nsq_dd_in when del_dec else opusgpu_nsq_in. With bits_in / ec_state (opusgpu_silk_bits_in with which = 3, the
         frame's range coder) the side information and the excitation are entropy-coded as well (silk_encode_indices +
-        silk_encode_pulses): ec_state is updated in place. Returns a dict of the stage outputs; "pulses" is int8 [N][320] (and
-        "Seed" int32 [N] for the delayed-decision quantiser)."""
+        silk_encode_pulses): ec_state is updated in place. With rate_ctl (opusgpu_silk_rate_ctl per frame: maxBits, useCBR, condCoding,
+        nb_subfr, frame_length set, the rest zero) the bitrate loop of silk_encode_frame_FIX (encode_frame_FIX.c:263-423) runs as well:
+        frames over / under their bit budget are quantised and coded again with adjusted gains, up to six more times, each time from
+        the coder and quantiser state they entered with; nsq_state / ec_state / "pulses" / "Seed" / bits_in end as the reference
+        leaves them, rate_ctl holds LastGainIndex, GainsIndices and the number of passes. Returns a dict of the stage outputs;
+        "pulses" is int8 [N][320] (and "Seed" int32 [N] for the delayed-decision quantiser)."""
         import torch
         mv, fl, ltp = self._move, self.frame_length, self.ltp_mem_length
         PO, SI, SO, FI, FO, GI, GO, XI, XO, Q = (S.FindPitchLagsOut, S.NoiseShapeIn, S.NoiseShapeOut, S.FindPredCoefsIn, S.FindPredCoefsOut,
@@ -96,6 +101,10 @@ class SilkAnalysisChain:
         mv(q_in, Q, "pitchL", pitch_out, PO, "pitchL")
         mv(q_in, Q, "signalType", pitch_out, PO, "signalType")
         out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out}
+        if rate_ctl is not None:
+            if bits_in is None or ec_state is None:
+                raise ValueError("rate_ctl needs bits_in and ec_state: the loop measures the coder")
+            nsq_entry, ec_entry = nsq_state.clone(), ec_state.clone()       # sNSQ_copy / sRangeEnc_copy (encode_frame_FIX.c:272-273)
         if del_dec:
             dd_out = S.silk_NSQ_del_dec(q_in, nsq_state)
             out["pulses"] = dd_out[:, :320].view(torch.int8)
@@ -118,7 +127,61 @@ class SilkAnalysisChain:
                 so, _ = _off(B, "Seed")
                 bits_in[:, so:so + 4] = dd_out[:, 320:324]
             out["bits_out"] = S.silk_encode_bits(bits_in, ec_state)
+        if rate_ctl is not None:
+            R = S.RateCtl
+            for name in ("GainsUnq_Q16", "Gains_Q16", "lastGainIndexPrev", "LastGainIndex", "Lambda_Q10", "GainsIndices"):
+                mv(rate_ctl, R, name, gains_out, GO, name)
+            self._rate_loop(rate_ctl, q_in, nsq_state, nsq_entry, ec_state, ec_entry, bits_in, del_dec, out)
+            out["rate_ctl"] = rate_ctl
         return out
+
+    def _rate_loop(self, rate_ctl, q_in, nsq_state, nsq_entry, ec_state, ec_entry, bits_in, del_dec, out):
+        """encode_frame_FIX.c:276-423 over the batch: one opusgpu_silk_rate_control_batch step after every pass decides per frame; the
+        frames that need another pass are gathered, quantised + coded from their entry states, and scattered back."""
+        import torch
+        mv, R, Q, B = self._move, S.RateCtl, S.NsqIn, S.SilkBitsIn
+        f0, _ = _off(R, "done")
+        po, _ = _off(B, "pulses")
+        so, _ = _off(B, "Seed")
+        nsq_low = ec_low = None                                             # sNSQ_copy2 / sRangeEnc_copy2 + ec_buf_copy, allocated on first use
+        for _ in range(8):                                                  # iter 0 .. maxIter: at most 7 passes, each followed by a step
+            S.silk_rate_control(rate_ctl, ec_state)
+            flags = rate_ctl[:, f0:f0 + 16].contiguous().view(torch.int32)  # done, recode, save2, restore2
+            keep = flags[:, 2].nonzero().squeeze(1)
+            if keep.numel():
+                if nsq_low is None:
+                    nsq_low, ec_low = torch.zeros_like(nsq_state), torch.zeros_like(ec_state)
+                nsq_low[keep] = nsq_state[keep]
+                ec_low[keep] = ec_state[keep]
+            back = flags[:, 3].nonzero().squeeze(1)
+            if back.numel():
+                nsq_state[back] = nsq_low[back]
+                ec_state[back] = ec_low[back]
+            rows = flags[:, 1].nonzero().squeeze(1)
+            if rows.numel() == 0:
+                return
+            ctl = rate_ctl[rows]
+            q = q_in[rows]
+            mv(q, Q, "Gains_Q16", ctl, R, "Gains_Q16")
+            mv(q, Q, "Lambda_Q10", ctl, R, "Lambda_Q10")
+            nsq, ec, b = nsq_entry[rows], ec_entry[rows], bits_in[rows]
+            if del_dec:
+                dd_out = S.silk_NSQ_del_dec(q, nsq)
+                pulses = dd_out[:, :320]
+                b[:, so:so + 4] = dd_out[:, 320:324]
+                out["Seed"][rows] = dd_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
+            else:
+                pulses = S.silk_NSQ(q, nsq).view(torch.uint8)
+            b[:, po:po + 320] = pulses
+            mv(b, B, "GainsIndices", ctl, R, "GainsIndices")
+            bits_out = S.silk_encode_bits(b, ec)
+            nsq_state[rows] = nsq
+            ec_state[rows] = ec
+            bits_in[rows] = b
+            q_in[rows] = q
+            out["pulses"][rows] = pulses.view(torch.int8)
+            out["bits_out"][rows] = bits_out
+        raise RuntimeError("silk rate loop: frames still asking for a pass after maxIter")
 
 
 CHAIN_FED_FIELDS = {       # the record fields run() fills: a caller (and the test) may leave them zero

@@ -398,6 +398,34 @@ typedef struct opusgpu_vad_out {
 
 int opusgpu_silk_vad_batch(const opusgpu_vad_in *d_in, opusgpu_vad_state *d_state, opusgpu_vad_out *d_out, int n, void *hip_stream);
 
+/* ---- the bitrate-control loop of silk_encode_frame_FIX, batched (tenth slice) ---------------------------
+ * Replaces the control arithmetic of the `for( iter = 0; ; iter++ )` loop of silk_encode_frame_FIX
+ * (opus-fix/silk/fixed/encode_frame_FIX.c:276-423): after every quantise + entropy-code pass of a frame it compares the
+ * coder's ec_tell() with maxBits, keeps the lower / upper bracket, moves the gain multiplier (rate/distortion slope or
+ * interpolation), raises Lambda_Q10, re-quantises the gains (silk_gains_quant, silk/gain_quant.c:41) and says what the host
+ * must do before the next pass. One record per frame carries the loop's locals between passes; zero `started` before the
+ * first call. A step consumes the pass just coded (the frame's opusgpu_ec_state) and runs on until the frame is finished
+ * (`done`) or needs another pass (`recode`: quantise with Gains_Q16 / Lambda_Q10, code with GainsIndices, both from the
+ * coder / quantiser state the frame ENTERED with); `save2` asks to keep a copy of the coder + quantiser state of the pass
+ * just consumed (the loop's sRangeEnc_copy2 / sNSQ_copy2, :389-395), `restore2` to make that copy the frame's result (:361-368).
+ * Finished frames are left untouched by later steps. */
+typedef struct opusgpu_silk_rate_ctl {
+    int32_t maxBits, useCBR, condCoding, nb_subfr;       /* arguments of silk_encode_frame_FIX / psEnc->sCmn.nb_subfr */
+    int32_t frame_length, started, reserved0[2];
+    int32_t GainsUnq_Q16[4];                             /* sEncCtrl.GainsUnq_Q16 (silk_process_gains_FIX) */
+    int32_t Gains_Q16[4];                                /* out: sEncCtrl.Gains_Q16 of the next pass */
+    int32_t lastGainIndexPrev, LastGainIndex;            /* sEncCtrl.lastGainIndexPrev; psEnc->sShape.LastGainIndex (in / out) */
+    int32_t Lambda_Q10;                                  /* in / out */
+    int8_t GainsIndices[4];                              /* psEnc->sCmn.indices.GainsIndices (in / out) */
+    int32_t iter, gainMult_Q8, found_lower, found_upper; /* the loop's locals */
+    int32_t nBits_lower, nBits_upper, gainMult_lower, gainMult_upper;
+    int32_t gainsID, gainsID_lower, gainsID_upper, LastGainIndex_copy2;
+    int32_t done, recode, save2, restore2;               /* out: decisions of this step */
+    int32_t nBits, passes, status, reserved1;            /* ec_tell() of the pass consumed; passes coded so far */
+} opusgpu_silk_rate_ctl;
+
+int opusgpu_silk_rate_control_batch(opusgpu_silk_rate_ctl *d_ctl, const opusgpu_ec_state *d_ec, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

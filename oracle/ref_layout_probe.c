@@ -65,6 +65,10 @@ int main(void)
     F(SideInfoIndices, signalType); F(SideInfoIndices, quantOffsetType); F(SideInfoIndices, NLSFInterpCoef_Q2);
     F(SideInfoIndices, Seed); F(SideInfoIndices, NLSFIndices);
     F(SideInfoIndices, LTPIndex); F(SideInfoIndices, PERIndex); F(SideInfoIndices, LTP_scaleIndex);
+    F(silk_encoder_state, inputBuf); F(silk_encoder_state, frameCounter); F(silk_encoder_state, prefillFlag); F(silk_encoder_state, sLP);
+    F(silk_LP_state, mode); F(silk_encoder_state, LBRR_enabled); F(silk_encoder_state, pulses); F(silk_encoder_state, sNSQ);
+    F(silk_encoder_state, nFramesEncoded); F(silk_encoder_state, ec_prevLagIndex); F(silk_encoder_state, ec_prevSignalType);
+    F(silk_encoder_state_FIX, x_buf);
     printf("  \"sizeof.silk_encoder_state\": %zu,\n  \"sizeof.SideInfoIndices\": %zu,\n  \"sizeof.silk_nsq_state\": %zu,\n  \"sizeof.silk_encoder_control_FIX\": %zu,\n  \"sizeof.silk_prefilter_state_FIX\": %zu,\n  \"sizeof.silk_encoder_state_FIX\": %zu,\n  \"sizeof.silk_VAD_state\": %zu\n}\n",
            sizeof(silk_encoder_state), sizeof(SideInfoIndices), sizeof(silk_nsq_state), sizeof(silk_encoder_control_FIX),
            sizeof(silk_prefilter_state_FIX), sizeof(silk_encoder_state_FIX), sizeof(silk_VAD_state));

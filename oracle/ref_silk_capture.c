@@ -1,5 +1,5 @@
 /* oracle/ref_silk_capture.c -- TEST INFRASTRUCTURE ONLY.
- * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX,--wrap=silk_encode_indices,--wrap=silk_encode_pulses,--wrap=silk_VAD_GetSA_Q8_c into a capture variant of the compiled
+ * Linked with -Wl,--wrap=silk_burg_modified_c,--wrap=silk_NSQ_c,--wrap=silk_NSQ_del_dec_c,--wrap=silk_find_LPC_FIX,--wrap=silk_process_NLSFs,--wrap=silk_residual_energy_FIX,--wrap=silk_find_pred_coefs_FIX,--wrap=silk_process_gains_FIX,--wrap=silk_noise_shape_analysis_FIX,--wrap=silk_prefilter_FIX,--wrap=silk_find_pitch_lags_FIX,--wrap=silk_encode_indices,--wrap=silk_encode_pulses,--wrap=silk_VAD_GetSA_Q8_c,--wrap=silk_encode_frame_FIX into a capture variant of the compiled
  * reference (oracle/_ref/libopus_ref_silkcap.so): every call of the two SILK functions on the hot
  * path is forwarded to the real reference code and its arguments / results are recorded as the flat
  * records of include/opusgpu_silk.h ("capture at the function boundary", SURVEY.md 4: the NailTester
@@ -13,7 +13,8 @@ typedef char nsq_state_layout_check[sizeof(silk_nsq_state) == sizeof(opusgpu_nsq
 
 /* Frame bookkeeping for the aligned ("chain") capture: g_frame counts calls of silk_find_pitch_lags_FIX (one per encoded frame);
  * every wrap notes the frame its record belongs to, so that the records of one frame can be matched across functions. */
-enum { FID_PITCH, FID_SHAPE, FID_FPC, FID_GAINS, FID_PREFILTER, FID_NSQ, FID_DD, FID_BITS_IDX, FID_BITS_PLS, FID_KINDS };
+enum { FID_PITCH, FID_SHAPE, FID_FPC, FID_GAINS, FID_PREFILTER, FID_NSQ, FID_DD, FID_BITS_IDX, FID_BITS_PLS, FID_FRAME, FID_KINDS };
+static int g_q_calls;      /* quantiser calls (silk_NSQ_c + silk_NSQ_del_dec_c), recorded or not */
 static int g_frame, *g_fid[FID_KINDS], g_fid_cap;
 static void fid_note(int kind, int rec) { if (g_fid[kind] && rec >= 0 && rec < g_fid_cap) g_fid[kind][rec] = g_frame; }
 void refcap_get_frame_ids(int kind, int *out, int n) { if (g_fid[kind]) memcpy(out, g_fid[kind], sizeof(int) * (size_t)n); }
@@ -75,6 +76,7 @@ void __wrap_silk_NSQ_c(const silk_encoder_state *psEncC, silk_nsq_state *NSQ, Si
 {
     int rec = (g_on && g_nin && g_nn < g_capn && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nn : -1;
     fid_note(FID_NSQ, rec);
+    g_q_calls++;
     if (rec >= 0) {
         opusgpu_nsq_in *r = &g_nin[rec];
         r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
@@ -132,6 +134,7 @@ void __wrap_silk_NSQ_del_dec_c(const silk_encoder_state *psEncC, silk_nsq_state 
 {
     int rec = (g_on && g_din && g_nd < g_capd && psEncC->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nd : -1;
     fid_note(FID_DD, rec);
+    g_q_calls++;
     if (rec >= 0) {
         opusgpu_nsq_in *r = &g_din[rec].base;
         r->nb_subfr = psEncC->nb_subfr; r->subfr_length = psEncC->subfr_length; r->frame_length = psEncC->frame_length;
@@ -529,10 +532,11 @@ void __wrap_silk_find_pitch_lags_FIX(silk_encoder_state_FIX *psEnc, silk_encoder
 /* Aligned capture of one encoder run: every analysis function and both quantisers record at once. */
 void refcap_start_dd(int max_records);
 void refcap_start_bits(int max_records);
+void refcap_start_frame(int max_records);
 void refcap_start_chain(int max_records)
 {
     refcap_start(max_records); refcap_start_dd(max_records); refcap_start_bits(max_records); refcap_start_fpc(max_records); refcap_start_gains(max_records);
-    refcap_start_shape(max_records); refcap_start_prefilter(max_records); refcap_start_pitch(max_records);
+    refcap_start_shape(max_records); refcap_start_prefilter(max_records); refcap_start_pitch(max_records); refcap_start_frame(max_records);
     g_frame = 0; g_fid_cap = max_records;
     for (int k = 0; k < FID_KINDS; k++) g_fid[k] = (int *)calloc(max_records, sizeof(int));
 }
@@ -639,6 +643,48 @@ opus_int __wrap_silk_VAD_GetSA_Q8_c(silk_encoder_state *psEncC, const opus_int16
         g_vout[rec].speech_activity_Q8 = psEncC->speech_activity_Q8; g_vout[rec].input_tilt_Q15 = psEncC->input_tilt_Q15;
         for (int k = 0; k < VAD_N_BANDS; k++) g_vout[rec].input_quality_bands_Q15[k] = psEncC->input_quality_bands_Q15[k];
         g_nv++;
+    }
+    return ret;
+}
+
+/* ---- silk_encode_frame_FIX whole (opus-fix/silk/fixed/encode_frame_FIX.c:88): its arguments and what the bitrate loop leaves behind --
+ * the range coder, the quantiser state, the gain index state, the pulses -- plus the number of quantiser passes it took. Part of the
+ * aligned capture (frame id = the find_pitch_lags call it contains). Records of this file only (test-side layout):
+ *   args[4]  = condCoding, maxBits, useCBR, quantiser passes
+ *   misc     = pulses[320], GainsIndices[4], LastGainIndex, Seed, nBytesOut, prefill, reserved[4] */
+typedef struct { opus_int8 pulses[OPUSGPU_SILK_MAX_FRAME]; opus_int8 GainsIndices[4]; opus_int32 LastGainIndex, Seed, nBytesOut, prefill, reserved[4]; } refcap_frame_misc;
+static opus_int32 (*g_fr_args)[4]; static opusgpu_ec_state *g_fr_ec; static opusgpu_nsq_state *g_fr_nsq; static refcap_frame_misc *g_fr_misc;
+static int g_nfr, g_capfr;
+void refcap_start_frame(int max_records)
+{
+    g_capfr = max_records; g_nfr = 0; g_on = 1;
+    g_fr_args = calloc(max_records, sizeof(*g_fr_args)); g_fr_ec = calloc(max_records, sizeof(*g_fr_ec));
+    g_fr_nsq = calloc(max_records, sizeof(*g_fr_nsq)); g_fr_misc = calloc(max_records, sizeof(*g_fr_misc));
+}
+int refcap_count_frame(void) { return g_nfr; }
+int refcap_sizes_frame(int which) { return which == 0 ? (int)sizeof(*g_fr_args) : which == 1 ? (int)sizeof(*g_fr_ec) : which == 2 ? (int)sizeof(*g_fr_nsq) : (int)sizeof(*g_fr_misc); }
+void refcap_get_frame(void *args, void *ec, void *nsq, void *misc)
+{
+    memcpy(args, g_fr_args, (size_t)g_nfr * sizeof(*g_fr_args)); memcpy(ec, g_fr_ec, (size_t)g_nfr * sizeof(*g_fr_ec));
+    memcpy(nsq, g_fr_nsq, (size_t)g_nfr * sizeof(*g_fr_nsq)); memcpy(misc, g_fr_misc, (size_t)g_nfr * sizeof(*g_fr_misc));
+}
+opus_int __real_silk_encode_frame_FIX(silk_encoder_state_FIX *psEnc, opus_int32 *pnBytesOut, ec_enc *psRangeEnc, opus_int condCoding, opus_int maxBits, opus_int useCBR);
+opus_int __wrap_silk_encode_frame_FIX(silk_encoder_state_FIX *psEnc, opus_int32 *pnBytesOut, ec_enc *psRangeEnc, opus_int condCoding, opus_int maxBits, opus_int useCBR)
+{
+    const silk_encoder_state *c = &psEnc->sCmn;
+    const int prefill = c->prefillFlag;
+    int rec = (g_on && g_fr_args && g_nfr < g_capfr && !prefill && psRangeEnc->storage <= OPUSGPU_EC_BUF && c->frame_length <= OPUSGPU_SILK_MAX_FRAME) ? g_nfr : -1;
+    const int q0 = g_q_calls;
+    if (rec >= 0 && g_fid[FID_FRAME] && rec < g_fid_cap) g_fid[FID_FRAME][rec] = g_frame + 1;      /* the pitch analysis inside counts the frame */
+    opus_int ret = __real_silk_encode_frame_FIX(psEnc, pnBytesOut, psRangeEnc, condCoding, maxBits, useCBR);
+    if (rec >= 0) {
+        g_fr_args[rec][0] = condCoding; g_fr_args[rec][1] = maxBits; g_fr_args[rec][2] = useCBR; g_fr_args[rec][3] = g_q_calls - q0;
+        ec_snapshot(&g_fr_ec[rec], psRangeEnc);
+        memcpy(&g_fr_nsq[rec], &c->sNSQ, sizeof(g_fr_nsq[rec]));
+        refcap_frame_misc *m = &g_fr_misc[rec];
+        memcpy(m->pulses, c->pulses, c->frame_length); memcpy(m->GainsIndices, c->indices.GainsIndices, 4);
+        m->LastGainIndex = psEnc->sShape.LastGainIndex; m->Seed = c->indices.Seed; m->nBytesOut = *pnBytesOut; m->prefill = prefill;
+        g_nfr++;
     }
     return ret;
 }

@@ -393,3 +393,10 @@ extern "C" void emu_silk_vad(const opusgpu_vad_in *in, opusgpu_vad_state *st, op
         for (int k = 0; k < 4; k++) out[r].input_quality_bands_Q15[k] = o.input_quality_bands_Q15[k];
     }
 }
+
+// ---- the bitrate loop of silk_encode_frame_FIX, host build of concentus_amd/csrc/silk_rate_dev.h: one step per record, nBits given ----
+#include "../../concentus_amd/csrc/silk_rate_dev.h"
+extern "C" void emu_silk_rate_control(opusgpu_silk_rate_ctl *ctl, const int32_t *nBits, long n)
+{
+    for (long r = 0; r < n; r++) ca::silk_rate_control_step_dev(ctl[r], nBits[r]);
+}

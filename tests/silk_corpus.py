@@ -24,7 +24,13 @@ CAPLIB = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_silkcap.so")
 FS = 16000
 FRAME = 320
 # (input rate, samples per opus_encode call); "wb40": two SILK frames per packet, the second one coded conditionally
-VARIANTS = {"wb20": (16000, 320), "nb20": (8000, 160), "wb10": (16000, 160), "wb40": (16000, 640)}
+VARIANTS = {"wb20": (16000, 320), "nb20": (8000, 160), "wb10": (16000, 160), "wb40": (16000, 640), "wb20cbr": (16000, 320),
+            "nb20cbr": (8000, 160), "wb20lo": (16000, 320)}
+# encoder settings a variant changes: "...cbr" = OPUS_SET_VBR(0) (silk_encode_frame_FIX runs its bitrate loop on every frame);
+# "wb20lo" = VBR with max_data_bytes 50 (the loop runs where the first pass overshoots maxBits)
+VARIANT_CTLS = {"wb20cbr": ((4006, 0),), "nb20cbr": ((4006, 0), (4002, 16000))}
+VARIANT_MAX_BYTES = {"wb20lo": 50}
+MAX_PASSES = 7              # silk_encode_frame_FIX: iter 0 .. maxIter = 6
 SEG_FRAMES = 2048           # frames per captured segment (one fresh encoder each)
 WARMUP = 8                  # leading frames of a segment whose records are dropped (encoder start-up)
 
@@ -33,7 +39,8 @@ SIZES = {"burg_in": 784, "burg_out": 72, "nsq_in": 1640, "nsq_state": 4380, "nsq
          "fpc_in": 2688, "fpc_out": 208, "gains_in": 112, "gains_out": 56,
          "shape_in": 1696, "shape_out": 384, "prefilter_in": 896, "prefilter_state": 1116, "prefilter_out": 1296,
          "pitch_in": 1408, "pitch_out": 1392, "bits_in": 416, "ec_state": 1328, "bits_out": 16,
-         "vad_in": 656, "vad_state": 112, "vad_out": 32}
+         "vad_in": 656, "vad_state": 112, "vad_out": 32,
+         "frame_args": 16, "frame_misc": 356, "frame_passes": 256}
 
 
 def available():
@@ -107,7 +114,8 @@ def _capture_segment(args):
     pcm = synth_voice(nfr * frame * (FS // fs), seed)[::FS // fs]          # 8 kHz: every second sample of the 16 kHz synthesis
     cap = 3 * nfr + 16
     if kind.startswith("chain"):
-        lib.refcap_start_chain(4 * nfr + 16)
+        # up to MAX_PASSES quantiser / coder calls per frame where the bitrate loop iterates
+        lib.refcap_start_chain((8 if variant in VARIANT_CTLS or variant in VARIANT_MAX_BYTES else 4) * nfr + 16)
     elif kind == "dd":
         lib.refcap_start_dd(cap)
     elif kind == "lpc":
@@ -133,12 +141,12 @@ def _capture_segment(args):
     err = C.c_int()
     enc = C.c_void_p(lib.opus_encoder_create(fs, 1, 2048, C.byref(err)))          # OPUS_APPLICATION_VOIP
     assert enc and err.value == 0
-    for req, v in ((4002, 32000), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)):
+    for req, v in ((4002, 32000), (4006, 1), (4020, 0), (4010, complexity), (4012, 0), (4016, 0), (4014, 0), (4036, 16)) + VARIANT_CTLS.get(variant, ()):
         lib.opus_encoder_ctl(enc, req, v)
     out = (C.c_ubyte * 1500)()
     for f in range(nfr):
         fr = np.ascontiguousarray(pcm[f * frame:(f + 1) * frame])
-        assert lib.opus_encode(enc, _p(fr), frame, out, 1500) > 0
+        assert lib.opus_encode(enc, _p(fr), frame, out, VARIANT_MAX_BYTES.get(variant, 1500)) > 0
     files = _files(cache, kind, total, mode="r+")
     if kind.startswith("chain"):
         dd = kind == "chain_dd"
@@ -204,6 +212,39 @@ def _capture_segment(args):
         files["c_ec_in"][row0:row0 + take] = bi[1][si]
         files["c_ec_out"][row0:row0 + take] = bp[2][sp]
         files["c_bits_out"][row0:row0 + take] = bi[3][si]
+        # silk_encode_frame_FIX as a whole: arguments, what it leaves behind, and every quantise + code pass of its bitrate loop
+        # (gain indices coded, gains and Lambda_Q10 quantised with, ec_tell() after the pass)
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        from concentus_amd import silk as S
+        nfrm = lib.refcap_count_frame()
+        assert [lib.refcap_sizes_frame(k) for k in range(4)] == [SIZES["frame_args"], SIZES["ec_state"], SIZES["nsq_state"], SIZES["frame_misc"]]
+        fr_bufs = grab(nfrm, lib.refcap_get_frame, ("frame_args", "ec_state", "nsq_state", "frame_misc"))
+        ffid = fids(9, nfrm)
+        fsel = {int(f): k for k, f in enumerate(ffid)}
+        sel = np.array([fsel[f] for f in frames])
+        for name, b in zip(("c_frame_args", "c_frame_ec", "c_frame_nsq", "c_frame_misc"), fr_bufs):
+            files[name][row0:row0 + take] = b[sel]
+        qb, qfid = got["q"][0][0], got["q"][1]
+        pfid = got["bits_pls"][1]
+        ec_after = bp[2]
+        tell = ec_after[:, 16:20].copy().view(np.int32)[:, 0] - np.array([int(v).bit_length() for v in ec_after[:, 24:28].copy().view(np.uint32)[:, 0]])
+        g_off, l_off = S.NsqIn.Gains_Q16.offset, S.NsqIn.Lambda_Q10.offset
+        passes = np.zeros((take, SIZES["frame_passes"]), np.uint8)
+        pv = passes.view(np.int32)
+        for row, f in enumerate(frames):
+            qi = np.flatnonzero(qfid == f)
+            pi = np.flatnonzero(pfid == f)
+            ii = np.flatnonzero(got["bits_idx"][1] == f)
+            assert len(qi) == len(pi) == len(ii) == fr_bufs[0][fsel[f]].view(np.int32)[3] <= MAX_PASSES, (f, len(qi), len(pi))
+            pv[row, 0] = len(qi)
+            for k in range(len(qi)):
+                base = 1 + 7 * k
+                passes[row, 4 * base:4 * base + 4] = bi[0][ii[k]][320:324]                       # GainsIndices coded in pass k
+                pv[row, base + 1] = tell[pi[k]]
+                pv[row, base + 2:base + 6] = qb[qi[k]][g_off:g_off + 16].view(np.int32)
+                pv[row, base + 6] = qb[qi[k]][l_off:l_off + 4].view(np.int32)[0]
+        files["c_frame_passes"][row0:row0 + take] = passes
         for f in files.values():
             f.flush()
         return take
@@ -313,7 +354,9 @@ _CHAIN_LAYOUT = (("c_pitch_in", "pitch_in"), ("c_pitch_out", "pitch_out"), ("c_s
                  ("c_fpc_in", "fpc_in"), ("c_fpc_out", "fpc_out"), ("c_gains_in", "gains_in"), ("c_gains_out", "gains_out"),
                  ("c_prefilter_in", "prefilter_in"), ("c_prefilter_state_in", "prefilter_state"), ("c_prefilter_state_out", "prefilter_state"),
                  ("c_prefilter_out", "prefilter_out"), ("c_q_state_in", "nsq_state"), ("c_q_state_out", "nsq_state"),
-                 ("c_bits_in", "bits_in"), ("c_ec_in", "ec_state"), ("c_ec_out", "ec_state"), ("c_bits_out", "bits_out"))
+                 ("c_bits_in", "bits_in"), ("c_ec_in", "ec_state"), ("c_ec_out", "ec_state"), ("c_bits_out", "bits_out"),
+                 ("c_frame_args", "frame_args"), ("c_frame_ec", "ec_state"), ("c_frame_nsq", "nsq_state"), ("c_frame_misc", "frame_misc"),
+                 ("c_frame_passes", "frame_passes"))
 _LAYOUT = {
     "nsq": (("burg_in", "burg_in"), ("burg_out", "burg_out"), ("nsq_in", "nsq_in"), ("nsq_state_in", "nsq_state"),
             ("nsq_state_out", "nsq_state"), ("nsq_out", "nsq_out")),
@@ -358,7 +401,8 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     complexities = complexities or ((3,) if kind in ("nsq", "chain_nsq") else (5, 7, 10) if kind in ("dd", "chain_dd") else (3, 5, 8, 10))
     # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
     cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
-                         "%s_%d_%s_%d%s" % (kind, n, "-".join(map(str, complexities)), seed, "" if variant == "wb20" else "_" + variant))
+                         "%s%s_%d_%s_%d%s" % (kind, "_v2" if kind.startswith("chain") else "", n, "-".join(map(str, complexities)), seed,
+                                              "" if variant == "wb20" else "_" + variant))
     os.makedirs(cache, exist_ok=True)
     done = os.path.join(cache, "done")
     if not os.path.exists(done):

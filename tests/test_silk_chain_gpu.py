@@ -103,3 +103,57 @@ def test_chain_from_pitch_buffer_to_range_coder_bytes(kind, variant):
     assert np.array_equal(out["bits_out"].cpu().numpy()[:, :8], rec["c_bits_out"][:, :8])
     written = rec["c_ec_out"][:, 20:24].copy().view(np.uint32)[:, 0] - rec["c_ec_in"][:, 20:24].copy().view(np.uint32)[:, 0]
     assert written.mean() > 20, "the frames' payload bytes"
+
+
+@pytest.mark.parametrize("kind,variant", [("chain_dd", "wb20cbr"), ("chain_nsq", "nb20cbr"), ("chain_dd", "wb20lo")])
+def test_chain_with_bitrate_loop_matches_silk_encode_frame(kind, variant):
+    """silk_encode_frame_FIX whole, after the VAD: the chain with the bitrate loop (opusgpu_silk_rate_control_batch after every pass,
+    re-quantising and re-coding the frames over / under budget from their entry states) against what the reference's function left
+    behind -- the range coder (fields + bytes), silk_nsq_state, the pulses, Seed, LastGainIndex, the gain indices and the number of
+    passes. Constant-bitrate encoders iterate on nearly every frame (1-7 passes); "wb20lo" is VBR squeezed by max_data_bytes."""
+    import torch
+    import concentus_amd as ca
+    from concentus_amd import silk as S
+    from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS
+    from test_silk_rate_cpu import fresh_ctl
+    if not silk_corpus.available():
+        pytest.skip("capture library did not travel")
+    n = 4096
+    rec = {k: np.array(v) for k, v in silk_corpus.corpus(n, kind, variant=variant).items()}
+    names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in", "prefilter_in": "c_prefilter_in",
+             "q_in": "c_q_in", "bits_in": "c_bits_in"}
+    host = {k: rec[v].copy() for k, v in names.items()}
+    for name, (cls, fields) in CHAIN_FED_FIELDS.items():
+        for f in fields:
+            d = getattr(cls, f)
+            host[name][:, d.offset:d.offset + d.size] = 0
+    ctl = fresh_ctl(rec, n)
+    for f in ("GainsUnq_Q16", "Gains_Q16", "lastGainIndexPrev", "LastGainIndex", "Lambda_Q10", "GainsIndices"):      # the chain fills them
+        ctl[f] = 0
+    dev = {k: torch.from_numpy(v).cuda() for k, v in host.items()}
+    rate_ctl = torch.from_numpy(ctl.view(np.uint8).reshape(n, -1).copy()).cuda()
+    pf, nsq, ec = (torch.from_numpy(rec[k]).cuda() for k in ("c_prefilter_state_in", "c_q_state_in", "c_ec_in"))
+    ca.silk.bad_records()
+    out = SilkAnalysisChain(8 if variant.startswith("nb") else 16, 4).run(
+        dev["pitch_in"], dev["shape_in"], dev["fpc_in"], dev["gains_in"], dev["prefilter_in"], pf, dev["q_in"], nsq, kind == "chain_dd",
+        bits_in=dev["bits_in"], ec_state=ec, rate_ctl=rate_ctl)
+    torch.cuda.synchronize()
+    assert ca.silk.bad_records() == 0
+    got_ctl = rate_ctl.cpu().numpy().view(np.dtype(S.RateCtl))[:, 0]
+    args, misc = rec["c_frame_args"].view(np.int32), rec["c_frame_misc"]
+    assert (got_ctl["done"] == 1).all() and (got_ctl["status"] == 0).all()
+    assert np.array_equal(got_ctl["passes"], args[:, 3]), "quantiser passes per frame"
+    got = ec.cpu().numpy()
+    bad = np.nonzero((got != rec["c_frame_ec"]).any(1))[0]
+    assert bad.size == 0, (bad.size, bad[:6], args[bad[:6], 3], np.nonzero(got[bad[0]] != rec["c_frame_ec"][bad[0]])[0][:12])
+    assert np.array_equal(nsq.cpu().numpy(), rec["c_frame_nsq"]), "silk_nsq_state"
+    assert np.array_equal(out["pulses"].cpu().numpy().view(np.uint8), misc[:, :320]), "pulses"
+    assert np.array_equal(got_ctl["LastGainIndex"], misc[:, 324:328].copy().view(np.int32)[:, 0])
+    assert np.array_equal(got_ctl["GainsIndices"].view(np.uint8), misc[:, 320:324])
+    if kind == "chain_dd":
+        assert np.array_equal(out["Seed"].cpu().numpy(), misc[:, 328:332].copy().view(np.int32)[:, 0]), "Seed"
+    assert np.array_equal(pf.cpu().numpy(), rec["c_prefilter_state_out"])
+    hist = np.bincount(args[:, 3], minlength=8)
+    assert hist[2:].sum() > (n // 2 if variant.endswith("cbr") else 40), hist
+    if variant.endswith("cbr"):
+        assert (got_ctl["found_lower"] & got_ctl["found_upper"]).sum() > 100, "frames that bracketed the budget from both sides"
