@@ -55,6 +55,9 @@ SYMBOLS = [
     ("opusgpu_silk_noise_shape_analysis_FIX", None, [_vp, _vp, _vp, _vp, _i]),
     ("opusgpu_silk_process_gains_FIX", None, [_vp, _vp, _i]),
     ("opusgpu_silk_prefilter_FIX", None, [_vp, _vp, _vp, _vp]),
+    ("opusgpu_silk_encode_indices", None, [_vp, _vp, _i, _i, _i]),
+    ("opusgpu_silk_encode_pulses", None, [_vp, _i, _i, _vp, _i]),
+    ("opusgpu_silk_encode_frame_FIX", _i, [_vp, _vp, _vp, _i, _i, _i]),
     ("opusgpu_silk_residual_energy_FIX", None, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     ("opusgpu_celt_dec_state_size", _i, []),
     ("opusgpu_celt_dec_state_init", _i, [_vp, _i, _vp]),

@@ -193,6 +193,32 @@ void opusgpu_silk_noise_shape_analysis_FIX(void *psEnc, void *psEncCtrl, const i
 void opusgpu_silk_process_gains_FIX(void *psEnc, void *psEncCtrl, int condCoding);
 void opusgpu_silk_prefilter_FIX(void *psEnc, const void *psEncCtrl, int32_t xw_Q3[], const int16_t x[]);
 
+/* ---- silk_encode_frame_FIX as a whole, and the two entropy-coding calls inside it ----------------------------------------
+ *   silk_encode_indices(psEncC, psRangeEnc, FrameIndex, encode_LBRR, condCoding)      silk/encode_indices.c:36   (encode_LBRR == 0)
+ *   silk_encode_pulses(psRangeEnc, signalType, quantOffsetType, pulses, frame_length) silk/encode_pulses.c:64
+ *   silk_encode_frame_FIX(psEnc, pnBytesOut, psRangeEnc, condCoding, maxBits, useCBR) silk/fixed/encode_frame_FIX.c:88
+ * psRangeEnc is the tree's ec_enc (celt/entcode.h:63-94 incl. its trailing EC_DIFF), storage <= 1280. The frame hook runs the
+ * reference function's sequence with every computing call replaced by the hook of the same name above and the bitrate loop's
+ * decisions by opusgpu_silk_rate_control_batch (include/opusgpu_silk.h); it returns 0, or -1 with opusgpu_get_last_error() set --
+ * OPUSGPU_UNIMPLEMENTED for a frame inside a bandwidth transition (sLP.mode != 0, silk_LP_variable_cutoff) or with in-band LBRR.
+ * Link-level drop-in: -Wl,--wrap=silk_encode_frame_FIX; tests/test_hooks_gpu.py runs the unmodified reference
+ * encoder with exactly that redirection and compares its packets with the plain reference's. */
+#define OPUSGPU_REF_OFF_INPUT_BUF 5144                 /* silk_encoder_state.inputBuf */
+#define OPUSGPU_REF_OFF_FRAME_COUNTER 4644             /* silk_encoder_state.frameCounter */
+#define OPUSGPU_REF_OFF_PREFILL_FLAG 4712              /* silk_encoder_state.prefillFlag */
+#define OPUSGPU_REF_OFF_SLP 16                         /* silk_encoder_state.sLP */
+#define OPUSGPU_REF_OFF_LP_MODE 12                     /* silk_LP_state.mode */
+#define OPUSGPU_REF_OFF_LBRR_ENABLED 6144              /* silk_encoder_state.LBRR_enabled */
+#define OPUSGPU_REF_OFF_PULSES 4820                    /* silk_encoder_state.pulses */
+#define OPUSGPU_REF_OFF_SNSQ 144                       /* silk_encoder_state.sNSQ */
+#define OPUSGPU_REF_OFF_N_FRAMES_ENCODED 5796          /* silk_encoder_state.nFramesEncoded */
+#define OPUSGPU_REF_OFF_EC_PREV_LAG_INDEX 5820         /* silk_encoder_state.ec_prevLagIndex (opus_int16) */
+#define OPUSGPU_REF_OFF_EC_PREV_SIGNAL_TYPE 5816       /* silk_encoder_state.ec_prevSignalType */
+#define OPUSGPU_REF_OFF_FIX_X_BUF 8356                 /* silk_encoder_state_FIX.x_buf */
+void opusgpu_silk_encode_indices(void *psEncC, void *psRangeEnc, int FrameIndex, int encode_LBRR, int condCoding);
+void opusgpu_silk_encode_pulses(void *psRangeEnc, int signalType, int quantOffsetType, int8_t pulses[], int frame_length);
+int opusgpu_silk_encode_frame_FIX(void *psEnc, int32_t *pnBytesOut, void *psRangeEnc, int condCoding, int maxBits, int useCBR);
+
 #ifdef __cplusplus
 }
 #endif

@@ -528,3 +528,59 @@ def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
     L.opusgpu_quant_all_bands(0, mode, 0, 21, p(X), p(Y), p(cm), p(bandE), p(pulses), 0, 2, 0, 0, p(tf_res), 100, 0, C.byref(e2), 3, 21,
                               C.byref(seed), 0)
     assert L.opusgpu_get_last_error() == -5                      # decode side: not through this hook
+
+
+GPUFRAME = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_gpuframe.so")
+
+
+def _encode_all(lib, pcm, fs, frame, ctls, max_bytes=1500):
+    lib.opus_encoder_create.restype = C.c_void_p
+    lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    err = C.c_int()
+    enc = C.c_void_p(lib.opus_encoder_create(fs, 1, 2048, C.byref(err)))          # OPUS_APPLICATION_VOIP
+    assert enc and err.value == 0
+    for req, v in ctls:
+        assert lib.opus_encoder_ctl(enc, req, v) == 0
+    out = (C.c_ubyte * 1500)()
+    rng = C.c_uint32()
+    lib.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    packets = []
+    for f in range(len(pcm) // frame):
+        fr = np.ascontiguousarray(pcm[f * frame:(f + 1) * frame])
+        n = lib.opus_encode(enc, p(fr), frame, out, max_bytes)
+        assert n > 0, (f, n)
+        assert lib.opus_encoder_ctl(enc, 4031, C.byref(rng)) == 0                  # OPUS_GET_FINAL_RANGE
+        packets.append((bytes(out[:n]), rng.value))
+    return packets
+
+
+@pytest.mark.parametrize("name,fs,frame,ctls,max_bytes,mask", [
+    ("wb 32k vbr cx10", 16000, 320, ((4002, 32000), (4006, 1), (4020, 0), (4010, 10)), 1500, 3),
+    ("wb 24k cbr cx5", 16000, 320, ((4002, 24000), (4006, 0), (4010, 5)), 1500, 3),
+    ("nb 12k cbr cx3", 8000, 160, ((4002, 12000), (4006, 0), (4010, 3)), 1500, 1),
+    ("wb 10 ms vbr cx8 squeezed", 16000, 160, ((4002, 40000), (4006, 1), (4020, 0), (4010, 8)), 40, 3),
+    ("wb 40 ms vbr cx7", 16000, 640, ((4002, 28000), (4006, 1), (4020, 0), (4010, 7)), 1500, 3),
+])
+def test_reference_encoder_with_its_silk_frame_function_replaced_emits_the_same_packets(L, name, fs, frame, ctls, max_bytes, mask):
+    """The drop-in claim at packet level: opus_encode() of the UNMODIFIED reference, linked with --wrap so that every call of
+    silk_encode_frame_FIX (and of silk_VAD_GetSA_Q8_c, mask 3) lands in libopusgpu.so's hooks of the same argument lists
+    (oracle/ref_gpuframe_wrap.c), against opus_encode() of the plain reference on the same speech-like PCM: every packet byte and
+    the final range, VBR / CBR (the bitrate loop), wideband / narrowband, 10 / 20 / 40 ms packets (conditional coding)."""
+    import silk_corpus
+    import concentus_amd
+    if not (reflib.available() and os.path.exists(GPUFRAME)):
+        pytest.skip("oracle/_ref did not travel")
+    nframes = 60 * 320 // frame if fs == 16000 else 60
+    pcm = silk_corpus.synth_voice(nframes * frame * (16000 // fs) + 16000, 424242)[16000:][::16000 // fs]      # skip the leading pause
+    common = ((4012, 0), (4016, 0), (4014, 0), (4036, 16))
+    want = _encode_all(C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libopus_ref.so")), pcm, fs, frame, ctls + common, max_bytes)
+    hooked = C.CDLL(GPUFRAME)
+    assert hooked.refgpu_load(concentus_amd.lib.LIB_PATH.encode(), mask) == 0
+    got = _encode_all(hooked, pcm, fs, frame, ctls + common, max_bytes)
+    assert hooked.refgpu_failures() == 0, (name, hooked.refgpu_failures(), hooked.refgpu_first_error())
+    assert hooked.refgpu_calls(0) >= nframes * (frame // (fs // 50) if frame > fs // 50 else 1), "every SILK frame went through the hook"
+    if mask & 2:
+        assert hooked.refgpu_calls(1) >= nframes
+    diff = [k for k in range(len(want)) if want[k] != got[k]]
+    assert not diff, (name, len(diff), diff[:8])
+    assert len(set(w[0] for w in want)) > len(want) // 2 and np.mean([len(w[0]) for w in want]) > 20, "real payloads"

@@ -11,6 +11,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAYOUT = os.path.join(ROOT, "oracle", "_ref", "layout.json")
 
 PAIRS = {
+    "OPUSGPU_REF_OFF_INPUT_BUF": "silk_encoder_state.inputBuf",
+    "OPUSGPU_REF_OFF_FRAME_COUNTER": "silk_encoder_state.frameCounter",
+    "OPUSGPU_REF_OFF_PREFILL_FLAG": "silk_encoder_state.prefillFlag",
+    "OPUSGPU_REF_OFF_SLP": "silk_encoder_state.sLP",
+    "OPUSGPU_REF_OFF_LP_MODE": "silk_LP_state.mode",
+    "OPUSGPU_REF_OFF_LBRR_ENABLED": "silk_encoder_state.LBRR_enabled",
+    "OPUSGPU_REF_OFF_PULSES": "silk_encoder_state.pulses",
+    "OPUSGPU_REF_OFF_SNSQ": "silk_encoder_state.sNSQ",
+    "OPUSGPU_REF_OFF_N_FRAMES_ENCODED": "silk_encoder_state.nFramesEncoded",
+    "OPUSGPU_REF_OFF_EC_PREV_LAG_INDEX": "silk_encoder_state.ec_prevLagIndex",
+    "OPUSGPU_REF_OFF_EC_PREV_SIGNAL_TYPE": "silk_encoder_state.ec_prevSignalType",
+    "OPUSGPU_REF_OFF_FIX_X_BUF": "silk_encoder_state_FIX.x_buf",
     "OPUSGPU_REF_SIZEOF_SILK_ENCODER_STATE": "sizeof.silk_encoder_state",
     "OPUSGPU_REF_OFF_NB_SUBFR": "silk_encoder_state.nb_subfr",
     "OPUSGPU_REF_OFF_FRAME_LENGTH": "silk_encoder_state.frame_length",
