@@ -30,23 +30,40 @@ CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int sub
     C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
     CAb[0] = CAf[0] = s_addw(s_addw(C0, s_smmul(COND_FAC_Q32, C0)), 1);
     for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
+    // the lag-1 .. lag-D products of every subframe in ONE pass over its samples: the 16 previous samples travel in a register
+    // window that starts at zero (so the first n products of lag n vanish, as the reference's loop bounds make them). The same
+    // products as burg_modified_FIX.c:77-99 in another order: exact in 64 bits (rshifts > 0), and order-free in the wrapping
+    // 32-bit sums of celt_pitch_xcorr otherwise.
     if (rshifts > 0) {
         for (s = 0; s < nb_subfr; s++) {
             const XA xp = x + s * subfr_length;
-            for (n = 1; n < D + 1; n++) {
-                i64 acc = 0;
-                for (k = 0; k < subfr_length - n; k++) acc += __mul24(xp[k], xp[k + n]);
-                C_first_row[n - 1] = s_addw(C_first_row[n - 1], (i32)(acc >> rshifts));
+            i64 acc[16];
+            i32 w[16];
+            for (k = 0; k < 16; k++) { acc[k] = 0; w[k] = 0; }
+            for (k = 0; k < subfr_length; k++) {
+                const i32 xk = xp[k];
+#pragma unroll
+                for (n = 0; n < 16; n++) acc[n] += __mul24(xk, w[n]);
+#pragma unroll
+                for (n = 15; n > 0; n--) w[n] = w[n - 1];
+                w[0] = xk;
             }
+            for (n = 0; n < D; n++) C_first_row[n] = s_addw(C_first_row[n], (i32)(acc[n] >> rshifts));
         }
     } else {
         for (s = 0; s < nb_subfr; s++) {
             const XA xp = x + s * subfr_length;
-            for (n = 1; n < D + 1; n++) {
-                i32 d = 0;           // celt_pitch_xcorr + tail loop = the full lag-n product, 32-bit wrap-around
-                for (k = n; k < subfr_length; k++) d = s_addw(d, __mul24(xp[k], xp[k - n]));
-                C_first_row[n - 1] = s_addw(C_first_row[n - 1], shl32(d, -rshifts));
+            i32 acc[16], w[16];
+            for (k = 0; k < 16; k++) { acc[k] = 0; w[k] = 0; }
+            for (k = 0; k < subfr_length; k++) {
+                const i32 xk = xp[k];
+#pragma unroll
+                for (n = 0; n < 16; n++) acc[n] = s_addw(acc[n], __mul24(xk, w[n]));
+#pragma unroll
+                for (n = 15; n > 0; n--) w[n] = w[n - 1];
+                w[0] = xk;
             }
+            for (n = 0; n < D; n++) C_first_row[n] = s_addw(C_first_row[n], shl32(acc[n], -rshifts));
         }
     }
     for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];

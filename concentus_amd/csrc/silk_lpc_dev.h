@@ -279,12 +279,19 @@ CA_DEV void silk_NLSF2A_dev(i16 *a_Q12, const i16 *NLSF, int d)                 
 template <class XA>
 CA_DEV void lpc_residual_energy(XA x, const i16 *B, int d, int first, int len, i32 *energy, int *shift)
 {
-    i32 nB[SILK_MAX_LPC];
-    for (int j = 0; j < d; j++) nB[j] = (i16)(-(i32)B[j]);
+    // the calls below ask for res(first), res(first + 1), ... in order: the d previous samples travel in a register window, so
+    // every sample of x is read once (not d + 1 times)
+    i32 nB[SILK_MAX_LPC], w[SILK_MAX_LPC];
+    for (int j = 0; j < SILK_MAX_LPC; j++) { nB[j] = j < d ? (i32)(i16)(-(i32)B[j]) : 0; w[j] = j < d ? (i32)x[first - 1 - j] : 0; }
     auto res = [&](int ix) -> i32 {
         i32 sum = 0;
-        for (int m = 0; m < d; m++) sum = (i32)((u32)sum + (u32)__mul24(nB[m], (i32)x[ix - 1 - m]));
-        const i32 v = (i32)x[ix] + pshr32(sum, 12);
+#pragma unroll
+        for (int m = 0; m < SILK_MAX_LPC; m++) sum = (i32)((u32)sum + (u32)__mul24(nB[m], w[m]));
+        const i32 xi = (i32)x[ix];
+        const i32 v = xi + pshr32(sum, 12);
+#pragma unroll
+        for (int m = SILK_MAX_LPC - 1; m > 0; m--) w[m] = w[m - 1];
+        w[0] = xi;
         return (i32)(i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
     };
     i32 nrg = 0;

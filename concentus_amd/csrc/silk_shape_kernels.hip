@@ -1,6 +1,6 @@
 // silk_shape_kernels.hip -- batched silk_noise_shape_analysis_FIX (opus-fix/silk/fixed/noise_shape_analysis_FIX.c:146-466), one lane
-// per frame. The arithmetic lives in silk_shape_dev.h; the windowed analysis block (and its down-shifted copy for the plain
-// autocorrelation) of each of the wavefront's 64 frames lives in LDS laid out [sample][lane].
+// per frame. The arithmetic lives in silk_shape_dev.h; the windowed analysis block of each of the wavefront's 64 frames lives in
+// LDS laid out [sample][lane].
 #include <string.h>
 #include "silk_shape_dev.h"
 #include "silk_prefilter_dev.h"
@@ -20,7 +20,9 @@ __global__ __launch_bounds__(64) void silk_noise_shape_kernel(const opusgpu_nois
                                                               opusgpu_noise_shape_out *__restrict__ outs, int n_rec,
                                                               int *__restrict__ bad_records)
 {
-    __shared__ i16 xw_s[240 * 64], xs_s[240 * 64];
+    // one block: the plain autocorrelation's down-shifted copy is made in place (the windowed block is not read again), which keeps
+    // the workgroup at 30 KB of LDS -- four of them per CU, i.e. all 65 536 frames of a full batch resident at once
+    __shared__ i16 xw_s[240 * 64];
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_noise_shape_in &in = recs[r];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(64) void silk_noise_shape_kernel(const opusgpu_nois
     o.HarmBoost_smth_Q16 = in.HarmBoost_smth_Q16; o.HarmShapeGain_smth_Q16 = in.HarmShapeGain_smth_Q16; o.Tilt_smth_Q16 = in.Tilt_smth_Q16;
     ShapeCol xw, xs;
     xw.p = xw_s + threadIdx.x;
-    xs.p = xs_s + threadIdx.x;
+    xs.p = xw_s + threadIdx.x;
     silk_noise_shape_analysis_dev(c, (const i16 *)in.pitch_res, (const i16 *)in.x + in.la_shape, xw, xs, o);
     memset(&out, 0, sizeof(out));
     for (int k = 0; k < in.nb_subfr; k++) { out.Gains_Q16[k] = o.Gains_Q16[k]; out.GainsPre_Q14[k] = o.GainsPre_Q14[k]; out.LF_shp_Q14[k] = o.LF_shp_Q14[k]; }
