@@ -9,17 +9,79 @@ namespace ca {
 
 enum { BURG_QA = 25, BURG_COND_FAC_Q32 = 42950 };                    // SILK_FIX_CONST(FIND_LPC_COND_FAC = 1e-5f, 32)
 
-// A_Q16[16] out (entries >= D zeroed), *res_nrg / *res_nrg_Q out.
+// The order recursion touches only the first and the last 16 samples of every subframe (x[n - k], x[subfr_length - n + k - 1],
+// k <= n < D <= 16); the passes over whole subframes (energy, lag products) read each sample once. The two kinds of access go
+// through two accessors so that a kernel can keep just the edges where latency counts (LDS) and stream the rest from where the
+// signal lies: XE::head(s, i) = x[s * subfr_length + i], XE::tail(s, j) = x[s * subfr_length + subfr_length - 16 + j], i, j < 16.
+#if defined(CA_HOST_EMU)
+#define CA_MEMBER inline
+#else
+#define CA_MEMBER __device__ __forceinline__
+#endif
 template <class XA>
-CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int subfr_length, const int nb_subfr, const int D,
+struct BurgEdgesOf {                                                  // the edges read straight from the signal
+    XA x;
+    int L;
+    CA_MEMBER i32 head(int s, int i) const { return (i32)x[s * L + i]; }
+    CA_MEMBER i32 tail(int s, int j) const { return (i32)x[s * L + L - 16 + j]; }
+    CA_MEMBER BurgEdgesOf from(int s0) const { BurgEdgesOf r; r.x = x + s0 * L; r.L = L; return r; }
+    template <class XB> CA_MEMBER void stage(XB, int, int) const {}
+};
+
+// the edges of up to four subframes in this lane's column of an LDS block laid out [slot][64 lanes]: 4 x 32 slots = 16 KB per
+// 64-frame workgroup (the whole signal would be 48 KB, i.e. three workgroups per CU instead of four: one wave per SIMD short)
+enum { BURG_EDGE_SLOTS = 4 * 32 };
+struct BurgEdgesCol {
+    i16 *p;
+    CA_MEMBER i32 head(int s, int i) const { return (i32)p[(s * 32 + i) * 64]; }
+    CA_MEMBER i32 tail(int s, int j) const { return (i32)p[(s * 32 + 16 + j) * 64]; }
+    CA_MEMBER BurgEdgesCol from(int s0) const { BurgEdgesCol r; r.p = p + s0 * 32 * 64; return r; }
+    template <class XB> CA_MEMBER void stage(XB x, int L, int nb) const
+    {
+        for (int s = 0; s < nb; s++)
+            for (int i = 0; i < 16; i++) {
+                p[(s * 32 + i) * 64] = (i16)(i32)x[s * L + i];
+                p[(s * 32 + 16 + i) * 64] = (i16)(i32)x[s * L + L - 16 + i];
+            }
+    }
+};
+
+// A_Q16[16] out (entries >= D zeroed), *res_nrg / *res_nrg_Q out.
+template <class XA, class XE>
+CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const int subfr_length, const int nb_subfr, const int D,
                                    i32 *A_Q16, i32 *res_nrg, int *res_nrg_Q)
 {
     enum { QA = BURG_QA, COND_FAC_Q32 = BURG_COND_FAC_Q32 };
     i32 C_first_row[16], C_last_row[16], Af_QA[16], CAf[17], CAb[17];
     i32 C0, num, nrg, rc_Q31, invGain_Q30, Atmp_QA, Atmp1, tmp1, tmp2, x1, x2;
     int k, n, s, lz, rshifts, reached_max_gain;
+    // ONE pass over the signal: its energy and the lag-1 .. lag-16 products of every subframe. The 16 previous samples travel in a
+    // register window that starts at zero at each subframe (so the first n products of lag n vanish, as the reference's loop
+    // bounds make them), the sums are kept exact in 64 bits per subframe until the energy has fixed rshifts: what
+    // burg_modified_FIX.c:77-99 adds is then (i32)(sum >> rshifts) (its 64-bit inner products), or the low 32 bits -- the
+    // wrapping sums of celt_pitch_xcorr, which do not depend on the order of the products -- shifted up.
     i64 C0_64 = 0;
-    for (k = 0; k < subfr_length * nb_subfr; k++) C0_64 += __mul24(x[k], x[k]);
+    i64 acc[4][16];
+#pragma unroll
+    for (s = 0; s < 4; s++) {
+#pragma unroll
+        for (n = 0; n < 16; n++) acc[s][n] = 0;
+        if (s < nb_subfr) {
+            const XA xp = x + s * subfr_length;
+            i32 w[16];
+#pragma unroll
+            for (n = 0; n < 16; n++) w[n] = 0;
+            for (k = 0; k < subfr_length; k++) {
+                const i32 xk = xp[k];
+                C0_64 += __mul24(xk, xk);
+#pragma unroll
+                for (n = 0; n < 16; n++) acc[s][n] += __mul24(xk, w[n]);
+#pragma unroll
+                for (n = 15; n > 0; n--) w[n] = w[n - 1];
+                w[0] = xk;
+            }
+        }
+    }
     {
         i32 hi = (i32)(C0_64 >> 32);
         lz = hi == 0 ? 32 + s_clz32((i32)C0_64) : s_clz32(hi);
@@ -30,40 +92,12 @@ CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int sub
     C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
     CAb[0] = CAf[0] = s_addw(s_addw(C0, s_smmul(COND_FAC_Q32, C0)), 1);
     for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
-    // the lag-1 .. lag-D products of every subframe in ONE pass over its samples: the 16 previous samples travel in a register
-    // window that starts at zero (so the first n products of lag n vanish, as the reference's loop bounds make them). The same
-    // products as burg_modified_FIX.c:77-99 in another order: exact in 64 bits (rshifts > 0), and order-free in the wrapping
-    // 32-bit sums of celt_pitch_xcorr otherwise.
-    if (rshifts > 0) {
-        for (s = 0; s < nb_subfr; s++) {
-            const XA xp = x + s * subfr_length;
-            i64 acc[16];
-            i32 w[16];
-            for (k = 0; k < 16; k++) { acc[k] = 0; w[k] = 0; }
-            for (k = 0; k < subfr_length; k++) {
-                const i32 xk = xp[k];
 #pragma unroll
-                for (n = 0; n < 16; n++) acc[n] += __mul24(xk, w[n]);
+    for (s = 0; s < 4; s++) {
+        if (s < nb_subfr) {
 #pragma unroll
-                for (n = 15; n > 0; n--) w[n] = w[n - 1];
-                w[0] = xk;
-            }
-            for (n = 0; n < D; n++) C_first_row[n] = s_addw(C_first_row[n], (i32)(acc[n] >> rshifts));
-        }
-    } else {
-        for (s = 0; s < nb_subfr; s++) {
-            const XA xp = x + s * subfr_length;
-            i32 acc[16], w[16];
-            for (k = 0; k < 16; k++) { acc[k] = 0; w[k] = 0; }
-            for (k = 0; k < subfr_length; k++) {
-                const i32 xk = xp[k];
-#pragma unroll
-                for (n = 0; n < 16; n++) acc[n] = s_addw(acc[n], __mul24(xk, w[n]));
-#pragma unroll
-                for (n = 15; n > 0; n--) w[n] = w[n - 1];
-                w[0] = xk;
-            }
-            for (n = 0; n < D; n++) C_first_row[n] = s_addw(C_first_row[n], shl32(acc[n], -rshifts));
+            for (n = 0; n < 16; n++)
+                if (n < D) C_first_row[n] = s_addw(C_first_row[n], rshifts > 0 ? (i32)(acc[s][n] >> rshifts) : shl32((i32)acc[s][n], -rshifts));
         }
     }
     for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
@@ -72,44 +106,42 @@ CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int sub
     for (n = 0; n < D; n++) {
         if (rshifts > -2) {
             for (s = 0; s < nb_subfr; s++) {
-                const XA xp = x + s * subfr_length;
-                x1 = (i32)(0u - (u32)shl32(xp[n], 16 - rshifts));
-                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], 16 - rshifts));
-                tmp1 = shl32(xp[n], QA - 16);
-                tmp2 = shl32(xp[subfr_length - n - 1], QA - 16);
+                x1 = (i32)(0u - (u32)shl32(e.head(s, n), 16 - rshifts));
+                x2 = (i32)(0u - (u32)shl32(e.tail(s, 16 - n - 1), 16 - rshifts));
+                tmp1 = shl32(e.head(s, n), QA - 16);
+                tmp2 = shl32(e.tail(s, 16 - n - 1), QA - 16);
                 for (k = 0; k < n; k++) {
-                    C_first_row[k] = s_smlawb(C_first_row[k], x1, xp[n - k - 1]);
-                    C_last_row[k] = s_smlawb(C_last_row[k], x2, xp[subfr_length - n + k]);
+                    C_first_row[k] = s_smlawb(C_first_row[k], x1, e.head(s, n - k - 1));
+                    C_last_row[k] = s_smlawb(C_last_row[k], x2, e.tail(s, 16 - n + k));
                     Atmp_QA = Af_QA[k];
-                    tmp1 = s_smlawb(tmp1, Atmp_QA, xp[n - k - 1]);
-                    tmp2 = s_smlawb(tmp2, Atmp_QA, xp[subfr_length - n + k]);
+                    tmp1 = s_smlawb(tmp1, Atmp_QA, e.head(s, n - k - 1));
+                    tmp2 = s_smlawb(tmp2, Atmp_QA, e.tail(s, 16 - n + k));
                 }
                 tmp1 = shl32((i32)(0u - (u32)tmp1), 32 - QA - rshifts);
                 tmp2 = shl32((i32)(0u - (u32)tmp2), 32 - QA - rshifts);
                 for (k = 0; k <= n; k++) {
-                    CAf[k] = s_smlawb(CAf[k], tmp1, xp[n - k]);
-                    CAb[k] = s_smlawb(CAb[k], tmp2, xp[subfr_length - n + k - 1]);
+                    CAf[k] = s_smlawb(CAf[k], tmp1, e.head(s, n - k));
+                    CAb[k] = s_smlawb(CAb[k], tmp2, e.tail(s, 16 - n + k - 1));
                 }
             }
         } else {
             for (s = 0; s < nb_subfr; s++) {
-                const XA xp = x + s * subfr_length;
-                x1 = (i32)(0u - (u32)shl32(xp[n], -rshifts));
-                x2 = (i32)(0u - (u32)shl32(xp[subfr_length - n - 1], -rshifts));
-                tmp1 = shl32(xp[n], 17);
-                tmp2 = shl32(xp[subfr_length - n - 1], 17);
+                x1 = (i32)(0u - (u32)shl32(e.head(s, n), -rshifts));
+                x2 = (i32)(0u - (u32)shl32(e.tail(s, 16 - n - 1), -rshifts));
+                tmp1 = shl32(e.head(s, n), 17);
+                tmp2 = shl32(e.tail(s, 16 - n - 1), 17);
                 for (k = 0; k < n; k++) {
-                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)(i32)xp[n - k - 1]);
-                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)(i32)xp[subfr_length - n + k]);
+                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)(i32)e.head(s, n - k - 1));
+                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)(i32)e.tail(s, 16 - n + k));
                     Atmp1 = s_rshift_round(Af_QA[k], QA - 17);
-                    tmp1 = (i32)((u32)tmp1 + (u32)(i32)xp[n - k - 1] * (u32)Atmp1);
-                    tmp2 = (i32)((u32)tmp2 + (u32)(i32)xp[subfr_length - n + k] * (u32)Atmp1);
+                    tmp1 = (i32)((u32)tmp1 + (u32)(i32)e.head(s, n - k - 1) * (u32)Atmp1);
+                    tmp2 = (i32)((u32)tmp2 + (u32)(i32)e.tail(s, 16 - n + k) * (u32)Atmp1);
                 }
                 tmp1 = (i32)(0u - (u32)tmp1);
                 tmp2 = (i32)(0u - (u32)tmp2);
                 for (k = 0; k <= n; k++) {
-                    CAf[k] = s_smlaww(CAf[k], tmp1, shl32(xp[n - k], -rshifts - 1));
-                    CAb[k] = s_smlaww(CAb[k], tmp2, shl32(xp[subfr_length - n + k - 1], -rshifts - 1));
+                    CAf[k] = s_smlaww(CAf[k], tmp1, shl32(e.head(s, n - k), -rshifts - 1));
+                    CAb[k] = s_smlaww(CAb[k], tmp2, shl32(e.tail(s, 16 - n + k - 1), -rshifts - 1));
                 }
             }
         }
@@ -168,16 +200,14 @@ CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int sub
         for (k = 0; k < D; k++) A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
         if (rshifts > 0) {
             for (s = 0; s < nb_subfr; s++) {
-                const XA xp = x + s * subfr_length;
                 i64 acc = 0;
-                for (k = 0; k < D; k++) acc += __mul24(xp[k], xp[k]);
+                for (k = 0; k < D; k++) acc += __mul24(e.head(s, k), e.head(s, k));
                 C0 = s_subw(C0, (i32)(acc >> rshifts));
             }
         } else {
             for (s = 0; s < nb_subfr; s++) {
-                const XA xp = x + s * subfr_length;
                 i32 acc = 0;
-                for (k = 0; k < D; k++) acc = s_addw(acc, __mul24(xp[k], xp[k]));
+                for (k = 0; k < D; k++) acc = s_addw(acc, __mul24(e.head(s, k), e.head(s, k)));
                 C0 = s_subw(C0, shl32(acc, -rshifts));
             }
         }
@@ -198,4 +228,14 @@ CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int sub
     for (k = D; k < 16; k++) A_Q16[k] = 0;
 }
 
+template <class XA>
+CA_DEV void silk_burg_modified_dev(XA x, const i32 minInvGain_Q30, const int subfr_length, const int nb_subfr, const int D,
+                                   i32 *A_Q16, i32 *res_nrg, int *res_nrg_Q)
+{
+    BurgEdgesOf<XA> e;
+    e.x = x; e.L = subfr_length;
+    silk_burg_modified_dev(x, e, minInvGain_Q30, subfr_length, nb_subfr, D, A_Q16, res_nrg, res_nrg_Q);
+}
+
 }  // namespace ca
+

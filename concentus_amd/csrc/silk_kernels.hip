@@ -41,7 +41,8 @@ struct BurgX {
 __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__restrict__ recs, opusgpu_burg_out *__restrict__ outs, int n_rec,
                                                        int *__restrict__ bad_records)
 {
-    __shared__ i16 xs[OPUSGPU_SILK_BURG_MAX_X * 64];
+    __shared__ i16 edge_s[BURG_EDGE_SLOTS * 64];               // the recursion's subframe edges, [slot][lane]: 16 KB, four workgroups per CU
+    i16 xs[OPUSGPU_SILK_BURG_MAX_X];                           // private: the energy and lag-product passes read it once each, in order
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_burg_in &in = recs[r];
@@ -57,16 +58,16 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
         static_assert(sizeof(opusgpu_burg_in) % 16 == 0 && OPUSGPU_SILK_BURG_MAX_X % 8 == 0, "16-byte loads of x");
         const int nx = in.subfr_length * in.nb_subfr;
         const int4 *src = reinterpret_cast<const int4 *>(in.x);
-        i16 *col = xs + threadIdx.x;
         for (int k = 0; k < nx; k += 8) {
             const int4 w = src[k >> 3];
-            col[(k + 0) * 64] = (i16)w.x; col[(k + 1) * 64] = (i16)(w.x >> 16); col[(k + 2) * 64] = (i16)w.y; col[(k + 3) * 64] = (i16)(w.y >> 16);
-            col[(k + 4) * 64] = (i16)w.z; col[(k + 5) * 64] = (i16)(w.z >> 16); col[(k + 6) * 64] = (i16)w.w; col[(k + 7) * 64] = (i16)(w.w >> 16);
+            xs[k + 0] = (i16)w.x; xs[k + 1] = (i16)(w.x >> 16); xs[k + 2] = (i16)w.y; xs[k + 3] = (i16)(w.y >> 16);
+            xs[k + 4] = (i16)w.z; xs[k + 5] = (i16)(w.z >> 16); xs[k + 6] = (i16)w.w; xs[k + 7] = (i16)(w.w >> 16);
         }
     }
-    BurgX x;
-    x.p = xs + threadIdx.x;
-    silk_burg_modified_dev(x, in.minInvGain_Q30, in.subfr_length, in.nb_subfr, in.D, outs[r].A_Q16, &outs[r].res_nrg, &outs[r].res_nrg_Q);
+    BurgEdgesCol e;
+    e.p = edge_s + threadIdx.x;
+    e.stage((const i16 *)xs, in.subfr_length, in.nb_subfr);
+    silk_burg_modified_dev((const i16 *)xs, e, in.minInvGain_Q30, in.subfr_length, in.nb_subfr, in.D, outs[r].A_Q16, &outs[r].res_nrg, &outs[r].res_nrg_Q);
 }
 
 // ---- silk_NSQ: one lane per record ---------------------------------------------------------------------

@@ -333,19 +333,20 @@ CA_DEV void lpc_residual_energy(XA x, const i16 *B, int d, int first, int len, i
 // ---- silk_find_LPC_FIX ----------------------------------------------------------------------------------------------------
 // x: (subfr_length + order) * nb_subfr samples (LPC_in_pre of find_pred_coefs_FIX.c:136); subfr_length as in psEncC (without
 // the order samples). Writes NLSF_Q15[order] and returns psEncC->indices.NLSFInterpCoef_Q2.
-template <class XA>
-CA_DEV int silk_find_LPC_dev(XA x, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, int order, int useInterpolatedNLSFs,
+// e: the Burg recursion's edge accessor over the same signal (silk_burg_dev.h), already staged.
+template <class XA, class XE>
+CA_DEV int silk_find_LPC_dev(XA x, XE e, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, int order, int useInterpolatedNLSFs,
                              int first_frame_after_reset, const i16 *prev_NLSFq_Q15, i16 *NLSF_Q15)
 {
     const int subfr_length = subfr_length_enc + order;
     int interp = 4;
     i32 a_Q16[SILK_MAX_LPC], res_nrg;
     int res_nrg_Q;
-    silk_burg_modified_dev(x, minInvGain_Q30, subfr_length, nb_subfr, order, a_Q16, &res_nrg, &res_nrg_Q);
+    silk_burg_modified_dev(x, e, minInvGain_Q30, subfr_length, nb_subfr, order, a_Q16, &res_nrg, &res_nrg_Q);
     if (useInterpolatedNLSFs && !first_frame_after_reset && nb_subfr == 4) {
         i32 a_tmp_Q16[SILK_MAX_LPC], res_tmp_nrg;
         int res_tmp_nrg_Q;
-        silk_burg_modified_dev(x + 2 * subfr_length, minInvGain_Q30, subfr_length, 2, order, a_tmp_Q16, &res_tmp_nrg, &res_tmp_nrg_Q);
+        silk_burg_modified_dev(x + 2 * subfr_length, e.from(2), minInvGain_Q30, subfr_length, 2, order, a_tmp_Q16, &res_tmp_nrg, &res_tmp_nrg_Q);
         int shift = res_tmp_nrg_Q - res_nrg_Q;
         if (shift >= 0) {
             if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift);
@@ -386,6 +387,15 @@ CA_DEV int silk_find_LPC_dev(XA x, i32 minInvGain_Q30, int subfr_length_enc, int
     }
     if (interp == 4) silk_A2NLSF_dev(NLSF_Q15, a_Q16, order);
     return interp;
+}
+
+template <class XA>
+CA_DEV int silk_find_LPC_dev(XA x, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, int order, int useInterpolatedNLSFs,
+                             int first_frame_after_reset, const i16 *prev_NLSFq_Q15, i16 *NLSF_Q15)
+{
+    BurgEdgesOf<XA> e;
+    e.x = x; e.L = subfr_length_enc + order;
+    return silk_find_LPC_dev(x, e, minInvGain_Q30, subfr_length_enc, nb_subfr, order, useInterpolatedNLSFs, first_frame_after_reset, prev_NLSFq_Q15, NLSF_Q15);
 }
 
 }  // namespace ca

@@ -22,7 +22,8 @@ struct LpcX {
 __global__ __launch_bounds__(64) void silk_find_lpc_kernel(const opusgpu_find_lpc_in *__restrict__ recs, opusgpu_find_lpc_out *__restrict__ outs,
                                                            int n_rec, int *__restrict__ bad_records)
 {
-    __shared__ i16 xs[OPUSGPU_SILK_BURG_MAX_X * 64];
+    __shared__ i16 edge_s[BURG_EDGE_SLOTS * 64];               // the Burg recursion's subframe edges, [slot][lane]
+    i16 xs[OPUSGPU_SILK_BURG_MAX_X];                           // private: streamed through in order, a handful of times
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_find_lpc_in &in = recs[r];
@@ -38,18 +39,19 @@ __global__ __launch_bounds__(64) void silk_find_lpc_kernel(const opusgpu_find_lp
         static_assert(sizeof(opusgpu_find_lpc_in) % 16 == 0, "16-byte loads of x");
         const int nx = (in.subfr_length + in.predictLPCOrder) * in.nb_subfr;
         const int4 *src = reinterpret_cast<const int4 *>(in.x);
-        i16 *col = xs + threadIdx.x;
         for (int k = 0; k < nx; k += 8) {
             const int4 w = src[k >> 3];
-            col[(k + 0) * 64] = (i16)w.x; col[(k + 1) * 64] = (i16)(w.x >> 16); col[(k + 2) * 64] = (i16)w.y; col[(k + 3) * 64] = (i16)(w.y >> 16);
-            col[(k + 4) * 64] = (i16)w.z; col[(k + 5) * 64] = (i16)(w.z >> 16); col[(k + 6) * 64] = (i16)w.w; col[(k + 7) * 64] = (i16)(w.w >> 16);
+            xs[k + 0] = (i16)w.x; xs[k + 1] = (i16)(w.x >> 16); xs[k + 2] = (i16)w.y; xs[k + 3] = (i16)(w.y >> 16);
+            xs[k + 4] = (i16)w.z; xs[k + 5] = (i16)(w.z >> 16); xs[k + 6] = (i16)w.w; xs[k + 7] = (i16)(w.w >> 16);
         }
     }
-    LpcX x;
-    x.p = xs + threadIdx.x;
+    const int L = in.subfr_length + in.predictLPCOrder;
+    BurgEdgesCol e;
+    e.p = edge_s + threadIdx.x;
+    e.stage((const i16 *)xs, L, in.nb_subfr);
     i16 prev[16], nlsf[16];
     for (int k = 0; k < 16; k++) { prev[k] = in.prev_NLSFq_Q15[k]; nlsf[k] = 0; }
-    const int interp = silk_find_LPC_dev(x, in.minInvGain_Q30, in.subfr_length, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
+    const int interp = silk_find_LPC_dev((const i16 *)xs, e, in.minInvGain_Q30, in.subfr_length, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
                                          in.first_frame_after_reset, prev, nlsf);
     for (int k = 0; k < 16; k++) o.NLSF_Q15[k] = nlsf[k];
     o.NLSFInterpCoef_Q2 = interp;

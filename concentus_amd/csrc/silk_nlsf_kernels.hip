@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64) void silk_residual_energy_kernel(const opusgpu_
                                                                   opusgpu_res_nrg_out *__restrict__ outs, int n_rec,
                                                                   int *__restrict__ bad_records)
 {
-    __shared__ i16 xs[OPUSGPU_SILK_BURG_MAX_X * 64];
+    i16 xs[OPUSGPU_SILK_BURG_MAX_X];                           // private: the residual filter's register window reads every sample once
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_res_nrg_in &in = recs[r];
@@ -62,19 +62,16 @@ __global__ __launch_bounds__(64) void silk_residual_energy_kernel(const opusgpu_
         return;
     }
     {
-        // every sample is read LPC_order + 1 times: stage the record once, [sample][lane], 16-byte loads (as silk_find_lpc_kernel)
         static_assert(sizeof(opusgpu_res_nrg_in) % 16 == 0, "16-byte loads of x");
         const int nx = (in.subfr_length + in.LPC_order) * in.nb_subfr;
         const int4 *src = reinterpret_cast<const int4 *>(in.x);
-        i16 *col = xs + threadIdx.x;
         for (int k = 0; k < nx; k += 8) {
             const int4 w = src[k >> 3];
-            col[(k + 0) * 64] = (i16)w.x; col[(k + 1) * 64] = (i16)(w.x >> 16); col[(k + 2) * 64] = (i16)w.y; col[(k + 3) * 64] = (i16)(w.y >> 16);
-            col[(k + 4) * 64] = (i16)w.z; col[(k + 5) * 64] = (i16)(w.z >> 16); col[(k + 6) * 64] = (i16)w.w; col[(k + 7) * 64] = (i16)(w.w >> 16);
+            xs[k + 0] = (i16)w.x; xs[k + 1] = (i16)(w.x >> 16); xs[k + 2] = (i16)w.y; xs[k + 3] = (i16)(w.y >> 16);
+            xs[k + 4] = (i16)w.z; xs[k + 5] = (i16)(w.z >> 16); xs[k + 6] = (i16)w.w; xs[k + 7] = (i16)(w.w >> 16);
         }
     }
-    ResX x;
-    x.p = xs + threadIdx.x;
+    const i16 *x = xs;
     i16 a[2][SILK_MAX_LPC];
     i32 gains[4], nrgs[4] = {0, 0, 0, 0}, nrgsQ[4] = {0, 0, 0, 0};
     for (int k = 0; k < SILK_MAX_LPC; k++) { a[0][k] = in.a_Q12[0][k]; a[1][k] = in.a_Q12[1][k]; }

@@ -29,8 +29,10 @@ struct PredCoefsCfg {                                   // the psEnc / psEncCtrl
 };
 
 // res_pitch: index 0 = res_pitch[0]; x: index 0 = the reference's x[0] (the frame), negative indices reach into x_buf.
-template <class XG, class PRE>
-CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr)
+// pre: storage of LPC_in_pre (nb * (subfr_length + order) samples, each read a handful of times, in order); e: the Burg recursion's
+// edge accessor over it (silk_burg_dev.h), staged here once LPC_in_pre exists.
+template <class XG, class PRE, class XE>
+CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, XE e, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr)
 {
     const int order = c.predictLPCOrder, nb = c.nb_subfr, L = c.subfr_length;
     i32 invGains_Q16[4], local_gains[4], Wght_Q15[4];
@@ -78,11 +80,20 @@ CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, 
         minInvGain_Q30 = s_log2lin(s_smlawb(16 << 7, o.LTPredCodGain_Q7, 21845));
         minInvGain_Q30 = s_div32_varq(minInvGain_Q30, s_smulww(10000, s_smlawb(65536, 196608, c.coding_quality_Q14)), 14);
     }
-    o.NLSFInterpCoef_Q2 = silk_find_LPC_dev(pre, minInvGain_Q30, L, nb, order, c.useInterpolatedNLSFs, c.first_frame_after_reset,
+    e.stage(pre, L + order, nb);
+    o.NLSFInterpCoef_Q2 = silk_find_LPC_dev(pre, e, minInvGain_Q30, L, nb, order, c.useInterpolatedNLSFs, c.first_frame_after_reset,
                                             c.prev_NLSFq_Q15, o.NLSF_Q15);
     silk_process_NLSFs_dev(o.PredCoef_Q12, o.NLSFIndices, o.NLSF_Q15, c.prev_NLSFq_Q15, c.speech_activity_Q8, nb, order,
                            c.useInterpolatedNLSFs, o.NLSFInterpCoef_Q2, c.NLSF_MSVQ_Survivors, c.signalType, tables);
     silk_residual_energy_dev(o.ResNrg, o.ResNrgQ, pre, o.PredCoef_Q12, local_gains, L, nb, order);
+}
+
+template <class XG, class PRE>
+CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr)
+{
+    BurgEdgesOf<PRE> e;
+    e.x = pre; e.L = c.subfr_length + c.predictLPCOrder;
+    silk_find_pred_coefs_dev(c, res_pitch, x, pre, e, o, tables);
 }
 
 }  // namespace ca

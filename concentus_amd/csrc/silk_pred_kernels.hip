@@ -1,7 +1,8 @@
 // silk_pred_kernels.hip -- batched silk_find_pred_coefs_FIX (opus-fix/silk/fixed/find_pred_coefs_FIX.c:35-148), one lane per frame.
-// The arithmetic lives in silk_pred_dev.h; this file checks the records and provides LPC_in_pre's storage: the wavefront's 64
-// LPC_in_pre signals live in LDS laid out [sample][lane] (the Burg analyses and the residual filters read every sample many
-// times); res_pitch and x are read from the records where they lie.
+// The arithmetic lives in silk_pred_dev.h; this file checks the records and provides LPC_in_pre's storage: private memory (384
+// samples, written once and streamed through a few times in order) plus the 2 x 16 edge samples of every subframe, which the Burg
+// recursion revisits in dependent chains, in LDS laid out [slot][lane] -- 18 KB per workgroup, so that four workgroups (one
+// wavefront per SIMD, all 65 536 frames of a full batch) are resident per CU. res_pitch and x are read from the records where they lie.
 #include <string.h>
 #include "silk_pred_dev.h"
 #include "silk_gains_dev.h"
@@ -12,17 +13,11 @@
 
 namespace ca {
 
-struct PreCol {                                                // this lane's column of the [sample][lane] block
-    i16 *p;
-    __device__ __forceinline__ i16 &operator[](int k) const { return p[k * 64]; }
-    __device__ __forceinline__ PreCol operator+(int o) const { PreCol r; r.p = p + o * 64; return r; }
-};
-
 __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_find_pred_coefs_in *__restrict__ recs,
                                                                   opusgpu_find_pred_coefs_out *__restrict__ outs, int n_rec,
                                                                   int *__restrict__ bad_records)
 {
-    __shared__ i16 pre_s[OPUSGPU_SILK_BURG_MAX_X * 64];
+    __shared__ i16 edge_s[BURG_EDGE_SLOTS * 64];
     __shared__ NlsfTablesLds tables;
     nlsf_stage_tables(tables, threadIdx.x, 64);
     __syncthreads();
@@ -47,9 +42,10 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     c.nFramesPerPacket = in.nFramesPerPacket;
     PredCoefsOut o;
     memset(&o, 0, sizeof(o));
-    PreCol pre;
-    pre.p = pre_s + threadIdx.x;
-    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, pre, o, &tables);
+    i16 pre[OPUSGPU_SILK_BURG_MAX_X];
+    BurgEdgesCol e;
+    e.p = edge_s + threadIdx.x;
+    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, o, &tables);
     const int order = in.predictLPCOrder, nb = in.nb_subfr;
     memset(&out, 0, sizeof(out));
     for (int k = 0; k < order; k++) { out.PredCoef_Q12[0][k] = o.PredCoef_Q12[0][k]; out.PredCoef_Q12[1][k] = o.PredCoef_Q12[1][k]; out.NLSF_Q15[k] = o.NLSF_Q15[k]; }
