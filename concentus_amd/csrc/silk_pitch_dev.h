@@ -425,13 +425,19 @@ CA_DEV void silk_bwexpander_dev(i16 *ar, int d, i32 chirp_Q16)                  
 template <class OUT, class XA>
 CA_DEV void silk_LPC_analysis_filter_dev(OUT out, XA in, const i16 *B, int len, int d)
 {
-    i32 nB[SILK_MAX_LPC];
-    for (int j = 0; j < d; j++) nB[j] = (i16)(-(i32)B[j]);
+    // the d previous input samples travel in a register window: every sample is read once
+    i32 nB[SILK_MAX_LPC], w[SILK_MAX_LPC];
+    for (int j = 0; j < SILK_MAX_LPC; j++) { nB[j] = j < d ? (i32)(i16)(-(i32)B[j]) : 0; w[j] = j < d ? (i32)in[d - 1 - j] : 0; }
     for (int ix = d; ix < len; ix++) {
         i32 sum = 0;
-        for (int m = 0; m < d; m++) sum = s_addw(sum, __mul24(nB[m], (i32)in[ix - 1 - m]));
-        const i32 v = (i32)in[ix] + pshr32(sum, 12);
+#pragma unroll
+        for (int m = 0; m < SILK_MAX_LPC; m++) sum = s_addw(sum, __mul24(nB[m], w[m]));
+        const i32 xi = (i32)in[ix];
+        const i32 v = xi + pshr32(sum, 12);
         out[ix] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+#pragma unroll
+        for (int m = SILK_MAX_LPC - 1; m > 0; m--) w[m] = w[m - 1];
+        w[0] = xi;
     }
     for (int j = 0; j < d; j++) out[j] = 0;
 }

@@ -31,10 +31,11 @@ __global__ __launch_bounds__(64) void silk_find_pitch_lags_kernel(const opusgpu_
     c.prevSignalType = in.prevSignalType; c.input_tilt_Q15 = in.input_tilt_Q15; c.prevLag = in.prevLag; c.LTPCorr_Q15 = in.LTPCorr_Q15;
     PitchOut o;
     memset(&o, 0, sizeof(o));
-    // one work array: the windowed block and its down-shifted copy (2 x 384) are dead before the estimator takes its stage-3 copy (640)
-    i16 work[768];
+    // one work array: the windowed block (384; its down-shifted copy for the autocorrelation is made in place) is dead before the
+    // estimator takes its stage-3 copy of the frame (640)
+    i16 work[PE_MAX_FRAME];
     const int buf_len = in.la_pitch + in.frame_length + in.ltp_mem_length;
-    silk_find_pitch_lags_dev(c, (const i16 *)in.x_buf, (i16 *)out.res, (i16 *)work, (i16 *)work + 384, (i16 *)work, o);
+    silk_find_pitch_lags_dev(c, (const i16 *)in.x_buf, (i16 *)out.res, (i16 *)work, (i16 *)work, (i16 *)work, o);
     for (int k = buf_len; k < OPUSGPU_SILK_PITCH_BUF; k++) out.res[k] = 0;
     for (int k = 0; k < 4; k++) out.pitchL[k] = k < in.nb_subfr ? o.pitchL[k] : 0;
     out.lagIndex = o.lagIndex; out.contourIndex = o.contourIndex; out.LTPCorr_Q15 = o.LTPCorr_Q15; out.signalType = o.signalType;

@@ -111,10 +111,22 @@ CA_DEV int silk_autocorr_dev(i32 *ac, XA x, XS xs, int n, int correlationCount)
         shift = 0;
         for (int i = 0; i < n; i++) xs[i] = (i16)(i32)x[i];
     }
-    for (int k = 0; k <= lag; k++) {
-        i32 d = 0;
-        for (int j = 0; j + k < n; j++) d = s_addw(d, __mul24((i32)xs[j], (i32)xs[j + k]));
-        ac[k] = d;
+    {
+        // all lags in one pass: the previous samples travel in a register window that starts at zero (the products a lag's loop
+        // bound leaves out vanish); MAC16_16 sums wrap, so the order of the products is free
+        enum { MAXLAG = MAX_SHAPE_LPC_ORDER + 1 };
+        i32 acc[MAXLAG], w[MAXLAG];
+#pragma unroll
+        for (int k = 0; k < MAXLAG; k++) { acc[k] = 0; w[k] = 0; }
+        for (int j = 0; j < n; j++) {
+            const i32 xj = (i32)xs[j];
+#pragma unroll
+            for (int k = MAXLAG - 1; k > 0; k--) w[k] = w[k - 1];
+            w[0] = xj;
+#pragma unroll
+            for (int k = 0; k < MAXLAG; k++) acc[k] = s_addw(acc[k], __mul24(xj, w[k]));
+        }
+        for (int k = 0; k <= lag; k++) ac[k] = acc[k];
     }
     shift = 2 * shift;
     if (shift <= 0) ac[0] = s_addw(ac[0], shl32((i32)1, -shift));
