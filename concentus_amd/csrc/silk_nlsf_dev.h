@@ -194,26 +194,61 @@ CA_DEV void silk_NLSF_unpack_dev(i16 *ec_ix, u8 *pred_Q8, const NlsfCB &cb, int 
 // NLSF_del_dec_quant.c:35-217. ind[][] rows are written for every coefficient the moment it is visited, so the
 // whole-row copy of the reference (:183, which also moves not-yet-written bytes) moves the same live bytes as the
 // copy of the visited suffix done here.
-CA_DEV i32 silk_NLSF_del_dec_quant_dev(i8 *indices, const i16 *x_Q10, const i16 *w_Q5, const u8 *pred_coef_Q8, const i16 *ec_ix,
+#if defined(CA_HOST_EMU)
+#define CA_NLSF_MEMBER inline
+#else
+#define CA_NLSF_MEMBER __device__ __forceinline__
+#endif
+// The trellis' survivor state: index paths, previous outputs, rate-distortion values. Every access is a dependent step of the search
+// (indexed by state and coefficient at run time), so where it lives sets the pace: local arrays (private memory on the device) by
+// default, a lane's column of an LDS block [slot][64 lanes] in the kernels (NlsfTrellisCol).
+struct NlsfTrellisLocal {
+    i32 v[28];
+    i16 path[NLSF_DD_STATES * SILK_MAX_LPC];
+    CA_NLSF_MEMBER i16 &ind(int j, int i) { return path[j * SILK_MAX_LPC + i]; }
+    CA_NLSF_MEMBER i32 &prev_out(int j) { return v[j]; }
+    CA_NLSF_MEMBER i32 &RD(int j) { return v[8 + j]; }
+    CA_NLSF_MEMBER i32 &RD_min(int j) { return v[16 + j]; }
+    CA_NLSF_MEMBER i32 &RD_max(int j) { return v[20 + j]; }
+    CA_NLSF_MEMBER i32 &sort(int j) { return v[24 + j]; }
+};
+enum { NLSF_TRELLIS_SLOTS16 = NLSF_DD_STATES * SILK_MAX_LPC + 2 * 28 };     // 64 16-bit slots + 28 32-bit slots per lane
+struct NlsfTrellisCol {
+    i16 *p16;                                            // -> this lane's 16-bit column (slot stride 64)
+    i32 *p32;                                            // -> this lane's 32-bit column behind it
+    CA_NLSF_MEMBER i16 &ind(int j, int i) { return p16[(j * SILK_MAX_LPC + i) * 64]; }
+    CA_NLSF_MEMBER i32 &prev_out(int j) { return p32[j * 64]; }
+    CA_NLSF_MEMBER i32 &RD(int j) { return p32[(8 + j) * 64]; }
+    CA_NLSF_MEMBER i32 &RD_min(int j) { return p32[(16 + j) * 64]; }
+    CA_NLSF_MEMBER i32 &RD_max(int j) { return p32[(20 + j) * 64]; }
+    CA_NLSF_MEMBER i32 &sort(int j) { return p32[(24 + j) * 64]; }
+    // block: NLSF_TRELLIS_SLOTS16 * 64 16-bit words of LDS, 4-byte aligned; lane: 0 .. 63
+    static CA_NLSF_MEMBER NlsfTrellisCol at(i16 *block, int lane)
+    {
+        NlsfTrellisCol t;
+        t.p16 = block + lane;
+        t.p32 = reinterpret_cast<i32 *>(block + NLSF_DD_STATES * SILK_MAX_LPC * 64) + lane;
+        return t;
+    }
+};
+
+template <class TM>
+CA_DEV i32 silk_NLSF_del_dec_quant_dev(TM &T, i8 *indices, const i16 *x_Q10, const i16 *w_Q5, const u8 *pred_coef_Q8, const i16 *ec_ix,
                                        const u8 *ec_rates_Q5, int quant_step_size_Q16, i32 inv_quant_step_size_Q6, i32 mu_Q20, int order)
 {
-    int ind_sort[NLSF_DD_STATES];
-    i8 ind[NLSF_DD_STATES][SILK_MAX_LPC];
-    i16 prev_out_Q10[2 * NLSF_DD_STATES];
-    i32 RD_Q25[2 * NLSF_DD_STATES], RD_min_Q25[NLSF_DD_STATES], RD_max_Q25[NLSF_DD_STATES];
     int nStates = 1;
-    RD_Q25[0] = 0;
-    prev_out_Q10[0] = 0;
+    T.RD(0) = 0;
+    T.prev_out(0) = 0;
     for (int i = order - 1;; i--) {
         const u8 *rates_Q5 = &ec_rates_Q5[ec_ix[i]];
         const i32 pred_coef_Q16 = (i32)pred_coef_Q8[i] << 8;
         const int in_Q10 = x_Q10[i];
         for (int j = 0; j < nStates; j++) {
-            const int pred_Q10 = s_smulwb(pred_coef_Q16, prev_out_Q10[j]);
+            const int pred_Q10 = s_smulwb(pred_coef_Q16, T.prev_out(j));
             const int res_Q10 = in_Q10 - pred_Q10;
             int ind_tmp = s_smulwb(inv_quant_step_size_Q6, res_Q10);
             ind_tmp = s_limit(ind_tmp, -NLSF_MAX_AMP_EXT, NLSF_MAX_AMP_EXT - 1);
-            ind[j][i] = (i8)ind_tmp;
+            T.ind(j, i) = (i8)ind_tmp;
             // out0 / out1: the two reconstruction levels around the residual (the reference tabulates them per call, :61-79)
             int out0_Q10 = shl32(ind_tmp, 10), out1_Q10 = out0_Q10 + 1024;
             if (ind_tmp > 0) { out0_Q10 -= NLSF_LEVEL_ADJ_Q10; out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
@@ -222,8 +257,8 @@ CA_DEV i32 silk_NLSF_del_dec_quant_dev(i8 *indices, const i16 *x_Q10, const i16 
             else { out0_Q10 += NLSF_LEVEL_ADJ_Q10; out1_Q10 += NLSF_LEVEL_ADJ_Q10; }
             out0_Q10 = s_smulwb(out0_Q10, quant_step_size_Q16) + pred_Q10;
             out1_Q10 = s_smulwb(out1_Q10, quant_step_size_Q16) + pred_Q10;
-            prev_out_Q10[j] = (i16)out0_Q10;
-            prev_out_Q10[j + nStates] = (i16)out1_Q10;
+            T.prev_out(j) = (i16)out0_Q10;
+            T.prev_out(j + nStates) = (i16)out1_Q10;
             int rate0_Q5, rate1_Q5;
             if (ind_tmp + 1 >= NLSF_MAX_AMP) {
                 if (ind_tmp + 1 == NLSF_MAX_AMP) {
@@ -245,49 +280,49 @@ CA_DEV i32 silk_NLSF_del_dec_quant_dev(i8 *indices, const i16 *x_Q10, const i16 
                 rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
                 rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
             }
-            const i32 RD_tmp = RD_Q25[j];
+            const i32 RD_tmp = T.RD(j);
             int diff_Q10 = in_Q10 - out0_Q10;
-            RD_Q25[j] = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate0_Q5));
+            T.RD(j) = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate0_Q5));
             diff_Q10 = in_Q10 - out1_Q10;
-            RD_Q25[j + nStates] = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate1_Q5));
+            T.RD(j + nStates) = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate1_Q5));
         }
         if (nStates <= (NLSF_DD_STATES >> 1)) {
-            for (int j = 0; j < nStates; j++) ind[j + nStates][i] = (i8)(ind[j][i] + 1);
+            for (int j = 0; j < nStates; j++) T.ind(j + nStates, i) = (i8)(T.ind(j, i) + 1);
             nStates <<= 1;
-            for (int j = nStates; j < NLSF_DD_STATES; j++) ind[j][i] = ind[j - nStates][i];
+            for (int j = nStates; j < NLSF_DD_STATES; j++) T.ind(j, i) = T.ind(j - nStates, i);
         } else if (i > 0) {
             for (int j = 0; j < NLSF_DD_STATES; j++) {
-                if (RD_Q25[j] > RD_Q25[j + NLSF_DD_STATES]) {
-                    RD_max_Q25[j] = RD_Q25[j];
-                    RD_min_Q25[j] = RD_Q25[j + NLSF_DD_STATES];
-                    RD_Q25[j] = RD_min_Q25[j];
-                    RD_Q25[j + NLSF_DD_STATES] = RD_max_Q25[j];
-                    const i16 t = prev_out_Q10[j];
-                    prev_out_Q10[j] = prev_out_Q10[j + NLSF_DD_STATES];
-                    prev_out_Q10[j + NLSF_DD_STATES] = t;
-                    ind_sort[j] = j + NLSF_DD_STATES;
+                if (T.RD(j) > T.RD(j + NLSF_DD_STATES)) {
+                    T.RD_max(j) = T.RD(j);
+                    T.RD_min(j) = T.RD(j + NLSF_DD_STATES);
+                    T.RD(j) = T.RD_min(j);
+                    T.RD(j + NLSF_DD_STATES) = T.RD_max(j);
+                    const i16 t = T.prev_out(j);
+                    T.prev_out(j) = T.prev_out(j + NLSF_DD_STATES);
+                    T.prev_out(j + NLSF_DD_STATES) = t;
+                    T.sort(j) = j + NLSF_DD_STATES;
                 } else {
-                    RD_min_Q25[j] = RD_Q25[j];
-                    RD_max_Q25[j] = RD_Q25[j + NLSF_DD_STATES];
-                    ind_sort[j] = j;
+                    T.RD_min(j) = T.RD(j);
+                    T.RD_max(j) = T.RD(j + NLSF_DD_STATES);
+                    T.sort(j) = j;
                 }
             }
             while (1) {
                 i32 min_max = 0x7FFFFFFF, max_min = 0;
                 int ind_min_max = 0, ind_max_min = 0;
                 for (int j = 0; j < NLSF_DD_STATES; j++) {
-                    if (min_max > RD_max_Q25[j]) { min_max = RD_max_Q25[j]; ind_min_max = j; }
-                    if (max_min < RD_min_Q25[j]) { max_min = RD_min_Q25[j]; ind_max_min = j; }
+                    if (min_max > T.RD_max(j)) { min_max = T.RD_max(j); ind_min_max = j; }
+                    if (max_min < T.RD_min(j)) { max_min = T.RD_min(j); ind_max_min = j; }
                 }
                 if (min_max >= max_min) break;
-                ind_sort[ind_max_min] = ind_sort[ind_min_max] ^ NLSF_DD_STATES;
-                RD_Q25[ind_max_min] = RD_Q25[ind_min_max + NLSF_DD_STATES];
-                prev_out_Q10[ind_max_min] = prev_out_Q10[ind_min_max + NLSF_DD_STATES];
-                RD_min_Q25[ind_max_min] = 0;
-                RD_max_Q25[ind_min_max] = 0x7FFFFFFF;
-                for (int k = i; k < order; k++) ind[ind_max_min][k] = ind[ind_min_max][k];
+                T.sort(ind_max_min) = T.sort(ind_min_max) ^ NLSF_DD_STATES;
+                T.RD(ind_max_min) = T.RD(ind_min_max + NLSF_DD_STATES);
+                T.prev_out(ind_max_min) = T.prev_out(ind_min_max + NLSF_DD_STATES);
+                T.RD_min(ind_max_min) = 0;
+                T.RD_max(ind_min_max) = 0x7FFFFFFF;
+                for (int k = i; k < order; k++) T.ind(ind_max_min, k) = T.ind(ind_min_max, k);
             }
-            for (int j = 0; j < NLSF_DD_STATES; j++) ind[j][i] = (i8)(ind[j][i] + (ind_sort[j] >> NLSF_DD_STATES_LOG2));
+            for (int j = 0; j < NLSF_DD_STATES; j++) T.ind(j, i) = (i8)(T.ind(j, i) + (T.sort(j) >> NLSF_DD_STATES_LOG2));
         } else {
             break;
         }
@@ -295,9 +330,9 @@ CA_DEV i32 silk_NLSF_del_dec_quant_dev(i8 *indices, const i16 *x_Q10, const i16 
     int ind_tmp = 0;
     i32 min_Q25 = 0x7FFFFFFF;
     for (int j = 0; j < 2 * NLSF_DD_STATES; j++) {
-        if (min_Q25 > RD_Q25[j]) { min_Q25 = RD_Q25[j]; ind_tmp = j; }
+        if (min_Q25 > T.RD(j)) { min_Q25 = T.RD(j); ind_tmp = j; }
     }
-    for (int j = 0; j < order; j++) indices[j] = ind[ind_tmp & (NLSF_DD_STATES - 1)][j];
+    for (int j = 0; j < order; j++) indices[j] = T.ind(ind_tmp & (NLSF_DD_STATES - 1), j);
     indices[0] = (i8)(indices[0] + (ind_tmp >> NLSF_DD_STATES_LOG2));
     return min_Q25;
 }
@@ -330,7 +365,8 @@ CA_DEV void silk_NLSF_decode_dev(i16 *pNLSF_Q15, const i8 *NLSFIndices, const Nl
 }
 
 // silk_NLSF_encode (NLSF_encode.c:38-157): quantises pNLSF_Q15 in place, writes NLSFIndices[order + 1], returns the RD value
-CA_DEV i32 silk_NLSF_encode_dev(i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &cb, const i16 *pW_QW, int NLSF_mu_Q20, int nSurvivors,
+template <class TM>
+CA_DEV i32 silk_NLSF_encode_dev(TM &T, i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &cb, const i16 *pW_QW, int NLSF_mu_Q20, int nSurvivors,
                                 int signalType)
 {
     i32 err_Q26[NLSF_MAX_SURVIVORS];                     // nVectors <= 32
@@ -370,7 +406,7 @@ CA_DEV i32 silk_NLSF_encode_dev(i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &c
             W_adj_Q5[i] = (i16)(((i32)pW_QW[i] << 5) / (i32)W_tmp_QW[i]);
         }
         silk_NLSF_unpack_dev(ec_ix, pred_Q8, cb, ind1);
-        i32 RD = silk_NLSF_del_dec_quant_dev(path, res_Q10, W_adj_Q5, pred_Q8, ec_ix, cb.ec_Rates_Q5, cb.quantStepSize_Q16,
+        i32 RD = silk_NLSF_del_dec_quant_dev(T, path, res_Q10, W_adj_Q5, pred_Q8, ec_ix, cb.ec_Rates_Q5, cb.quantStepSize_Q16,
                                              cb.invQuantStepSize_Q6, NLSF_mu_Q20, cb.order);
         const u8 *iCDF_ptr = &cb.CB1_iCDF[(signalType >> 1) * cb.nVectors];
         const int prob_Q8 = ind1 == 0 ? 256 - iCDF_ptr[ind1] : iCDF_ptr[ind1 - 1] - iCDF_ptr[ind1];
@@ -389,7 +425,9 @@ CA_DEV i32 silk_NLSF_encode_dev(i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &c
 }
 
 // silk_process_NLSFs (process_NLSFs.c:35-106). pNLSF_Q15: in = silk_find_LPC_FIX's NLSFs, out = the quantised ones.
-CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
+// T: the trellis' survivor state (NlsfTrellisLocal / NlsfTrellisCol above).
+template <class TM>
+CA_DEV void silk_process_NLSFs_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
                                    int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
                                    int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
 {
@@ -407,7 +445,7 @@ CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIn
         for (int i = 0; i < order; i++)
             pNLSFW_QW[i] = (i16)s_smlawb(pNLSFW_QW[i] >> 1, (i32)pNLSFW0_temp_QW[i], i_sqr_Q15);
     }
-    silk_NLSF_encode_dev(NLSFIndices, pNLSF_Q15, cb, pNLSFW_QW, NLSF_mu_Q20, nSurvivors, signalType);
+    silk_NLSF_encode_dev(T, NLSFIndices, pNLSF_Q15, cb, pNLSFW_QW, NLSF_mu_Q20, nSurvivors, signalType);
     silk_NLSF2A_dev(PredCoef_Q12[1], pNLSF_Q15, order);
     if (doInterpolate) {
         silk_interpolate_dev(pNLSF0_temp_Q15, prev_NLSFq_Q15, pNLSF_Q15, NLSFInterpCoef_Q2, order);
@@ -415,6 +453,15 @@ CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIn
     } else {
         for (int i = 0; i < order; i++) PredCoef_Q12[0][i] = PredCoef_Q12[1][i];
     }
+}
+
+CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
+                                   int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
+                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
+{
+    NlsfTrellisLocal T;
+    silk_process_NLSFs_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, order, useInterpolatedNLSFs,
+                           NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
 }
 
 // silk_residual_energy_FIX (residual_energy_FIX.c:37-98): x = LPC_in_pre, nb_subfr * (subfr_length + LPC_order) samples

@@ -15,6 +15,7 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
                                                                 int *__restrict__ bad_records)
 {
     __shared__ NlsfTablesLds tables;
+    __shared__ __attribute__((aligned(16))) i16 trellis_s[NLSF_TRELLIS_SLOTS16 * 64];     // the trellis' survivor state, [slot][lane]
     nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
     i8 idx[SILK_MAX_LPC + 1];
     for (int k = 0; k < SILK_MAX_LPC; k++) { nlsf[k] = in.NLSF_Q15[k]; prev[k] = in.prev_NLSFq_Q15[k]; pc[0][k] = pc[1][k] = 0; }
     for (int k = 0; k <= SILK_MAX_LPC; k++) idx[k] = 0;
-    silk_process_NLSFs_dev(pc, idx, nlsf, prev, in.speech_activity_Q8, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
+    NlsfTrellisCol T = NlsfTrellisCol::at(trellis_s, threadIdx.x);
+    silk_process_NLSFs_dev(T, pc, idx, nlsf, prev, in.speech_activity_Q8, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
                            in.NLSFInterpCoef_Q2, in.NLSF_MSVQ_Survivors, in.signalType, &tables);
     for (int k = 0; k < in.predictLPCOrder; k++) { o.PredCoef_Q12[0][k] = pc[0][k]; o.PredCoef_Q12[1][k] = pc[1][k]; o.NLSF_Q15[k] = nlsf[k]; }
     for (int k = 0; k <= in.predictLPCOrder; k++) o.NLSFIndices[k] = idx[k];

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
                                                                   opusgpu_find_pred_coefs_out *__restrict__ outs, int n_rec,
                                                                   int *__restrict__ bad_records)
 {
-    __shared__ i16 edge_s[BURG_EDGE_SLOTS * 64];
+    __shared__ __attribute__((aligned(16))) i16 edge_s[BURG_EDGE_SLOTS * 64];
     __shared__ NlsfTablesLds tables;
     nlsf_stage_tables(tables, threadIdx.x, 64);
     __syncthreads();
@@ -45,7 +45,10 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     i16 pre[OPUSGPU_SILK_BURG_MAX_X];
     BurgEdgesCol e;
     e.p = edge_s + threadIdx.x;
-    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, o, &tables);
+    // the NLSF trellis takes over the edge block once the Burg analyses are done
+    static_assert(NLSF_TRELLIS_SLOTS16 <= BURG_EDGE_SLOTS, "the trellis state fits the edge block");
+    NlsfTrellisCol T = NlsfTrellisCol::at(edge_s, threadIdx.x);
+    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, T, o, &tables);
     const int order = in.predictLPCOrder, nb = in.nb_subfr;
     memset(&out, 0, sizeof(out));
     for (int k = 0; k < order; k++) { out.PredCoef_Q12[0][k] = o.PredCoef_Q12[0][k]; out.PredCoef_Q12[1][k] = o.PredCoef_Q12[1][k]; out.NLSF_Q15[k] = o.NLSF_Q15[k]; }
