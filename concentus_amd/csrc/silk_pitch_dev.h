@@ -102,6 +102,32 @@ CA_DEV i32 pe_inner_prod(XA x, YA y, int len)                                   
     return s;
 }
 
+// Correlations of a 40-sample target against a basis that slides DOWN one sample per lag: sink(j, <tgt, sig[b0 - j ..)>, entering,
+// leaving) for j = 0 .. nlags - 1, where entering = sig[b0 - j] and leaving = sig[b0 - j + 40] (the samples the basis gains / loses
+// when it moves from lag j - 1 to lag j; for j = 0: its first sample and the one after its last). Target and basis live in
+// registers; every signal sample is read once instead of once per lag. `acc0`: per-lag values to add to (for targets longer than
+// 40: call again with the next 40 samples), or nullptr.
+enum { PE_BLK = 40 };
+template <class TA, class XA, class F>
+CA_DEV void pe_xcorr_sliding(TA tgt, XA sig, int b0, int nlags, F sink)
+{
+    i32 t[PE_BLK], b[PE_BLK];
+#pragma unroll
+    for (int i = 0; i < PE_BLK; i++) { t[i] = (i32)tgt[i]; b[i] = (i32)sig[b0 + i]; }
+    i32 leaving = (i32)sig[b0 + PE_BLK];
+    for (int j = 0;; j++) {
+        i32 cc = 0;
+#pragma unroll
+        for (int i = 0; i < PE_BLK; i++) cc = s_addw(cc, __mul24(t[i], b[i]));
+        sink(j, cc, b[0], leaving);
+        if (j + 1 >= nlags) break;
+        leaving = b[PE_BLK - 1];
+#pragma unroll
+        for (int i = PE_BLK - 1; i > 0; i--) b[i] = b[i - 1];
+        b[0] = (i32)sig[b0 - j - 1];
+    }
+}
+
 // pitch_analysis_core_FIX.c:598-746: correlations and energies of every subframe against the lags the stage-3 code books can
 // reach; `frame` is the (possibly down-shifted) full-rate signal. The reference expands both into [subframe][code book vector][5]
 // arrays (2 x 2.7 KB); kept here as the per-subframe lag tables they are copied from (2 x 4 x 22 values) -- the search below
@@ -114,8 +140,11 @@ CA_DEV void pe_calc_corr_energy_st3(i32 *corr /*[4][PE_SCRATCH_SIZE]*/, i32 *nrg
         const int t0 = 4 * sf_length + k * sf_length;                                       // target_ptr
         const int lag_low = Lag_range_ptr[k * 2], lag_high = Lag_range_ptr[k * 2 + 1];
         i32 *scratch_c = corr + k * PE_SCRATCH_SIZE, *scratch_e = nrg + k * PE_SCRATCH_SIZE;
-        // correlations: scratch[j - lag_low] = <target, target - start_lag - j>, j = lag_low .. lag_high
-        for (int j = lag_low; j <= lag_high; j++) scratch_c[j - lag_low] = pe_inner_prod(frame + t0, frame + (t0 - start_lag - j), sf_length);
+        // correlations: scratch[j - lag_low] = <target, target - start_lag - j>, j = lag_low .. lag_high: the basis slides down with j
+        for (int j = 0; j <= lag_high - lag_low; j++) scratch_c[j] = 0;
+        for (int h = 0; h < sf_length; h += PE_BLK)
+            pe_xcorr_sliding(frame + (t0 + h), frame, t0 + h - start_lag - lag_low, lag_high - lag_low + 1,
+                             [&](int j, i32 cc, i32, i32) { scratch_c[j] = s_addw(scratch_c[j], cc); });
         // energies, recursively from the first lag (:713-727)
         const int b0 = t0 - (start_lag + lag_low);                                          // basis_ptr
         i32 energy = pe_inner_prod(frame + b0, frame + b0, sf_length);
@@ -165,19 +194,18 @@ CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *
     i16 C[PE_MAX_NB_SUBFR * CSTRIDE_8KHZ];
     for (int i = 0; i < (nb_subfr >> 1) * CSTRIDE_4KHZ; i++) C[i] = 0;
     for (int k = 0; k < (nb_subfr >> 1); k++) {
-        const i16 *target_ptr = &frame_4kHz[4 * SF_LENGTH_4KHZ + k * SF_LENGTH_8KHZ];
-        const i16 *basis_ptr = target_ptr - MIN_LAG_4KHZ;
-        i32 cross_corr = pe_inner_prod(target_ptr, basis_ptr, SF_LENGTH_8KHZ);             // xcorr32[MAX_LAG_4KHZ - d] = <target, target - d>
+        const int t0 = 4 * SF_LENGTH_4KHZ + k * SF_LENGTH_8KHZ;
+        const i16 *target_ptr = &frame_4kHz[t0];
+        static_assert(SF_LENGTH_8KHZ == PE_BLK, "one block per target");
         i32 normalizer = pe_inner_prod(target_ptr, target_ptr, SF_LENGTH_8KHZ);
-        normalizer = s_addw(normalizer, pe_inner_prod(basis_ptr, basis_ptr, SF_LENGTH_8KHZ));
+        normalizer = s_addw(normalizer, pe_inner_prod(target_ptr - MIN_LAG_4KHZ, target_ptr - MIN_LAG_4KHZ, SF_LENGTH_8KHZ));
         normalizer = s_addw(normalizer, s_smulbb(SF_LENGTH_8KHZ, 4000));
-        C[k * CSTRIDE_4KHZ] = (i16)s_div32_varq(cross_corr, normalizer, 13 + 1);
-        for (int d = MIN_LAG_4KHZ + 1; d <= MAX_LAG_4KHZ; d++) {
-            basis_ptr--;
-            cross_corr = pe_inner_prod(target_ptr, basis_ptr, SF_LENGTH_8KHZ);
-            normalizer = s_addw(normalizer, __mul24((i32)basis_ptr[0], (i32)basis_ptr[0]) - __mul24((i32)basis_ptr[SF_LENGTH_8KHZ], (i32)basis_ptr[SF_LENGTH_8KHZ]));
-            C[k * CSTRIDE_4KHZ + d - MIN_LAG_4KHZ] = (i16)s_div32_varq(cross_corr, normalizer, 13 + 1);
-        }
+        // lag d = MIN_LAG_4KHZ + j: xcorr32[MAX_LAG_4KHZ - d] = <target, target - d>; the normaliser follows the basis' energy
+        pe_xcorr_sliding(target_ptr, (const i16 *)frame_4kHz, t0 - MIN_LAG_4KHZ, MAX_LAG_4KHZ - MIN_LAG_4KHZ + 1,
+                         [&](int j, i32 cross_corr, i32 entering, i32 leaving) {
+                             if (j > 0) normalizer = s_addw(normalizer, __mul24(entering, entering) - __mul24(leaving, leaving));
+                             C[k * CSTRIDE_4KHZ + j] = (i16)s_div32_varq(cross_corr, normalizer, 13 + 1);
+                         });
     }
     if (nb_subfr == PE_MAX_NB_SUBFR) {
         for (int i = MAX_LAG_4KHZ; i >= MIN_LAG_4KHZ; i--) {
@@ -229,13 +257,20 @@ CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *
     for (int i = 0; i < nb_subfr * CSTRIDE_8KHZ; i++) C[i] = 0;
     for (int k = 0; k < nb_subfr; k++) {
         const i16 *target_ptr = &frame_8kHz[PE_LTP_MEM_LENGTH_MS * 8 + k * SF_LENGTH_8KHZ];
-        const i32 energy_target = s_addw(pe_inner_prod(target_ptr, target_ptr, SF_LENGTH_8KHZ), 1);
+        i32 t[SF_LENGTH_8KHZ];                                                             // the target in registers: read once per subframe
+        i32 energy_target = 1;
+#pragma unroll
+        for (int i = 0; i < SF_LENGTH_8KHZ; i++) { t[i] = (i32)target_ptr[i]; energy_target = s_addw(energy_target, __mul24(t[i], t[i])); }
         for (int j = 0; j < length_d_comp; j++) {
             const int d = d_comp[j];
             const i16 *basis_ptr = target_ptr - d;
-            const i32 cross_corr = pe_inner_prod(target_ptr, basis_ptr, SF_LENGTH_8KHZ);
+            i32 b[SF_LENGTH_8KHZ], cross_corr = 0;                                         // the basis too: one read serves both sums
+#pragma unroll
+            for (int i = 0; i < SF_LENGTH_8KHZ; i++) { b[i] = (i32)basis_ptr[i]; cross_corr = s_addw(cross_corr, __mul24(t[i], b[i])); }
             if (cross_corr > 0) {
-                const i32 energy_basis = pe_inner_prod(basis_ptr, basis_ptr, SF_LENGTH_8KHZ);
+                i32 energy_basis = 0;
+#pragma unroll
+                for (int i = 0; i < SF_LENGTH_8KHZ; i++) energy_basis = s_addw(energy_basis, __mul24(b[i], b[i]));
                 C[k * CSTRIDE_8KHZ + d - (MIN_LAG_8KHZ - 2)] = (i16)s_div32_varq(cross_corr, s_addw(energy_target, energy_basis), 13 + 1);
             } else {
                 C[k * CSTRIDE_8KHZ + d - (MIN_LAG_8KHZ - 2)] = 0;
