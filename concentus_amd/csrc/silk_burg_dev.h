@@ -5,7 +5,14 @@
 #pragma once
 #include "silk_math.h"
 
+#include <utility>
+
 namespace ca {
+
+template <class F, int... I>
+CA_DEV void ca_static_for_impl(F &f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+CA_DEV void ca_static_for(F &f) { ca_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 enum { BURG_QA = 25, BURG_COND_FAC_Q32 = 42950 };                    // SILK_FIX_CONST(FIND_LPC_COND_FAC = 1e-5f, 32)
 
@@ -91,6 +98,7 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
     if (rshifts < -16) rshifts = -16;
     C0 = rshifts > 0 ? (i32)(C0_64 >> rshifts) : shl32((i32)C0_64, -rshifts);
     CAb[0] = CAf[0] = s_addw(s_addw(C0, s_smmul(COND_FAC_Q32, C0)), 1);
+#pragma unroll
     for (k = 0; k < 16; k++) { C_first_row[k] = 0; Af_QA[k] = 0; }
 #pragma unroll
     for (s = 0; s < 4; s++) {
@@ -100,46 +108,60 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
                 if (n < D) C_first_row[n] = s_addw(C_first_row[n], rshifts > 0 ? (i32)(acc[s][n] >> rshifts) : shl32((i32)acc[s][n], -rshifts));
         }
     }
+#pragma unroll
     for (k = 0; k < 16; k++) C_last_row[k] = C_first_row[k];
     invGain_Q30 = (i32)1 << 30;
     reached_max_gain = 0;
-    for (n = 0; n < D; n++) {
+    // The order recursion, unrolled over n at compile time: with n a constant every index into C_first_row / C_last_row / Af_QA /
+    // CAf / CAb below is one too, so the five arrays live in registers (indexed at run time they are private memory, and each of
+    // their ~1 500 dependent updates is a round trip to it). Steps with n >= D, or after the gain limit was hit, do nothing.
+    auto order_step = [&](auto NC) __attribute__((always_inline)) {
+        constexpr int n = decltype(NC)::value;
+        if (n >= D || reached_max_gain) return;
+        i32 tmp1, tmp2, x1, x2, num, nrg, rc_Q31, Atmp_QA, Atmp1;
+        int lz;
         if (rshifts > -2) {
-            for (s = 0; s < nb_subfr; s++) {
+            for (int s = 0; s < nb_subfr; s++) {
                 x1 = (i32)(0u - (u32)shl32(e.head(s, n), 16 - rshifts));
                 x2 = (i32)(0u - (u32)shl32(e.tail(s, 16 - n - 1), 16 - rshifts));
                 tmp1 = shl32(e.head(s, n), QA - 16);
                 tmp2 = shl32(e.tail(s, 16 - n - 1), QA - 16);
-                for (k = 0; k < n; k++) {
-                    C_first_row[k] = s_smlawb(C_first_row[k], x1, e.head(s, n - k - 1));
-                    C_last_row[k] = s_smlawb(C_last_row[k], x2, e.tail(s, 16 - n + k));
+#pragma unroll
+                for (int k = 0; k < n; k++) {
+                    const i32 h = e.head(s, n - k - 1), t = e.tail(s, 16 - n + k);
+                    C_first_row[k] = s_smlawb(C_first_row[k], x1, h);
+                    C_last_row[k] = s_smlawb(C_last_row[k], x2, t);
                     Atmp_QA = Af_QA[k];
-                    tmp1 = s_smlawb(tmp1, Atmp_QA, e.head(s, n - k - 1));
-                    tmp2 = s_smlawb(tmp2, Atmp_QA, e.tail(s, 16 - n + k));
+                    tmp1 = s_smlawb(tmp1, Atmp_QA, h);
+                    tmp2 = s_smlawb(tmp2, Atmp_QA, t);
                 }
                 tmp1 = shl32((i32)(0u - (u32)tmp1), 32 - QA - rshifts);
                 tmp2 = shl32((i32)(0u - (u32)tmp2), 32 - QA - rshifts);
-                for (k = 0; k <= n; k++) {
+#pragma unroll
+                for (int k = 0; k <= n; k++) {
                     CAf[k] = s_smlawb(CAf[k], tmp1, e.head(s, n - k));
                     CAb[k] = s_smlawb(CAb[k], tmp2, e.tail(s, 16 - n + k - 1));
                 }
             }
         } else {
-            for (s = 0; s < nb_subfr; s++) {
+            for (int s = 0; s < nb_subfr; s++) {
                 x1 = (i32)(0u - (u32)shl32(e.head(s, n), -rshifts));
                 x2 = (i32)(0u - (u32)shl32(e.tail(s, 16 - n - 1), -rshifts));
                 tmp1 = shl32(e.head(s, n), 17);
                 tmp2 = shl32(e.tail(s, 16 - n - 1), 17);
-                for (k = 0; k < n; k++) {
-                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)(i32)e.head(s, n - k - 1));
-                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)(i32)e.tail(s, 16 - n + k));
+#pragma unroll
+                for (int k = 0; k < n; k++) {
+                    const i32 h = e.head(s, n - k - 1), t = e.tail(s, 16 - n + k);
+                    C_first_row[k] = (i32)((u32)C_first_row[k] + (u32)x1 * (u32)h);
+                    C_last_row[k] = (i32)((u32)C_last_row[k] + (u32)x2 * (u32)t);
                     Atmp1 = s_rshift_round(Af_QA[k], QA - 17);
-                    tmp1 = (i32)((u32)tmp1 + (u32)(i32)e.head(s, n - k - 1) * (u32)Atmp1);
-                    tmp2 = (i32)((u32)tmp2 + (u32)(i32)e.tail(s, 16 - n + k) * (u32)Atmp1);
+                    tmp1 = (i32)((u32)tmp1 + (u32)h * (u32)Atmp1);
+                    tmp2 = (i32)((u32)tmp2 + (u32)t * (u32)Atmp1);
                 }
                 tmp1 = (i32)(0u - (u32)tmp1);
                 tmp2 = (i32)(0u - (u32)tmp2);
-                for (k = 0; k <= n; k++) {
+#pragma unroll
+                for (int k = 0; k <= n; k++) {
                     CAf[k] = s_smlaww(CAf[k], tmp1, shl32(e.head(s, n - k), -rshifts - 1));
                     CAb[k] = s_smlaww(CAb[k], tmp2, shl32(e.tail(s, 16 - n + k - 1), -rshifts - 1));
                 }
@@ -149,7 +171,8 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
         tmp2 = C_last_row[n];
         num = 0;
         nrg = s_addw(CAb[0], CAf[0]);
-        for (k = 0; k < n; k++) {
+#pragma unroll
+        for (int k = 0; k < n; k++) {
             Atmp_QA = Af_QA[k];
             lz = s_clz32(s_abs(Atmp_QA)) - 1;
             if (lz > 32 - QA) lz = 32 - QA;
@@ -178,7 +201,8 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
         } else {
             invGain_Q30 = tmp1;
         }
-        for (k = 0; k < (n + 1) >> 1; k++) {
+#pragma unroll
+        for (int k = 0; k < (n + 1) >> 1; k++) {
             tmp1 = Af_QA[k];
             tmp2 = Af_QA[n - k - 1];
             Af_QA[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
@@ -186,18 +210,22 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
         }
         Af_QA[n] = rc_Q31 >> (31 - QA);
         if (reached_max_gain) {
-            for (k = n + 1; k < D; k++) Af_QA[k] = 0;
-            break;
+#pragma unroll
+            for (int k = n + 1; k < 16; k++) if (k < D) Af_QA[k] = 0;
+            return;
         }
-        for (k = 0; k <= n + 1; k++) {
+#pragma unroll
+        for (int k = 0; k <= n + 1; k++) {
             tmp1 = CAf[k];
             tmp2 = CAb[n - k + 1];
             CAf[k] = s_addw(tmp1, shl32(s_smmul(tmp2, rc_Q31), 1));
             CAb[n - k + 1] = s_addw(tmp2, shl32(s_smmul(tmp1, rc_Q31), 1));
         }
-    }
+    };
+    ca_static_for<16>(order_step);
     if (reached_max_gain) {
-        for (k = 0; k < D; k++) A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
+#pragma unroll
+        for (k = 0; k < 16; k++) if (k < D) A_Q16[k] = (i32)(0u - (u32)s_rshift_round(Af_QA[k], QA - 16));
         if (rshifts > 0) {
             for (s = 0; s < nb_subfr; s++) {
                 i64 acc = 0;
@@ -216,11 +244,14 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
     } else {
         nrg = CAf[0];
         tmp1 = (i32)1 << 16;
-        for (k = 0; k < D; k++) {
-            Atmp1 = s_rshift_round(Af_QA[k], QA - 16);
-            nrg = s_smlaww(nrg, CAf[k + 1], Atmp1);
-            tmp1 = s_smlaww(tmp1, Atmp1, Atmp1);
-            A_Q16[k] = (i32)(0u - (u32)Atmp1);
+#pragma unroll
+        for (k = 0; k < 16; k++) {
+            if (k < D) {
+                Atmp1 = s_rshift_round(Af_QA[k], QA - 16);
+                nrg = s_smlaww(nrg, CAf[k + 1], Atmp1);
+                tmp1 = s_smlaww(tmp1, Atmp1, Atmp1);
+                A_Q16[k] = (i32)(0u - (u32)Atmp1);
+            }
         }
         *res_nrg = s_smlaww(nrg, s_smmul(COND_FAC_Q32, C0), (i32)(0u - (u32)tmp1));
         *res_nrg_Q = -rshifts;
