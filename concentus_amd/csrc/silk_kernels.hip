@@ -125,11 +125,23 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
                 const i16 *inp = &NSQ.xq[start_idx + k * subfr_length];
                 i16 *outp = &sLTP[start_idx];
                 const int len = ltp_mem_length - start_idx;
+                // the predictLPCOrder previous input samples travel in a register window: every sample of xq is read once
+                i32 nA[16], w[16];
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    nA[m] = m < predictLPCOrder ? (i32)(i16)(-A_Q12[m]) : 0;
+                    w[m] = m < predictLPCOrder ? (i32)inp[predictLPCOrder - 1 - m] : 0;
+                }
                 for (int ix = predictLPCOrder; ix < len; ix++) {
                     i32 sum = 0;
-                    for (int m = 0; m < predictLPCOrder; m++) sum = s_addw(sum, __mul24((i32)(i16)(-A_Q12[m]), (i32)inp[ix - 1 - m]));
-                    i32 v = (i32)inp[ix] + pshr32(sum, 12);
+#pragma unroll
+                    for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
+                    const i32 xi = (i32)inp[ix];
+                    i32 v = xi + pshr32(sum, 12);
                     outp[ix] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+#pragma unroll
+                    for (int m = 15; m > 0; m--) w[m] = w[m - 1];
+                    w[0] = xi;
                 }
                 for (int j = 0; j < predictLPCOrder; j++) outp[j] = 0;
                 rewhite_flag = 1;

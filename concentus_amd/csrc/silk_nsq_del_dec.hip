@@ -134,10 +134,26 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 const i16 *inp = &NSQ.xq[start_idx + sf * L];
                 i16 *outp = &sLTP[start_idx];
                 const int len = ltp_mem - start_idx;
-                for (int ix = pord + k; ix < len; ix += 4) {
-                    i32 sum = 0;
-                    for (int m = 0; m < pord; m++) sum = s_addw(sum, __mul24((i32)(i16)(-A_Q12[m]), (i32)inp[ix - 1 - m]));
-                    outp[ix] = sat16((i32)inp[ix] + pshr32(sum, 12));
+                {
+                    // every lane of the quad takes a contiguous quarter of the outputs; the pord previous input samples travel in a
+                    // register window, so each sample of xq is read once per lane that needs it
+                    const int chunk = (len - pord + 3) >> 2, i0 = pord + k * chunk, i1 = imin(len, i0 + chunk);
+                    i32 nA[16], w[16];
+#pragma unroll
+                    for (int m = 0; m < 16; m++) {
+                        nA[m] = m < pord ? (i32)(i16)(-A_Q12[m]) : 0;
+                        w[m] = (m < pord && i0 < i1) ? (i32)inp[i0 - 1 - m] : 0;
+                    }
+                    for (int ix = i0; ix < i1; ix++) {
+                        i32 sum = 0;
+#pragma unroll
+                        for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
+                        const i32 xi = (i32)inp[ix];
+                        outp[ix] = sat16(xi + pshr32(sum, 12));
+#pragma unroll
+                        for (int m = 15; m > 0; m--) w[m] = w[m - 1];
+                        w[0] = xi;
+                    }
                 }
                 for (int j = k; j < pord; j += 4) outp[j] = 0;
                 ltp_idx = ltp_mem;
