@@ -18,6 +18,8 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
   silk_frames     65 536 frames through the WHOLE chain on the device: pitch buffer -> find_pitch_lags -> noise_shape_analysis ->
                   find_pred_coefs -> process_gains -> prefilter -> NSQ_del_dec -> encode_indices + encode_pulses -> range-coder bytes (records between the kernels filled on the
                   device, concentus_amd/silk_chain.py); parity per frame against the reference's own results.
+  silk_frames_cbr the same on frames captured from a constant-bitrate encoder, with silk_encode_frame_FIX's bitrate loop: a rate-control
+                  step after every pass, frames over / under budget quantised + coded again (about four passes per frame)
   silk_analysis   the five analysis calls of silk_encode_frame_FIX between the VAD and the quantiser (silk_find_pitch_lags_FIX,
                   silk_noise_shape_analysis_FIX, silk_find_pred_coefs_FIX, silk_process_gains_FIX, silk_prefilter_FIX), 65 536
                   distinct captured records each; value = frames/s through all five.
@@ -68,7 +70,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "silk_frames", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "silk_frames", "silk_frames_cbr", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -743,7 +745,8 @@ def main(argv=None):
             if not np.array_equal(lo.cpu().numpy()[:, :36], rec["lpc_out"][:, :36]):
                 raise SystemExit("PARITY FAILURE (silk_find_LPC)")
             parity = {"checked": F, "note": "every record (NLSF_Q15, NLSFInterpCoef_Q2) vs the reference's own captured outputs"}
-    elif a.workload == "silk_frames":
+    elif a.workload in ("silk_frames", "silk_frames_cbr"):
+        cbr = a.workload == "silk_frames_cbr"      # constant bitrate: silk_encode_frame_FIX's bitrate loop runs on (almost) every frame
         F = a.frames or 65536
         steps = a.steps or 5
         warm = a.warmup if a.warmup is not None else 1
@@ -752,7 +755,8 @@ def main(argv=None):
         from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS
         if not silk_corpus.available():
             raise SystemExit("silk_frames needs oracle/_ref/libopus_ref_silkcap.so (frames are captured from the reference encoder)")
-        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "chain_dd", seed=20260401 + 1000003 * rank).items()}
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "chain_dd", seed=20260401 + 1000003 * rank,
+                                                              variant="wb20cbr" if cbr else "wb20").items()}
         names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in",
                  "prefilter_in": "c_prefilter_in", "q_in": "c_q_in", "bits_in": "c_bits_in"}
         host_in = {k: rec[v].copy() for k, v in names.items()}
@@ -764,13 +768,23 @@ def main(argv=None):
         pf0, nsq0, ec0 = (torch.from_numpy(rec[k]).to(dev) for k in ("c_prefilter_state_in", "c_q_state_in", "c_ec_in"))
         pf_st, nsq_st, ec_st = pf0.clone(), nsq0.clone(), ec0.clone()
         chain = SilkAnalysisChain(16, 4)
+        rate0 = rate_st = None
+        if cbr:
+            from concentus_amd import silk as S
+            ctl = np.zeros(F, dtype=np.dtype(S.RateCtl))
+            fargs = rec["c_frame_args"].view(np.int32)
+            ctl["condCoding"], ctl["maxBits"], ctl["useCBR"], ctl["nb_subfr"], ctl["frame_length"] = fargs[:, 0], fargs[:, 1], fargs[:, 2], 4, 320
+            rate0 = torch.from_numpy(ctl.view(np.uint8).reshape(F, -1).copy()).to(dev)
+            rate_st = rate0.clone()
 
         def one_step():
             pf_st.copy_(pf0)
             nsq_st.copy_(nsq0)
             ec_st.copy_(ec0)
+            if cbr:
+                rate_st.copy_(rate0)
             return chain.run(d_in["pitch_in"], d_in["shape_in"], d_in["fpc_in"], d_in["gains_in"], d_in["prefilter_in"], pf_st, d_in["q_in"],
-                             nsq_st, True, bits_in=d_in["bits_in"], ec_state=ec_st)
+                             nsq_st, True, bits_in=d_in["bits_in"], ec_state=ec_st, rate_ctl=rate_st)
         for _ in range(warm):
             one_step()
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
@@ -788,6 +802,8 @@ def main(argv=None):
         kbytes = F * (1408 + 324 + 4380 + 1116 + 1328)  # per frame: pitch buffer in, pulses + Seed out, the carried states and the coder rewritten
         limiter = "latency / VALU issue (seven lane-per-frame kernels of serial fixed-point recurrences; whole step timed, kernel = the longest)"
         metric = "SILK 16kHz mono 20ms frames/sec (analysis chain + silk_NSQ_del_dec + entropy coding, pitch buffer -> range-coder bytes)"
+        if cbr:
+            metric = "SILK 16kHz mono 20ms frames/sec, constant bitrate (silk_encode_frame_FIX after the VAD incl. its bitrate loop, pitch buffer -> range-coder bytes)"
         workload = ("%d frames per GPU, each with the records of ONE frame captured from the reference encoder (synthetic 16 kHz mono "
                     "speech, 32 kb/s VOIP, complexity 5/7/10 in turn); the seven kernels run back to back (find_pitch_lags, "
                     "noise_shape_analysis, find_pred_coefs, process_gains, prefilter, NSQ_del_dec, encode_indices + encode_pulses), records between them filled on "
@@ -804,19 +820,39 @@ def main(argv=None):
             v = 1.0 / (1.0 / a_["value"] + 1.0 / b_["value"] + 1.0 / c_["value"])
             return {"value": round(v, 1), "unit": "frames/s", "cores": a_["cores"], "kind": "port", "cpu": a_["cpu"],
                     "sample": "analysis: " + a_["sample"] + "; quantiser: " + b_["sample"] + "; entropy coding: " + c_["sample"]
-                              + "; combined as 1 / (1/a + 1/b + 1/c)"}
+                              + "; combined as 1 / (1/a + 1/b + 1/c)"
+                              + ("; ONE pass per frame (the loop's further quantiser + coder passes are not in this baseline)" if cbr else "")}
+        if cbr:
+            passes = rec["c_frame_args"].view(np.int32)[:, 3]
+            workload += ("; CBR: after every pass one rate-control step, the frames over / under budget quantised + coded again from their "
+                         "entry states (%.2f passes per frame on average, 1-7)" % float(passes.mean()))
+            extra["passes_per_frame"] = round(float(passes.mean()), 3)
         if not a.no_parity and rank == 0:
             for key, want, nb in (("pitch_out", "c_pitch_out", 1380), ("shape_out", "c_shape_out", 380), ("fpc_out", "c_fpc_out", 204),
                                   ("gains_out", "c_gains_out", 52), ("prefilter_out", "c_prefilter_out", 1280)):
                 if not np.array_equal(res[key].cpu().numpy()[:, :nb], rec[want][:, :nb]):
                     raise SystemExit("PARITY FAILURE (silk_frames: %s)" % key)
-            ok = (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), rec["c_q_out"][:, :320])
+            if cbr:
+                misc = rec["c_frame_misc"]
+                got_ctl = rate_st.cpu().numpy().view(np.dtype(S.RateCtl))[:, 0]
+                ok = (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), misc[:, :320])
+                      and np.array_equal(res["Seed"].cpu().numpy(), misc[:, 328:332].copy().view(np.int32)[:, 0])
+                      and np.array_equal(nsq_st.cpu().numpy(), rec["c_frame_nsq"]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"])
+                      and np.array_equal(ec_st.cpu().numpy(), rec["c_frame_ec"]) and np.array_equal(got_ctl["passes"], passes)
+                      and np.array_equal(got_ctl["LastGainIndex"], misc[:, 324:328].copy().view(np.int32)[:, 0]))
+                if not ok:
+                    raise SystemExit("PARITY FAILURE (silk_frames_cbr: what silk_encode_frame_FIX leaves behind)")
+                parity = {"checked": F, "note": "every frame: every stage's output record, and what silk_encode_frame_FIX leaves behind after its "
+                                               "bitrate loop -- pulses, Seed, all of silk_nsq_state, LastGainIndex, the number of passes, the range "
+                                               "coder (every field, every byte written) -- vs the reference"}
+            ok = cbr or (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), rec["c_q_out"][:, :320])
                   and np.array_equal(res["Seed"].cpu().numpy(), rec["c_q_out"][:, 320:324].copy().view(np.int32)[:, 0])
                   and np.array_equal(nsq_st.cpu().numpy(), rec["c_q_state_out"]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"])
                   and np.array_equal(ec_st.cpu().numpy(), rec["c_ec_out"]))
             if not ok:
                 raise SystemExit("PARITY FAILURE (silk_frames: pulses / Seed / silk_nsq_state / prefilter state / range coder)")
-            parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX, "
+            if not cbr:
+                parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX, "
                                            "and the range coder (every field, every byte written) vs what the reference computed for the same frame"}
     elif a.workload == "silk_analysis":
         F = a.frames or 65536

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for w in silk_frames silk_analysis silk_pred silk_nlsf; do
+for w in silk_frames silk_frames_cbr silk_analysis silk_pred silk_nlsf; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > $O/bench_prof_$w.json 2> $O/prof_$w.err
   echo "$w rc=$?"; cut -c1-200 $O/bench_prof_$w.json
 done
