@@ -335,8 +335,8 @@ CA_DEV void lpc_residual_energy(XA x, const i16 *B, int d, int first, int len, i
 // the order samples). Writes NLSF_Q15[order] and returns psEncC->indices.NLSFInterpCoef_Q2.
 // e: the Burg recursion's edge accessor over the same signal (silk_burg_dev.h), already staged.
 template <class XA, class XE>
-CA_DEV int silk_find_LPC_dev(XA x, XE e, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, int order, int useInterpolatedNLSFs,
-                             int first_frame_after_reset, const i16 *prev_NLSFq_Q15, i16 *NLSF_Q15)
+CA_DEV int silk_find_LPC_order_dev(XA x, XE e, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, const int order, int useInterpolatedNLSFs,
+                                   int first_frame_after_reset, const i16 *prev_NLSFq_Q15, i16 *NLSF_Q15)
 {
     const int subfr_length = subfr_length_enc + order;
     int interp = 4;
@@ -387,6 +387,18 @@ CA_DEV int silk_find_LPC_dev(XA x, XE e, i32 minInvGain_Q30, int subfr_length_en
     }
     if (interp == 4) silk_A2NLSF_dev(NLSF_Q15, a_Q16, order);
     return interp;
+}
+
+// The two LPC orders of the format as two instances of the inlined body (order a constant: the coefficient loops of Burg, A2NLSF,
+// NLSF2A and the stabilisers unroll and their small arrays are registers).
+template <class XA, class XE>
+CA_DEV int silk_find_LPC_dev(XA x, XE e, i32 minInvGain_Q30, int subfr_length_enc, int nb_subfr, int order, int useInterpolatedNLSFs,
+                             int first_frame_after_reset, const i16 *prev_NLSFq_Q15, i16 *NLSF_Q15)
+{
+    if (order == 16)
+        return silk_find_LPC_order_dev(x, e, minInvGain_Q30, subfr_length_enc, nb_subfr, 16, useInterpolatedNLSFs, first_frame_after_reset, prev_NLSFq_Q15, NLSF_Q15);
+    return silk_find_LPC_order_dev(x, e, minInvGain_Q30, subfr_length_enc, nb_subfr, order == 10 ? 10 : order, useInterpolatedNLSFs, first_frame_after_reset,
+                                   prev_NLSFq_Q15, NLSF_Q15);
 }
 
 template <class XA>

@@ -142,6 +142,7 @@ CA_DEV void silk_NLSF_VQ_weights_laroia_dev(i16 *W, const i16 *NLSF_Q15, int D) 
     i32 tmp1 = one / imax(NLSF_Q15[0], 1);
     i32 tmp2 = one / imax(NLSF_Q15[1] - NLSF_Q15[0], 1);
     W[0] = (i16)imin(tmp1 + tmp2, 32767);
+#pragma unroll
     for (int k = 1; k < D - 1; k += 2) {
         tmp1 = one / imax(NLSF_Q15[k + 1] - NLSF_Q15[k], 1);
         W[k] = (i16)imin(tmp1 + tmp2, 32767);
@@ -182,6 +183,7 @@ CA_DEV void silk_insertion_sort_increasing_dev(i32 *a, int *idx, int L, int K)
 CA_DEV void silk_NLSF_unpack_dev(i16 *ec_ix, u8 *pred_Q8, const NlsfCB &cb, int CB1_index)   // NLSF_unpack.c:35-55
 {
     const u8 *ec_sel_ptr = &cb.ec_sel[CB1_index * cb.order / 2];
+#pragma unroll
     for (int i = 0; i < cb.order; i += 2) {
         const int entry = *ec_sel_ptr++;
         ec_ix[i] = (i16)(((entry >> 1) & 7) * (2 * NLSF_MAX_AMP + 1));
@@ -397,8 +399,10 @@ CA_DEV i32 silk_NLSF_encode_dev(TM &T, i8 *NLSFIndices, i16 *pNLSF_Q15, const Nl
         u8 pred_Q8[SILK_MAX_LPC];
         i8 path[SILK_MAX_LPC];
         const u8 *pCB_element = &cb.CB1_Q8[ind1 * cb.order];
+#pragma unroll
         for (int i = 0; i < cb.order; i++) NLSF_tmp_Q15[i] = (i16)((i32)pCB_element[i] << 7);
         silk_NLSF_VQ_weights_laroia_dev(W_tmp_QW, NLSF_tmp_Q15, cb.order);
+#pragma unroll
         for (int i = 0; i < cb.order; i++) {
             const i32 res_Q15 = (i16)(pNLSF_Q15[i] - NLSF_tmp_Q15[i]);
             const i32 W_tmp_Q9 = s_sqrt_approx((i32)W_tmp_QW[i] << (18 - NLSF_W_Q));
@@ -427,9 +431,9 @@ CA_DEV i32 silk_NLSF_encode_dev(TM &T, i8 *NLSFIndices, i16 *pNLSF_Q15, const Nl
 // silk_process_NLSFs (process_NLSFs.c:35-106). pNLSF_Q15: in = silk_find_LPC_FIX's NLSFs, out = the quantised ones.
 // T: the trellis' survivor state (NlsfTrellisLocal / NlsfTrellisCol above).
 template <class TM>
-CA_DEV void silk_process_NLSFs_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
-                                   int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
-                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
+CA_DEV void silk_process_NLSFs_order_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
+                                         int speech_activity_Q8, int nb_subfr, const int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
+                                         int nSurvivors, int signalType, const NlsfTablesLds *tables)
 {
     const NlsfCB cb = nlsf_codebook(order, tables);
     i16 pNLSF0_temp_Q15[SILK_MAX_LPC], pNLSFW_QW[SILK_MAX_LPC], pNLSFW0_temp_QW[SILK_MAX_LPC];
@@ -453,6 +457,22 @@ CA_DEV void silk_process_NLSFs_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 
     } else {
         for (int i = 0; i < order; i++) PredCoef_Q12[0][i] = PredCoef_Q12[1][i];
     }
+}
+
+// The two LPC orders of the format (16 wideband, 10 narrow / medium band) as two instances of the inlined body: with the order a
+// constant the per-coefficient loops unroll and the small per-survivor arrays they fill (residuals, weights, entropy-table
+// offsets, predictor taps) are registers instead of run-time-indexed private memory.
+template <class TM>
+CA_DEV void silk_process_NLSFs_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
+                                   int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
+                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
+{
+    if (order == 16)
+        silk_process_NLSFs_order_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, 16, useInterpolatedNLSFs,
+                                     NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
+    else
+        silk_process_NLSFs_order_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, 10, useInterpolatedNLSFs,
+                                     NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
 }
 
 CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
