@@ -487,6 +487,22 @@ struct PitchOut {                                       // what it writes beside
     int pitchL[4], lagIndex, contourIndex, LTPCorr_Q15, signalType, predGain_Q16;
 };
 
+// find_pitch_lags_FIX.c:83-103: reflection coefficients, prediction gain, bandwidth-expanded whitening filter from the autocorrelation
+CA_DEV i32 pitch_whitening_filter_dev(i16 *A_Q12, const i32 *auto_corr, const int order)
+{
+    i32 A_Q24[SILK_MAX_LPC];
+    i16 rc_Q15[SILK_MAX_LPC];
+    const i32 res_nrg = silk_schur_dev(rc_Q15, auto_corr, order);
+    const i32 predGain_Q16 = s_div32_varq(auto_corr[0], imax(res_nrg, 1), 16);
+    silk_k2a_dev(A_Q24, rc_Q15, order);
+    for (int i = 0; i < order; i++) {
+        const i32 v = A_Q24[i] >> 12;
+        A_Q12[i] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+    }
+    silk_bwexpander_dev(A_Q12, order, 64881);                                               // FIND_PITCH_BANDWIDTH_EXPANSION Q16
+    return predGain_Q16;
+}
+
 // x_buf: index 0 = x - ltp_mem_length (buf_len samples); res: buf_len samples out (read back by the estimator); ws / xs / scr:
 // scratch of pitch_LPC_win_length, pitch_LPC_win_length and (20 + 5 nb_subfr) fs_kHz samples in the caller's storage.
 template <class XG, class RES, class SCR>
@@ -498,18 +514,16 @@ CA_DEV void silk_find_pitch_lags_dev(const PitchCfg &c, XG x_buf, RES res, SCR w
     const int mid = W - (c.la_pitch << 1);
     for (int i = 0; i < mid; i++) ws[c.la_pitch + i] = (i16)(i32)xw[c.la_pitch + i];
     silk_apply_sine_window_dev(ws + (c.la_pitch + mid), xw + (c.la_pitch + mid), 2, c.la_pitch);
-    i32 auto_corr[SILK_MAX_LPC + 1], A_Q24[SILK_MAX_LPC];
-    i16 rc_Q15[SILK_MAX_LPC], A_Q12[SILK_MAX_LPC];
+    i32 auto_corr[SILK_MAX_LPC + 1];
+    i16 A_Q12[SILK_MAX_LPC];
     (void)silk_autocorr_dev(auto_corr, ws, xs, W, order + 1);
     auto_corr[0] = s_addw(s_smlawb(auto_corr[0], auto_corr[0], 66), 1);
-    const i32 res_nrg = silk_schur_dev(rc_Q15, auto_corr, order);
-    o.predGain_Q16 = s_div32_varq(auto_corr[0], imax(res_nrg, 1), 16);
-    silk_k2a_dev(A_Q24, rc_Q15, order);
-    for (int i = 0; i < order; i++) {
-        const i32 v = A_Q24[i] >> 12;
-        A_Q12[i] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
-    }
-    silk_bwexpander_dev(A_Q12, order, 64881);                                               // FIND_PITCH_BANDWIDTH_EXPANSION Q16
+    // the orders the complexity settings use (control_codec.c:333-404) as constants: Schur / k2a / bandwidth expansion unrolled, in registers
+    if (order == 16) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 16);
+    else if (order == 12) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 12);
+    else if (order == 10) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 10);
+    else if (order == 8) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 8);
+    else o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, order);
     silk_LPC_analysis_filter_dev(res, x_buf, A_Q12, buf_len, order);
     o.signalType = c.signalType;
     o.LTPCorr_Q15 = c.LTPCorr_Q15;

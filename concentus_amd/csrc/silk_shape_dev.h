@@ -280,9 +280,8 @@ struct ShapeOut {                                       // what it writes (psEnc
 // x: index 0 = the reference's x[0] (frame start; indices from -la_shape); pitch_res: the frame's LPC residual; xw / xs: two
 // scratch arrays of shapeWinLength samples in the caller's fast storage.
 template <class XG, class SCR>
-CA_DEV void silk_noise_shape_analysis_dev(const ShapeCfg &c, XG pitch_res, XG x, SCR xw, SCR xs, ShapeOut &o)
+CA_DEV void silk_noise_shape_analysis_order_dev(const ShapeCfg &c, XG pitch_res, XG x, SCR xw, SCR xs, ShapeOut &o, const int order)
 {
-    const int order = c.shapingLPCOrder;
     i32 SNR_adj_dB_Q7 = c.SNR_dB_Q7;
     o.input_quality_Q14 = ((i32)c.input_quality_bands_Q15[0] + c.input_quality_bands_Q15[1]) >> 2;
     o.coding_quality_Q14 = silk_sigm_Q15_dev(s_rshift_round(SNR_adj_dB_Q7 - 2560, 4)) >> 1;
@@ -410,6 +409,18 @@ CA_DEV void silk_noise_shape_analysis_dev(const ShapeCfg &c, XG pitch_res, XG x,
         o.HarmShapeGain_Q14[k] = s_rshift_round(o.HarmShapeGain_smth_Q16, 2);
         o.Tilt_Q14[k] = s_rshift_round(o.Tilt_smth_Q16, 2);
     }
+}
+
+// The shaping orders the encoder's complexity settings use (control_codec.c:333-404: 16, 14, 12; 10 / 8 at the lowest settings go
+// through the generic instance) as separate instances of the inlined body: with the order a constant the coefficient loops of the
+// autocorrelation, Schur, k2a, bandwidth expansion and coefficient limiting unroll and their arrays are registers.
+template <class XG, class SCR>
+CA_DEV void silk_noise_shape_analysis_dev(const ShapeCfg &c, XG pitch_res, XG x, SCR xw, SCR xs, ShapeOut &o)
+{
+    if (c.shapingLPCOrder == 16) silk_noise_shape_analysis_order_dev(c, pitch_res, x, xw, xs, o, 16);
+    else if (c.shapingLPCOrder == 14) silk_noise_shape_analysis_order_dev(c, pitch_res, x, xw, xs, o, 14);
+    else if (c.shapingLPCOrder == 12) silk_noise_shape_analysis_order_dev(c, pitch_res, x, xw, xs, o, 12);
+    else silk_noise_shape_analysis_order_dev(c, pitch_res, x, xw, xs, o, c.shapingLPCOrder);
 }
 
 }  // namespace ca
