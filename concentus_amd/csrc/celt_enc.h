@@ -248,7 +248,9 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     (void)stage_clock;
     if (lane() == 0) F.diag = (void *)stage_clock;
     wave_sync();
-    const int C = cfg.channels, N = FRAME, LM = LM3, M = M8, end = NB;
+    // stereo is the only channel count the entry points admit (config_ok): a constant, so that the channel loops unroll
+    const int C = 2, N = FRAME, LM = LM3, M = M8, end = NB;
+    (void)cfg.channels;
     FrameCtx fc;
     RangeEnc enc;
     int max_data_bytes, nbCompressedBytes, nbAvailableBytes, effectiveBytes, silence, pitch_index, pf_on, prefilter_tapset;
@@ -547,7 +549,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
 {
     (void)stage_clock;
     if (lane() == 0) F.diag = (void *)stage_clock;
-    const int C = cfg.channels, LM = LM3, end = NB;
+    const int C = 2, LM = LM3, end = NB;                                           // stereo only (config_ok): a constant
     const int celt_vbr = cfg.vbr, constrained_vbr = cfg.constrained_vbr;
     const int nbFilledBytes = 0;
     FrameCtx fc;
