@@ -162,8 +162,8 @@ CA_DEV void pe_calc_corr_energy_st3(i32 *corr /*[4][PE_SCRATCH_SIZE]*/, i32 *nrg
 // pitch_analysis_core_FIX.c:86-581; returns 0 voiced / 1 unvoiced. `scr`: frame_length samples of scratch for the down-shifted
 // copy of the input that stage 3 may need.
 template <class XA, class SCR>
-CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *lagIndex, int *contourIndex, int *LTPCorr_Q15, int prevLag,
-                                        i32 search_thres1_Q16, int search_thres2_Q13, int Fs_kHz, int complexity, int nb_subfr)
+CA_DEV int silk_pitch_analysis_core_geom_dev(XA frame, SCR scr, int *pitch_out, int *lagIndex, int *contourIndex, int *LTPCorr_Q15, int prevLag,
+                                             i32 search_thres1_Q16, int search_thres2_Q13, const int Fs_kHz, int complexity, const int nb_subfr)
 {
     const int frame_length = (PE_LTP_MEM_LENGTH_MS + nb_subfr * PE_SUBFR_LENGTH_MS) * Fs_kHz;
     const int frame_length_4kHz = (PE_LTP_MEM_LENGTH_MS + nb_subfr * PE_SUBFR_LENGTH_MS) * 4;
@@ -454,6 +454,19 @@ CA_DEV void silk_bwexpander_dev(i16 *ar, int d, i32 chirp_Q16)                  
         chirp_Q16 += s_rshift_round(s_mulw(chirp_Q16, chirp_minus_one_Q16), 16);
     }
     ar[d - 1] = (i16)s_rshift_round(s_mulw(chirp_Q16, ar[d - 1]), 16);
+}
+
+// The usual geometries (16 kHz and 8 kHz input, 20 ms frames) as instances of the inlined body with the sampling rate and the subframe
+// count constant (lengths, lag ranges and the subframe loops become constants); anything else through the generic instance.
+template <class XA, class SCR>
+CA_DEV int silk_pitch_analysis_core_dev(XA frame, SCR scr, int *pitch_out, int *lagIndex, int *contourIndex, int *LTPCorr_Q15, int prevLag,
+                                        i32 search_thres1_Q16, int search_thres2_Q13, int Fs_kHz, int complexity, int nb_subfr)
+{
+    if (Fs_kHz == 16 && nb_subfr == 4)
+        return silk_pitch_analysis_core_geom_dev(frame, scr, pitch_out, lagIndex, contourIndex, LTPCorr_Q15, prevLag, search_thres1_Q16, search_thres2_Q13, 16, complexity, 4);
+    if (Fs_kHz == 8 && nb_subfr == 4)
+        return silk_pitch_analysis_core_geom_dev(frame, scr, pitch_out, lagIndex, contourIndex, LTPCorr_Q15, prevLag, search_thres1_Q16, search_thres2_Q13, 8, complexity, 4);
+    return silk_pitch_analysis_core_geom_dev(frame, scr, pitch_out, lagIndex, contourIndex, LTPCorr_Q15, prevLag, search_thres1_Q16, search_thres2_Q13, Fs_kHz, complexity, nb_subfr);
 }
 
 // LPC_analysis_filter.c:41-108, FIXED_POINT branch: out[0 .. d) = 0, out[ix] = SAT16(in[ix] + PSHR32(sum_m (-B[m]) * in[ix - 1 - m], 12))
