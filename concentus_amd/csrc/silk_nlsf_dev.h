@@ -234,107 +234,131 @@ struct NlsfTrellisCol {
     }
 };
 
+// element idx (run-time, 0 .. 3) of a four-entry register array: compare chains instead of memory
+CA_DEV i32 nlsf_get4(const i32 *a, int idx) { return idx == 0 ? a[0] : idx == 1 ? a[1] : idx == 2 ? a[2] : a[3]; }
+CA_DEV void nlsf_set4(i32 *a, int idx, i32 v) { a[0] = idx == 0 ? v : a[0]; a[1] = idx == 1 ? v : a[1]; a[2] = idx == 2 ? v : a[2]; a[3] = idx == 3 ? v : a[3]; }
+
+// One coefficient of the trellis with NS (1, 2 or 4: a compile-time constant) live states: every index into the rate-distortion
+// values / previous outputs is then a constant and the two arrays are registers; only the index paths (T.ind: addressed by
+// coefficient and, in the survivor exchange, by run-time state) stay in the trellis memory.
+template <int NS, class TM>
+CA_DEV void nlsf_trellis_step(TM &T, i32 *RD /*[8]*/, i32 *po /*[8]*/, const int i, const int order, const bool last, const int in_Q10, const i32 w_Q5i,
+                              const i32 pred_coef_Q16, const u8 *rates_Q5, const int quant_step_size_Q16, const i32 inv_quant_step_size_Q6,
+                              const i32 mu_Q20)
+{
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+        const int pred_Q10 = s_smulwb(pred_coef_Q16, po[j]);
+        const int res_Q10 = in_Q10 - pred_Q10;
+        int ind_tmp = s_smulwb(inv_quant_step_size_Q6, res_Q10);
+        ind_tmp = s_limit(ind_tmp, -NLSF_MAX_AMP_EXT, NLSF_MAX_AMP_EXT - 1);
+        T.ind(j, i) = (i8)ind_tmp;
+        // out0 / out1: the two reconstruction levels around the residual (the reference tabulates them per call, :61-79)
+        int out0_Q10 = shl32(ind_tmp, 10), out1_Q10 = out0_Q10 + 1024;
+        if (ind_tmp > 0) { out0_Q10 -= NLSF_LEVEL_ADJ_Q10; out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
+        else if (ind_tmp == 0) { out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
+        else if (ind_tmp == -1) { out0_Q10 += NLSF_LEVEL_ADJ_Q10; }
+        else { out0_Q10 += NLSF_LEVEL_ADJ_Q10; out1_Q10 += NLSF_LEVEL_ADJ_Q10; }
+        out0_Q10 = s_smulwb(out0_Q10, quant_step_size_Q16) + pred_Q10;
+        out1_Q10 = s_smulwb(out1_Q10, quant_step_size_Q16) + pred_Q10;
+        po[j] = (i16)out0_Q10;
+        po[j + NS] = (i16)out1_Q10;
+        int rate0_Q5, rate1_Q5;
+        if (ind_tmp + 1 >= NLSF_MAX_AMP) {
+            if (ind_tmp + 1 == NLSF_MAX_AMP) {
+                rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
+                rate1_Q5 = 280;
+            } else {
+                rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(43, ind_tmp);
+                rate1_Q5 = rate0_Q5 + 43;
+            }
+        } else if (ind_tmp <= -NLSF_MAX_AMP) {
+            if (ind_tmp == -NLSF_MAX_AMP) {
+                rate0_Q5 = 280;
+                rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
+            } else {
+                rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(-43, ind_tmp);
+                rate1_Q5 = rate0_Q5 - 43;
+            }
+        } else {
+            rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
+            rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
+        }
+        const i32 RD_tmp = RD[j];
+        int diff_Q10 = in_Q10 - out0_Q10;
+        RD[j] = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)w_Q5i)), s_smulbb(mu_Q20, rate0_Q5));
+        diff_Q10 = in_Q10 - out1_Q10;
+        RD[j + NS] = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)w_Q5i)), s_smulbb(mu_Q20, rate1_Q5));
+    }
+    if (NS <= (NLSF_DD_STATES >> 1)) {                                                      // the states double (:136-145)
+#pragma unroll
+        for (int j = 0; j < NS; j++) T.ind(j + NS, i) = (i8)(T.ind(j, i) + 1);
+#pragma unroll
+        for (int j = 2 * NS; j < NLSF_DD_STATES; j++) T.ind(j, i) = T.ind(j - 2 * NS, i);
+    } else if (!last) {                                                                     // keep the best four of the eight (:146-199)
+        i32 RD_min[NLSF_DD_STATES], RD_max[NLSF_DD_STATES], srt[NLSF_DD_STATES];
+#pragma unroll
+        for (int j = 0; j < NLSF_DD_STATES; j++) {
+            if (RD[j] > RD[j + NLSF_DD_STATES]) {
+                RD_max[j] = RD[j];
+                RD_min[j] = RD[j + NLSF_DD_STATES];
+                RD[j] = RD_min[j];
+                RD[j + NLSF_DD_STATES] = RD_max[j];
+                const i32 t = po[j];
+                po[j] = po[j + NLSF_DD_STATES];
+                po[j + NLSF_DD_STATES] = t;
+                srt[j] = j + NLSF_DD_STATES;
+            } else {
+                RD_min[j] = RD[j];
+                RD_max[j] = RD[j + NLSF_DD_STATES];
+                srt[j] = j;
+            }
+        }
+        while (1) {
+            i32 min_max = 0x7FFFFFFF, max_min = 0;
+            int ind_min_max = 0, ind_max_min = 0;
+#pragma unroll
+            for (int j = 0; j < NLSF_DD_STATES; j++) {
+                if (min_max > RD_max[j]) { min_max = RD_max[j]; ind_min_max = j; }
+                if (max_min < RD_min[j]) { max_min = RD_min[j]; ind_max_min = j; }
+            }
+            if (min_max >= max_min) break;
+            nlsf_set4(srt, ind_max_min, nlsf_get4(srt, ind_min_max) ^ NLSF_DD_STATES);
+            nlsf_set4(RD, ind_max_min, nlsf_get4(RD + NLSF_DD_STATES, ind_min_max));
+            nlsf_set4(po, ind_max_min, nlsf_get4(po + NLSF_DD_STATES, ind_min_max));
+            nlsf_set4(RD_min, ind_max_min, 0);
+            nlsf_set4(RD_max, ind_min_max, 0x7FFFFFFF);
+            for (int k = i; k < order; k++) T.ind(ind_max_min, k) = T.ind(ind_min_max, k);
+        }
+#pragma unroll
+        for (int j = 0; j < NLSF_DD_STATES; j++) T.ind(j, i) = (i8)(T.ind(j, i) + (srt[j] >> NLSF_DD_STATES_LOG2));
+    }
+}
+
 template <class TM>
 CA_DEV i32 silk_NLSF_del_dec_quant_dev(TM &T, i8 *indices, const i16 *x_Q10, const i16 *w_Q5, const u8 *pred_coef_Q8, const i16 *ec_ix,
                                        const u8 *ec_rates_Q5, int quant_step_size_Q16, i32 inv_quant_step_size_Q6, i32 mu_Q20, int order)
 {
-    int nStates = 1;
-    T.RD(0) = 0;
-    T.prev_out(0) = 0;
-    for (int i = order - 1;; i--) {
+    i32 RD[2 * NLSF_DD_STATES], po[2 * NLSF_DD_STATES];
+#pragma unroll
+    for (int j = 0; j < 2 * NLSF_DD_STATES; j++) { RD[j] = 0; po[j] = 0; }
+    for (int i = order - 1; i >= 0; i--) {
         const u8 *rates_Q5 = &ec_rates_Q5[ec_ix[i]];
         const i32 pred_coef_Q16 = (i32)pred_coef_Q8[i] << 8;
         const int in_Q10 = x_Q10[i];
-        for (int j = 0; j < nStates; j++) {
-            const int pred_Q10 = s_smulwb(pred_coef_Q16, T.prev_out(j));
-            const int res_Q10 = in_Q10 - pred_Q10;
-            int ind_tmp = s_smulwb(inv_quant_step_size_Q6, res_Q10);
-            ind_tmp = s_limit(ind_tmp, -NLSF_MAX_AMP_EXT, NLSF_MAX_AMP_EXT - 1);
-            T.ind(j, i) = (i8)ind_tmp;
-            // out0 / out1: the two reconstruction levels around the residual (the reference tabulates them per call, :61-79)
-            int out0_Q10 = shl32(ind_tmp, 10), out1_Q10 = out0_Q10 + 1024;
-            if (ind_tmp > 0) { out0_Q10 -= NLSF_LEVEL_ADJ_Q10; out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
-            else if (ind_tmp == 0) { out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
-            else if (ind_tmp == -1) { out0_Q10 += NLSF_LEVEL_ADJ_Q10; }
-            else { out0_Q10 += NLSF_LEVEL_ADJ_Q10; out1_Q10 += NLSF_LEVEL_ADJ_Q10; }
-            out0_Q10 = s_smulwb(out0_Q10, quant_step_size_Q16) + pred_Q10;
-            out1_Q10 = s_smulwb(out1_Q10, quant_step_size_Q16) + pred_Q10;
-            T.prev_out(j) = (i16)out0_Q10;
-            T.prev_out(j + nStates) = (i16)out1_Q10;
-            int rate0_Q5, rate1_Q5;
-            if (ind_tmp + 1 >= NLSF_MAX_AMP) {
-                if (ind_tmp + 1 == NLSF_MAX_AMP) {
-                    rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
-                    rate1_Q5 = 280;
-                } else {
-                    rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(43, ind_tmp);
-                    rate1_Q5 = rate0_Q5 + 43;
-                }
-            } else if (ind_tmp <= -NLSF_MAX_AMP) {
-                if (ind_tmp == -NLSF_MAX_AMP) {
-                    rate0_Q5 = 280;
-                    rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
-                } else {
-                    rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(-43, ind_tmp);
-                    rate1_Q5 = rate0_Q5 - 43;
-                }
-            } else {
-                rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
-                rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
-            }
-            const i32 RD_tmp = T.RD(j);
-            int diff_Q10 = in_Q10 - out0_Q10;
-            T.RD(j) = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate0_Q5));
-            diff_Q10 = in_Q10 - out1_Q10;
-            T.RD(j + nStates) = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)(i32)w_Q5[i])), s_smulbb(mu_Q20, rate1_Q5));
-        }
-        if (nStates <= (NLSF_DD_STATES >> 1)) {
-            for (int j = 0; j < nStates; j++) T.ind(j + nStates, i) = (i8)(T.ind(j, i) + 1);
-            nStates <<= 1;
-            for (int j = nStates; j < NLSF_DD_STATES; j++) T.ind(j, i) = T.ind(j - nStates, i);
-        } else if (i > 0) {
-            for (int j = 0; j < NLSF_DD_STATES; j++) {
-                if (T.RD(j) > T.RD(j + NLSF_DD_STATES)) {
-                    T.RD_max(j) = T.RD(j);
-                    T.RD_min(j) = T.RD(j + NLSF_DD_STATES);
-                    T.RD(j) = T.RD_min(j);
-                    T.RD(j + NLSF_DD_STATES) = T.RD_max(j);
-                    const i16 t = T.prev_out(j);
-                    T.prev_out(j) = T.prev_out(j + NLSF_DD_STATES);
-                    T.prev_out(j + NLSF_DD_STATES) = t;
-                    T.sort(j) = j + NLSF_DD_STATES;
-                } else {
-                    T.RD_min(j) = T.RD(j);
-                    T.RD_max(j) = T.RD(j + NLSF_DD_STATES);
-                    T.sort(j) = j;
-                }
-            }
-            while (1) {
-                i32 min_max = 0x7FFFFFFF, max_min = 0;
-                int ind_min_max = 0, ind_max_min = 0;
-                for (int j = 0; j < NLSF_DD_STATES; j++) {
-                    if (min_max > T.RD_max(j)) { min_max = T.RD_max(j); ind_min_max = j; }
-                    if (max_min < T.RD_min(j)) { max_min = T.RD_min(j); ind_max_min = j; }
-                }
-                if (min_max >= max_min) break;
-                T.sort(ind_max_min) = T.sort(ind_min_max) ^ NLSF_DD_STATES;
-                T.RD(ind_max_min) = T.RD(ind_min_max + NLSF_DD_STATES);
-                T.prev_out(ind_max_min) = T.prev_out(ind_min_max + NLSF_DD_STATES);
-                T.RD_min(ind_max_min) = 0;
-                T.RD_max(ind_min_max) = 0x7FFFFFFF;
-                for (int k = i; k < order; k++) T.ind(ind_max_min, k) = T.ind(ind_min_max, k);
-            }
-            for (int j = 0; j < NLSF_DD_STATES; j++) T.ind(j, i) = (i8)(T.ind(j, i) + (T.sort(j) >> NLSF_DD_STATES_LOG2));
-        } else {
-            break;
-        }
+        const i32 w = (i32)w_Q5[i];
+        // one state at the last coefficient, two at the one before, four from there on (NLSF_DD_STATES = 4; order >= 3)
+        if (i == order - 1) nlsf_trellis_step<1>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
+        else if (i == order - 2) nlsf_trellis_step<2>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
+        else nlsf_trellis_step<4>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
     }
     int ind_tmp = 0;
     i32 min_Q25 = 0x7FFFFFFF;
+#pragma unroll
     for (int j = 0; j < 2 * NLSF_DD_STATES; j++) {
-        if (min_Q25 > T.RD(j)) { min_Q25 = T.RD(j); ind_tmp = j; }
+        if (min_Q25 > RD[j]) { min_Q25 = RD[j]; ind_tmp = j; }
     }
-    for (int j = 0; j < order; j++) indices[j] = T.ind(ind_tmp & (NLSF_DD_STATES - 1), j);
+    for (int j = 0; j < order; j++) indices[j] = (i8)T.ind(ind_tmp & (NLSF_DD_STATES - 1), j);
     indices[0] = (i8)(indices[0] + (ind_tmp >> NLSF_DD_STATES_LOG2));
     return min_Q25;
 }
