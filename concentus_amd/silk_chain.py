@@ -4,16 +4,25 @@
         -> silk_prefilter_FIX -> silk_NSQ / silk_NSQ_del_dec -> silk_encode_indices + silk_encode_pulses
 
 i.e. what silk_encode_frame_FIX (opus-fix/silk/fixed/encode_frame_FIX.c:176-317) runs between the VAD and the range coder for
-the first pass of a frame. Every stage is one batched kernel of libopusgpu.so driven from a flat record; this module is the
-host-side plumbing a batched SILK front end needs between them: after each stage it moves the fields the next records take
-from it -- byte ranges of device tensors, no arithmetic -- exactly along the edges that tests/test_silk_chain_cpu.py pins
-against the unmodified reference. What the caller provides per frame are the records' remaining fields: the input buffer,
-the VAD results, the configuration and the states the previous frame left behind.
+the first pass of a frame, and the bitrate loop around quantiser and coder (:263-423) on top of it. The first pass is ONE call of the
+C ABI, opusgpu_silk_encode_frames_batch (concentus_amd/csrc/silk_chain.hip): the eight batched kernels back to back and, between
+them, small kernels that complete the next records from the outputs of the earlier stages -- field to field, no arithmetic, exactly
+along the edges that tests/test_silk_chain_cpu.py pins against the unmodified reference. What the caller provides per frame are the
+records' remaining fields: the input buffer, the VAD results, the configuration and the states the previous frame left behind. The
+loop (run(..., rate_ctl=...)) is host-side plumbing over opusgpu_silk_rate_control_batch: gather the frames that ask for another
+pass, quantise + code them again from their entry states, scatter them back.
 
 Geometry is fixed per chain object (all frames of a batch share fs_kHz / nb_subfr, as one encoder configuration does)."""
 import ctypes as C
 
 from . import silk as S
+
+
+class ChainBufs(C.Structure):
+    """opusgpu_silk_chain_bufs (include/opusgpu_silk.h): device pointers to the n records of every stage."""
+    _fields_ = [(k, C.c_void_p) for k in ("pitch_in", "pitch_out", "shape_in", "shape_out", "fpc_in", "fpc_out", "gains_in", "gains_out",
+                                          "prefilter_in", "prefilter_state", "prefilter_out", "q_in", "nsq_state", "q_out", "bits_in", "ec_state",
+                                          "bits_out", "workspace")] + [("workspace_bytes", C.c_size_t)]
 
 
 def _off(cls, name):
@@ -59,74 +68,44 @@ class SilkAnalysisChain:
         leaves them, rate_ctl holds LastGainIndex, GainsIndices and the number of passes. Returns a dict of the stage outputs;
         "pulses" is int8 [N][320] (and "Seed" int32 [N] for the delayed-decision quantiser)."""
         import torch
-        mv, fl, ltp = self._move, self.frame_length, self.ltp_mem_length
-        PO, SI, SO, FI, FO, GI, GO, XI, XO, Q = (S.FindPitchLagsOut, S.NoiseShapeIn, S.NoiseShapeOut, S.FindPredCoefsIn, S.FindPredCoefsOut,
-                                                 S.ProcessGainsIn, S.ProcessGainsOut, S.PrefilterIn, S.PrefilterOut, S.NsqIn)
-        pitch_out = S.silk_find_pitch_lags(pitch_in)
-        # noise_shape_analysis <- find_pitch_lags
-        mv(shape_in, SI, "pitch_res", pitch_out, PO, "res", nbytes=2 * fl, src_skip=2 * ltp)
-        for name in ("signalType", "LTPCorr_Q15", "predGain_Q16", "pitchL"):
-            mv(shape_in, SI, name, pitch_out, PO, name)
-        shape_out = S.silk_noise_shape_analysis(shape_in)
-        # find_pred_coefs <- find_pitch_lags, noise_shape_analysis
-        mv(fpc_in, FI, "res_pitch", pitch_out, PO, "res", nbytes=2 * (ltp + fl))
-        mv(fpc_in, FI, "pitchL", pitch_out, PO, "pitchL")
-        mv(fpc_in, FI, "signalType", pitch_out, PO, "signalType")
-        mv(fpc_in, FI, "Gains_Q16", shape_out, SO, "Gains_Q16")
-        mv(fpc_in, FI, "coding_quality_Q14", shape_out, SO, "coding_quality_Q14")
-        fpc_out = S.silk_find_pred_coefs(fpc_in)
-        # process_gains <- noise_shape_analysis, find_pred_coefs
-        mv(gains_in, GI, "Gains_Q16", shape_out, SO, "Gains_Q16")
-        for name in ("ResNrg", "ResNrgQ", "LTPredCodGain_Q7"):
-            mv(gains_in, GI, name, fpc_out, FO, name)
-        for name in ("quantOffsetType", "input_quality_Q14", "coding_quality_Q14"):
-            mv(gains_in, GI, name, shape_out, SO, name)
-        mv(gains_in, GI, "signalType", pitch_out, PO, "signalType")
-        gains_out = S.silk_process_gains(gains_in)
-        # prefilter <- noise_shape_analysis, find_pitch_lags
-        for name in ("AR1_Q13", "HarmShapeGain_Q14", "HarmBoost_Q14", "Tilt_Q14", "GainsPre_Q14", "LF_shp_Q14", "coding_quality_Q14"):
-            mv(prefilter_in, XI, name, shape_out, SO, name)
-        mv(prefilter_in, XI, "pitchL", pitch_out, PO, "pitchL")
-        mv(prefilter_in, XI, "signalType", pitch_out, PO, "signalType")
-        prefilter_out = S.silk_prefilter(prefilter_in, prefilter_state)
-        # quantiser <- everything before (opusgpu_nsq_dd_in starts with an opusgpu_nsq_in)
-        mv(q_in, Q, "x_Q3", prefilter_out, XO, "xw_Q3")
-        for name in ("PredCoef_Q12", "LTPCoef_Q14", "LTP_scale_Q14"):
-            mv(q_in, Q, name, fpc_out, FO, name)
-        self._move_i8_to_i32(q_in, Q, "NLSFInterpCoef_Q2", fpc_out, FO, "NLSFInterpCoef_Q2")
-        for name in ("AR2_Q13", "HarmShapeGain_Q14", "Tilt_Q14", "LF_shp_Q14"):
-            mv(q_in, Q, name, shape_out, SO, name)
-        for name in ("Gains_Q16", "Lambda_Q10", "quantOffsetType"):
-            mv(q_in, Q, name, gains_out, GO, name)
-        mv(q_in, Q, "pitchL", pitch_out, PO, "pitchL")
-        mv(q_in, Q, "signalType", pitch_out, PO, "signalType")
-        out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out}
+        from . import lib as _lib
+        mv = self._move
+        GO = S.ProcessGainsOut
+        n, dev = pitch_in.shape[0], pitch_in.device
+        recs = (("pitch_in", pitch_in, "find_pitch_lags_in"), ("shape_in", shape_in, "noise_shape_in"), ("fpc_in", fpc_in, "find_pred_coefs_in"),
+                ("gains_in", gains_in, "process_gains_in"), ("prefilter_in", prefilter_in, "prefilter_in"),
+                ("prefilter_state", prefilter_state, "prefilter_state"), ("q_in", q_in, "nsq_dd_in" if del_dec else "nsq_in"),
+                ("nsq_state", nsq_state, "nsq_state")) + ((("bits_in", bits_in, "silk_bits_in"), ("ec_state", ec_state, "ec_state")) if bits_in is not None else ())
+        for name, t, size in recs:
+            S._check(t, S.SIZES[size], name)
+            if t.shape[0] != n:
+                raise ValueError("%s: %d records for %d frames" % (name, t.shape[0], n))
         if rate_ctl is not None:
             if bits_in is None or ec_state is None:
                 raise ValueError("rate_ctl needs bits_in and ec_state: the loop measures the coder")
             nsq_entry, ec_entry = nsq_state.clone(), ec_state.clone()       # sNSQ_copy / sRangeEnc_copy (encode_frame_FIX.c:272-273)
+
+        def new(size, zero=False):
+            return (torch.zeros if zero else torch.empty)((n, S.SIZES[size]), dtype=torch.uint8, device=dev)
+        pitch_out, shape_out, fpc_out, gains_out, prefilter_out = (new(k) for k in ("find_pitch_lags_out", "noise_shape_out", "find_pred_coefs_out",
+                                                                                   "process_gains_out", "prefilter_out"))
+        q_out = new("nsq_dd_out" if del_dec else "nsq_out", zero=True)
+        bits_out = new("silk_bits_out") if bits_in is not None else None
+        L = _lib.load()
+        need = (L.opusgpu_silk_nsq_del_dec_workspace_bytes if del_dec else L.opusgpu_silk_nsq_workspace_bytes)(n)
+        ws = S._scratch(dev, need, "nsq_del_dec" if del_dec else "nsq")
+        # one C call: the eight kernels and the field moves between their records (csrc/silk_chain.hip)
+        bufs = ChainBufs(*[C.c_void_p(t.data_ptr() if t is not None else None) for t in (
+            pitch_in, pitch_out, shape_in, shape_out, fpc_in, fpc_out, gains_in, gains_out, prefilter_in, prefilter_state, prefilter_out,
+            q_in, nsq_state, q_out, bits_in, ec_state if bits_in is not None else None, bits_out, ws)], C.c_size_t(ws.numel()))
+        rc = L.opusgpu_silk_encode_frames_batch(C.byref(bufs), self.fs_kHz, self.nb_subfr, 1 if del_dec else 0, n, _lib.current_stream_handle())
+        _lib.check(rc, "opusgpu_silk_encode_frames_batch")
+        out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out,
+               "pulses": q_out[:, :320].view(torch.int8)}
         if del_dec:
-            dd_out = S.silk_NSQ_del_dec(q_in, nsq_state)
-            out["pulses"] = dd_out[:, :320].view(torch.int8)
-            out["Seed"] = dd_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
-        else:
-            out["pulses"] = S.silk_NSQ(q_in, nsq_state)
+            out["Seed"] = q_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
         if bits_in is not None:
-            B, i8to32 = S.SilkBitsIn, self._move_i8_to_i32
-            do, _ = _off(B, "pulses")
-            bits_in[:, do:do + 320] = out["pulses"].view(torch.uint8)
-            mv(bits_in, B, "GainsIndices", gains_out, GO, "GainsIndices")
-            mv(bits_in, B, "NLSFIndices", fpc_out, FO, "NLSFIndices")
-            mv(bits_in, B, "LTPIndex", fpc_out, FO, "LTPIndex")
-            for name in ("NLSFInterpCoef_Q2", "PERIndex", "LTP_scaleIndex"):
-                i8to32(bits_in, B, name, fpc_out, FO, name)
-            for name in ("lagIndex", "contourIndex", "signalType"):
-                mv(bits_in, B, name, pitch_out, PO, name)
-            mv(bits_in, B, "quantOffsetType", gains_out, GO, "quantOffsetType")
-            if del_dec:                                   # silk_NSQ_del_dec rewrites psIndices->Seed (NSQ_del_dec.c:297)
-                so, _ = _off(B, "Seed")
-                bits_in[:, so:so + 4] = dd_out[:, 320:324]
-            out["bits_out"] = S.silk_encode_bits(bits_in, ec_state)
+            out["bits_out"] = bits_out
         if rate_ctl is not None:
             R = S.RateCtl
             for name in ("GainsUnq_Q16", "Gains_Q16", "lastGainIndexPrev", "LastGainIndex", "Lambda_Q10", "GainsIndices"):

@@ -426,6 +426,31 @@ typedef struct opusgpu_silk_rate_ctl {
 
 int opusgpu_silk_rate_control_batch(opusgpu_silk_rate_ctl *d_ctl, const opusgpu_ec_state *d_ec, int n, void *hip_stream);
 
+/* ---- the first pass of silk_encode_frame_FIX for a batch of frames, one call ------------------------------
+ * silk_find_pitch_lags_FIX -> silk_noise_shape_analysis_FIX -> silk_find_pred_coefs_FIX -> silk_process_gains_FIX ->
+ * silk_prefilter_FIX -> silk_NSQ / silk_NSQ_del_dec -> silk_encode_indices + silk_encode_pulses
+ * (opus-fix/silk/fixed/encode_frame_FIX.c:176-336) over n frames on one stream: the batched entry points above back to back, each
+ * record completed on the device from the outputs of the earlier stages (the fields the reference passes on through psEnc /
+ * psEncCtrl). The caller fills what a frame brings with it -- the pitch buffer, x, the configuration and VAD fields, the states the
+ * previous frame left -- in every *_in record; the fields the chain fills may be left zero (they are listed per record in
+ * concentus_amd/silk_chain.py: CHAIN_FED_FIELDS). All pointers are device pointers to n records; every *_out buffer is written;
+ * prefilter_state / nsq_state / ec_state are updated in place. q_in / q_out: opusgpu_nsq_in / opusgpu_nsq_out records, or
+ * opusgpu_nsq_dd_in / opusgpu_nsq_dd_out when del_dec. bits_in NULL: stop after the quantiser. workspace: the quantiser's scratch
+ * (opusgpu_silk_nsq_workspace_bytes / opusgpu_silk_nsq_del_dec_workspace_bytes). The bitrate loop sits on top of this call:
+ * opusgpu_silk_rate_control_batch after it, then quantiser + coder again on the frames that ask for it. */
+typedef struct opusgpu_silk_chain_bufs {
+    const opusgpu_find_pitch_lags_in *pitch_in; opusgpu_find_pitch_lags_out *pitch_out;
+    opusgpu_noise_shape_in *shape_in; opusgpu_noise_shape_out *shape_out;
+    opusgpu_find_pred_coefs_in *fpc_in; opusgpu_find_pred_coefs_out *fpc_out;
+    opusgpu_process_gains_in *gains_in; opusgpu_process_gains_out *gains_out;
+    opusgpu_prefilter_in *prefilter_in; opusgpu_prefilter_state *prefilter_state; opusgpu_prefilter_out *prefilter_out;
+    void *q_in; opusgpu_nsq_state *nsq_state; void *q_out;
+    opusgpu_silk_bits_in *bits_in; opusgpu_ec_state *ec_state; opusgpu_silk_bits_out *bits_out;
+    void *workspace; size_t workspace_bytes;
+} opusgpu_silk_chain_bufs;
+
+int opusgpu_silk_encode_frames_batch(const opusgpu_silk_chain_bufs *bufs, int fs_kHz, int nb_subfr, int del_dec, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif
