@@ -76,3 +76,23 @@ def test_compat_library_exports_the_libopus_names():
     assert b"gfx950" in L.opus_get_version_string()
     toc = (ctypes.c_ubyte * 2)(0xFC, 0)
     assert L.opus_packet_get_samples_per_frame(toc, 48000) == 960 and L.opus_packet_get_nb_frames(toc, 2) == 1
+
+
+def test_chain_entry_point_rejects_bad_arguments_before_touching_a_gpu():
+    """opusgpu_silk_encode_frames_batch checks its buffer table and geometry on the host first: NULL table, a missing stage buffer,
+    12 kHz / three subframes -> OPUSGPU_BAD_ARG; zero frames -> OK. None of these reaches a HIP call, so they run here."""
+    import ctypes as C
+    lib = _ensure_built()
+    from concentus_amd.silk_chain import ChainBufs
+    L = C.CDLL(lib.LIB_PATH)
+    f = L.opusgpu_silk_encode_frames_batch
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    assert f(None, 16, 4, 1, 8, None) == -1
+    empty = ChainBufs()
+    assert f(C.byref(empty), 16, 4, 1, 0, None) == 0
+    assert f(C.byref(empty), 16, 4, 1, 8, None) == -1
+    full = ChainBufs(*([C.c_void_p(4096)] * 18), C.c_size_t(0))               # never dereferenced: the geometry is rejected first
+    assert f(C.byref(full), 12, 4, 1, 8, None) == -1
+    assert f(C.byref(full), 16, 3, 0, 8, None) == -1
+    assert f(C.byref(full), 16, 4, 0, -1, None) == -1
