@@ -1132,7 +1132,11 @@ def main(argv=None):
             if mixed:
                 silk_join()
         torch.cuda.synchronize()
-        from concentus_amd.sharding import gather_packets
+        from concentus_amd.sharding import gather_packets, trim_width, truncated
+        # row width of the packet exchange: learnt ONCE from the warm-up output (one all_reduce + host read, before the
+        # clock); the timed steps pass it as a number, so no step synchronises with the host for it. The lengths travel
+        # with the rows and are checked after the clock (a longer packet would have been cut).
+        gather_w = trim_width(lens if host_gather is False else lens.cpu(), out.shape[1]) if (world > 1 and not a.no_gather and warm > 0) else False
         L.opusgpu_kernel_timing_enable(1)          # HIP events around each kernel, on the launch stream
         barrier()
         t0 = time.perf_counter()
@@ -1167,14 +1171,15 @@ def main(argv=None):
                 for pg in pending:
                     pg.wait()
                 hc = (lambda t: t.cpu()) if host_gather else (lambda t: t)
-                pending = [gather_packets(hc(out), hc(lens), hc(_r), world, sizes=[F] * world, trim=True, async_op=True)]
+                pending = [gather_packets(hc(out), hc(lens), hc(_r), world, sizes=[F] * world, trim=gather_w, async_op=True)]
                 if mixed:
                     pending.append(gather_packets(hc(s_pulses), hc(s_bo), hc(s_bo[:, :4]).contiguous(), world, sizes=[NS] * world, async_op=True))
-        for pg in pending:
-            pg.wait()
+        gathered = [pg.wait() for pg in pending]
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
+        if gathered and gathered[0] is not None and gather_w and truncated(gathered[0][1], pending[0].width):
+            raise SystemExit("packet gather: a packet of the last step is longer than the row width learnt in the warm-up")
         kern, mean_len = celt_kernel_table(ca, L, F, steps, lens, traffic_db)
         dom = kern[0]
         kname, kms = dom["kernel"], dom["avg_launch_ms"]
@@ -1221,9 +1226,15 @@ def main(argv=None):
             F = FT
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_gather else dev)
+    per_rank_s = [elapsed]
     if world > 1:
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)                  # what each rank's clock read: shows a slow rank in the line
+        per_rank_s = [float(e.item()) for e in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    dist_info = {"backend": (dist.get_backend() if world > 1 else None), "dist_world_size": (dist.get_world_size() if world > 1 else 1),
+                 "device": torch.cuda.get_device_name(local)}
     achieved = kbytes / (kms * 1e-3) / 1e9
 
     if rank == 0:
@@ -1260,6 +1271,10 @@ def main(argv=None):
             "config": {"workload": workload, "frames_per_gpu": F, "channels": 2,
                        "sharding": "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0"},
             **({"rehearsal": True} if (host_gather or one_device) else {}),
+            # transport evidence for a multi-GPU record: which torch.distributed backend ran ("nccl" = RCCL), how many ranks
+            # it saw, and every rank's own rate over the timed region (units/s from that rank's clock)
+            **dist_info,
+            "per_rank_units_per_s": [round(F * steps / e, 1) for e in per_rank_s],
             "parity_checked": parity["checked"],
             "parity_note": parity["note"],
             "roofline": dict(roof, **extra),

@@ -66,7 +66,42 @@ __global__ void celt_dec_state_init_kernel(opusgpu_celt_dec_state *states, int n
     }
 }
 
+// quant_all_bands(encode = 0) on its own (bands.c:1337-1502 as called at celt_decoder.c:977), for the per-call hook
+// opusgpu_quant_all_bands: ONE lane of the lane build runs quant_all_bands_dec on a record -- the same code the batched
+// decoder runs per stream.
+__global__ __launch_bounds__(64) void quant_all_bands_dec_hook_kernel(opusgpu_qab_dec_record *rec)
+{
+    fill_lds_tables();
+    if (threadIdx.x != 0) return;
+    DecWork F;
+    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32);
+    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16);
+    F.X = rec->X;
+    F.diag = nullptr;
+    for (int k = 0; k < NB; k++) { F.pulses[k] = rec->pulses[k]; F.tf_res[k] = rec->tf_res[k]; }
+    for (int k = 0; k < 2 * NB; k++) F.collapse_masks[k] = 0;
+    RangeDec dec;
+    dec.buf = rec->buf;
+    dec.storage = rec->ec_storage; dec.end_offs = rec->ec_end_offs; dec.end_window = rec->ec_end_window;
+    dec.nend_bits = rec->ec_nend_bits; dec.nbits_total = rec->ec_nbits_total; dec.offs = rec->ec_offs; dec.rng = rec->ec_rng;
+    dec.val = rec->ec_val; dec.ext = rec->ec_ext; dec.rem = rec->ec_rem; dec.error = rec->ec_error;
+    u32 seed = rec->seed;
+    quant_all_bands_dec(F, dec, rec->shortBlocks, rec->spread, rec->dual_stereo, rec->intensity, rec->total_bits, rec->balance,
+                        rec->codedBands, &seed);
+    for (int k = 0; k < 2 * NB; k++) rec->collapse_masks[k] = F.collapse_masks[k];
+    rec->seed = seed;
+    rec->ec_end_offs = dec.end_offs; rec->ec_end_window = dec.end_window; rec->ec_nend_bits = dec.nend_bits;
+    rec->ec_nbits_total = dec.nbits_total; rec->ec_offs = dec.offs; rec->ec_rng = dec.rng; rec->ec_val = dec.val;
+    rec->ec_ext = dec.ext; rec->ec_rem = dec.rem; rec->ec_error = dec.error;
+}
+
 }  // namespace ca
+
+extern "C" int opusgpu_launch_quant_all_bands_dec(opusgpu_qab_dec_record *d_rec)
+{
+    hipLaunchKernelGGL(ca::quant_all_bands_dec_hook_kernel, dim3(1), dim3(64), 0, 0, d_rec);
+    return opusgpu_check_launch();
+}
 
 extern "C" void opusgpu_launch_dec_synth(void *states, int n, hipStream_t s);
 

@@ -1,9 +1,11 @@
 // inner_hooks.hip -- per-call hooks with the reference's own argument lists (include/opusgpu_hooks.h): opus_ifft,
 // comb_filter_const, exp_rotation1, renormalise_vector, silk_NSQ, silk_NSQ_del_dec. Host pointers in and out; each call
 // is one small launch between copies (plumbing / parity), the arithmetic is the device code of the batch kernels.
+#include <stdlib.h>
 #include <string.h>
 #include "mdct_dev.h"
 #include "celt_math.h"
+#include "ec_script.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_hooks.h"
 #include "../../include/opusgpu_silk.h"
@@ -26,13 +28,13 @@ __global__ __launch_bounds__(64) void ifft_kernel(const int2 *__restrict__ fin, 
     wave_sync();
     for (int i = lane; i < NFFT; i += 64) {
         const int2 v = fin[i];
-        S.x[T.bitrev[i]] = make_int2(v.x, neg32(v.y));
+        fft_put<SHIFT, 1>(S.x, T.bitrev[i], cpx{v.x, neg32(v.y)});
     }
     wave_sync();
     fft_wave<SHIFT, 1>(S.x, T.tw, lane);
     for (int i = lane; i < NFFT; i += 64) {
-        const int2 v = S.x[i];
-        fout[i] = make_int2(v.x, neg32(v.y));
+        const cpx v = fft_get<SHIFT, 1>(S.x, i);
+        fout[i] = make_int2(v.r, neg32(v.i));
     }
 }
 
@@ -112,6 +114,50 @@ __global__ __launch_bounds__(64) void renormalise_vector_kernel(i16 *X, int N, i
     const i32 t = vshr32(E, 2 * (k - 7));
     const i32 g = (i16)mul16_16_p15(celt_rsqrt_norm(t), gain);
     for (int i = threadIdx.x; i < N; i += 64) X[i] = (i16)pshr32(mul16_16(g, X[i]), k + 1);
+}
+
+// ---- range coder scripts (ec_script.h) -------------------------------------------------------------------
+struct EcScriptRecord {
+    u32 storage, end_offs, end_window, offs, rng, val, ext;
+    i32 nend_bits, nbits_total, rem, error, bad_script;
+    u8 buf[1280];
+};
+
+__global__ __launch_bounds__(64) void ec_enc_script_kernel(EcScriptRecord *rec, const i32 *__restrict__ ops, int n)
+{
+    __shared__ u8 buf[1280];
+    const u32 storage = uni(rec->storage);
+    for (u32 k = lane(); k < storage; k += LANES) buf[k] = rec->buf[k];
+    RangeEnc e;
+    e.buf = buf;
+    e.storage = storage; e.end_offs = uni(rec->end_offs); e.end_window = uni(rec->end_window); e.offs = uni(rec->offs);
+    e.rng = uni(rec->rng); e.val = uni(rec->val); e.ext = uni(rec->ext); e.nend_bits = uni(rec->nend_bits);
+    e.nbits_total = uni(rec->nbits_total); e.rem = uni(rec->rem); e.error = uni(rec->error);
+    wave_sync();
+    const bool ok = ec_enc_script_ok(ops, n);
+    if (ok) ec_enc_run_script(e, ops, n);
+    wave_sync();
+    for (u32 k = lane(); k < storage; k += LANES) rec->buf[k] = buf[k];
+    if (lane() == 0) {
+        rec->storage = e.storage; rec->end_offs = e.end_offs; rec->end_window = e.end_window; rec->offs = e.offs; rec->rng = e.rng;
+        rec->val = e.val; rec->ext = e.ext; rec->nend_bits = e.nend_bits; rec->nbits_total = e.nbits_total; rec->rem = e.rem;
+        rec->error = e.error; rec->bad_script = !ok;
+    }
+}
+
+__global__ __launch_bounds__(64) void ec_dec_script_kernel(EcScriptRecord *rec, const i32 *__restrict__ ops, int n, i32 *out)
+{
+    if (threadIdx.x != 0) return;                      // decoding is one serial chain: one lane
+    RangeDec d;
+    d.buf = rec->buf;
+    d.storage = rec->storage; d.end_offs = rec->end_offs; d.end_window = rec->end_window; d.offs = rec->offs; d.rng = rec->rng;
+    d.val = rec->val; d.ext = rec->ext; d.nend_bits = rec->nend_bits; d.nbits_total = rec->nbits_total; d.rem = rec->rem;
+    d.error = rec->error;
+    const bool ok = ec_dec_script_ok(ops, n);
+    if (ok) ec_dec_run_script(d, ops, n, out);
+    rec->end_offs = d.end_offs; rec->end_window = d.end_window; rec->offs = d.offs; rec->rng = d.rng; rec->val = d.val;
+    rec->ext = d.ext; rec->nend_bits = d.nend_bits; rec->nbits_total = d.nbits_total; rec->rem = d.rem; rec->error = d.error;
+    rec->bad_script = !ok;
 }
 
 }  // namespace ca
@@ -286,3 +332,49 @@ extern "C" void opusgpu_silk_NSQ_del_dec(const void *psEncC, void *NSQ, void *ps
     nsq_hook(1, psEncC, NSQ, psIndices, x_Q3, pulses, PredCoef_Q12, LTPCoef_Q14, AR2_Q13, HarmShapeGain_Q14, Tilt_Q14, LF_shp_Q14,
              Gains_Q16, pitchL, Lambda_Q10, LTP_scale_Q14);
 }
+
+// ---- range coder scripts -------------------------------------------------------------------------------------
+// the tree's ec_ctx, x86-64 (celt/entcode.h:63-94, with the trailing EC_DIFF of this tree)
+namespace {
+struct ref_ec_ctx_s {
+    unsigned char *buf;
+    uint32_t storage, end_offs, end_window;
+    int nend_bits, nbits_total;
+    uint32_t offs, rng, val, ext;
+    int rem, error, EC_DIFF;
+};
+
+int run_ec_script(void *ec, const int32_t *ops, int n, int32_t *out, bool decode)
+{
+    ref_ec_ctx_s *e = (ref_ec_ctx_s *)ec;
+    if (!e || !e->buf || n < 0 || (n > 0 && !ops) || (decode && n > 0 && !out)) return fail(OPUSGPU_BAD_ARG);
+    if (e->storage > sizeof(((EcScriptRecord *)nullptr)->buf) || n > 65536) return fail(OPUSGPU_UNIMPLEMENTED);
+    if (n == 0) return fail(OPUSGPU_OK);
+    EcScriptRecord *h = (EcScriptRecord *)calloc(1, sizeof(EcScriptRecord));
+    if (!h) return fail(OPUSGPU_ALLOC_FAIL);
+    h->storage = e->storage; h->end_offs = e->end_offs; h->end_window = e->end_window; h->offs = e->offs; h->rng = e->rng; h->val = e->val;
+    h->ext = e->ext; h->nend_bits = e->nend_bits; h->nbits_total = e->nbits_total; h->rem = e->rem; h->error = e->error;
+    memcpy(h->buf, e->buf, e->storage);
+    DevBuf drec(sizeof(*h)), dops((size_t)n * 16), dout((size_t)n * 4);
+    int rc = (drec.p && dops.p && dout.p) ? OPUSGPU_OK : OPUSGPU_ALLOC_FAIL;
+    if (rc == OPUSGPU_OK && !(h2d(drec.p, h, sizeof(*h)) && h2d(dops.p, ops, (size_t)n * 16))) rc = OPUSGPU_INTERNAL_ERROR;
+    if (rc == OPUSGPU_OK) {
+        if (decode) hipLaunchKernelGGL(ca::ec_dec_script_kernel, dim3(1), dim3(64), 0, 0, (EcScriptRecord *)drec.p, (const i32 *)dops.p, n, (i32 *)dout.p);
+        else hipLaunchKernelGGL(ca::ec_enc_script_kernel, dim3(1), dim3(64), 0, 0, (EcScriptRecord *)drec.p, (const i32 *)dops.p, n);
+        rc = opusgpu_check_launch();
+    }
+    if (rc == OPUSGPU_OK && !d2h(h, drec.p, sizeof(*h))) rc = OPUSGPU_INTERNAL_ERROR;
+    if (rc == OPUSGPU_OK && h->bad_script) rc = OPUSGPU_BAD_ARG;           // an argument the reference's celt_assert()s reject: nothing ran
+    if (rc == OPUSGPU_OK && decode && !d2h(out, dout.p, (size_t)n * 4)) rc = OPUSGPU_INTERNAL_ERROR;
+    if (rc == OPUSGPU_OK) {
+        if (!decode) memcpy(e->buf, h->buf, e->storage);
+        e->storage = h->storage; e->end_offs = h->end_offs; e->end_window = h->end_window; e->offs = h->offs; e->rng = h->rng; e->val = h->val;
+        e->ext = h->ext; e->nend_bits = h->nend_bits; e->nbits_total = h->nbits_total; e->rem = h->rem; e->error = h->error;
+    }
+    free(h);
+    return fail(rc);
+}
+}  // namespace
+
+extern "C" int opusgpu_ec_enc_script(void *ec, const int32_t *ops, int n_ops) { return run_ec_script(ec, ops, n_ops, nullptr, false); }
+extern "C" int opusgpu_ec_dec_script(void *ec, const int32_t *ops, int n_ops, int32_t *out) { return run_ec_script(ec, ops, n_ops, out, true); }

@@ -78,6 +78,59 @@ CA_DEV cpx c_mul(cpx a, u32 tw)                     // _kiss_fft_guts.h:59 C_MUL
 CA_DEV cpx c_add(cpx a, cpx b) { return cpx{add32(a.r, b.r), add32(a.i, b.i)}; }
 CA_DEV cpx c_sub(cpx a, cpx b) { return cpx{sub32(a.r, b.r), sub32(a.i, b.i)}; }
 
+// The trips of a stage's lane loop stay rolled: unrolled, the loads of two or three trips are in flight together and the
+// transform needs ~120 VGPRs (four wavefronts per SIMD); rolled it fits the budget of six to eight, and it is the other
+// wavefronts of the SIMD, not the next trip of the same one, that cover a trip's LDS round trip.
+#if defined(CA_HOST_EMU)
+#define CA_FFT_ROLLED
+CA_DEV int fft_lane(int lane) { return lane; }
+#else
+#define CA_FFT_ROLLED _Pragma("clang loop unroll(disable)")
+// the lane index as a value the compiler cannot see through: every stage derives its addresses from it afresh, so the
+// address arithmetic of a later stage is not hoisted above the earlier ones (where it would only hold registers)
+CA_DEV int fft_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
+#endif
+
+// ---- bank swizzle of the FFT scratch (long transforms) ---------------------------------------------------
+// Point e of a 480-point transform lives at x[fsw<0>(e)]. Laid out plainly, the butterfly strides of the first stages
+// (4, 8, 32 points x 8 bytes) and the bit-reversed scatter of the pre-rotation (fifteen consecutive inputs land 32 points
+// apart) put most lanes of a wave-instruction on a few LDS banks: 570 conflict cycles on 277 useful ones per transform
+// (measured ratio 2.6 on the frame kernel, profiles/r02_s7). The permutation
+//     fsw(e) = e ^ (LUT[e >> 5] << 1) ^ (((e >> 4) & 1) << 2)
+// keeps bit 0 (a pair of points stays one aligned 16-byte unit), permutes inside aligned groups of 32 points (so the
+// lane-contiguous sweeps of the later stages stay conflict-free) and was searched (tools/fft_swizzle_search.py, the
+// bank model of MI355X_MICROARCH.md: lane groups and banks per ds_read/ds_write width) for the access patterns below:
+// pair scatter (b128), eight points per lane (b128), radix-4 at stride 8, radix-3 at 32, radix-5 at 96, linear read-out
+// -- 12 conflict cycles left per transform, all in the scatter. Other sizes (short blocks, the hooks' 240 / 120) keep the plain layout.
+template <int SHIFT>
+CA_DEV int fsw(int e)
+{
+    if constexpr (SHIFT == 0) {
+        // LUT[t], t = e >> 5 = 0..14: 9 4 2 15 3 14 8 5 11 14 1 4 2 7 8, four bits each, pre-shifted left by one
+        constexpr unsigned long long LUT = (9ull << 1) | (4ull << 5) | (2ull << 9) | (15ull << 13) | (3ull << 17) | (14ull << 21)
+            | (8ull << 25) | (5ull << 29) | (11ull << 33) | (14ull << 37) | (1ull << 41) | (4ull << 45) | (2ull << 49) | (7ull << 53)
+            | (8ull << 57);
+        const int s = (int)(LUT >> ((e >> 3) & 60)) & 30;
+        return e ^ s ^ ((e >> 2) & 4);
+    } else {
+        return e;
+    }
+}
+
+// a pair of points (16 bytes, e even) in one LDS access
+struct cpx2 { cpx a, b; };
+CA_DEV cpx2 ld2(const int2 *p)
+{
+    const int4 v = *reinterpret_cast<const int4 *>(p);
+    return cpx2{cpx{v.x, v.y}, cpx{v.z, v.w}};
+}
+CA_DEV void st2(int2 *p, cpx a, cpx b)
+{
+    int4 v;
+    v.x = a.r; v.y = a.i; v.z = b.r; v.w = b.i;
+    *reinterpret_cast<int4 *>(p) = v;
+}
+
 // ---- butterfly stages: B blocks of NFFT points laid out back to back in x[] ----------------------
 template <int NFFT, int B>
 CA_DEV void fft_radix4_first(int2 *x, int lane)     // kiss_fft.c:123-145, m == 1
@@ -126,28 +179,79 @@ CA_DEV void fft_radix2_m4(int2 *x, int lane)        // kiss_fft.c:72-107, m == 4
     }
 }
 
+// The first two stages of the 480-point transform -- radix 4 at m == 1 (kiss_fft.c:123-145) and radix 2 at m == 4
+// (:72-107) -- on eight consecutive points held by ONE lane: four 16-byte loads, twelve butterflies in registers, four
+// 16-byte stores; 60 lanes, one LDS round trip instead of two (and no 4- and 8-point strides across lanes).
+template <int SHIFT>
+CA_DEV void fft_first8(int2 *x, int lane)
+{
+    constexpr int NFFT = 480 >> SHIFT;
+    constexpr i32 TW = 23170;
+    lane = fft_lane(lane);
+    for (int g = lane; g < NFFT / 8; g += LANES) {
+        cpx v[8];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const cpx2 t = ld2(x + fsw<SHIFT>(8 * g + 2 * q));
+            v[2 * q] = t.a;
+            v[2 * q + 1] = t.b;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                                  // radix 4, m == 1, on points 4h .. 4h+3
+            cpx x0 = v[4 * h], x1 = v[4 * h + 1], x2 = v[4 * h + 2], x3 = v[4 * h + 3];
+            cpx s0 = c_sub(x0, x2);
+            x0 = c_add(x0, x2);
+            cpx s1 = c_add(x1, x3);
+            x2 = c_sub(x0, s1);
+            x0 = c_add(x0, s1);
+            s1 = c_sub(x1, x3);
+            v[4 * h] = x0;
+            v[4 * h + 2] = x2;
+            v[4 * h + 1] = cpx{add32(s0.r, s1.i), sub32(s0.i, s1.r)};
+            v[4 * h + 3] = cpx{sub32(s0.r, s1.i), add32(s0.i, s1.r)};
+        }
+        {                                                               // radix 2, m == 4: (k, k + 4), rotation by k eighths
+            cpx t, b;
+            b = v[4]; t = b;
+            v[4] = c_sub(v[0], t); v[0] = c_add(v[0], t);
+            b = v[5]; t.r = CA_SMUL(add32(b.r, b.i), TW); t.i = CA_SMUL(sub32(b.i, b.r), TW);
+            v[5] = c_sub(v[1], t); v[1] = c_add(v[1], t);
+            b = v[6]; t.r = b.i; t.i = neg32(b.r);
+            v[6] = c_sub(v[2], t); v[2] = c_add(v[2], t);
+            b = v[7]; t.r = CA_SMUL(sub32(b.i, b.r), TW); t.i = CA_SMUL(sub32(neg32(b.i), b.r), TW);
+            v[7] = c_sub(v[3], t); v[3] = c_add(v[3], t);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) st2(x + fsw<SHIFT>(8 * g + 2 * q), v[2 * q], v[2 * q + 1]);
+    }
+}
+
 template <int NFFT, int B, int M>
 CA_DEV void fft_radix4(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:146-176
 {
     constexpr int G = NFFT / (4 * M);
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 4;
+    constexpr int SW = (NFFT == 480 && B == 1) ? 0 : 1;                 // layout: swizzled for the long transform only
+    lane = fft_lane(lane);
+    CA_FFT_ROLLED
     for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
-        int2 *f = x + blk * NFFT + g * 4 * M + j;
-        cpx f0 = ld(f);
-        cpx a = c_mul(ld(f + M), tw[j * TWS]);
-        cpx b = c_mul(ld(f + 2 * M), tw[2 * j * TWS]);
-        cpx c = c_mul(ld(f + 3 * M), tw[3 * j * TWS]);
+        const int e = blk * NFFT + g * 4 * M + j;
+        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M), *f3p = x + fsw<SW>(e + 3 * M);
+        cpx f0 = ld(f0p);
+        cpx a = c_mul(ld(f1p), tw[j * TWS]);
+        cpx b = c_mul(ld(f2p), tw[2 * j * TWS]);
+        cpx c = c_mul(ld(f3p), tw[3 * j * TWS]);
         cpx d5 = c_sub(f0, b);
         f0 = c_add(f0, b);
         cpx s3 = c_add(a, c);
         cpx s4 = c_sub(a, c);
-        st(f + 2 * M, c_sub(f0, s3));
-        st(f, c_add(f0, s3));
-        st(f + M, cpx{add32(d5.r, s4.i), sub32(d5.i, s4.r)});
-        st(f + 3 * M, cpx{sub32(d5.r, s4.i), add32(d5.i, s4.r)});
+        st(f2p, c_sub(f0, s3));
+        st(f0p, c_add(f0, s3));
+        st(f1p, cpx{add32(d5.r, s4.i), sub32(d5.i, s4.r)});
+        st(f3p, cpx{sub32(d5.r, s4.i), add32(d5.i, s4.r)});
     }
 }
 
@@ -157,22 +261,26 @@ CA_DEV void fft_radix3(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:185-241
     constexpr int G = NFFT / (3 * M);
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 3;
+    constexpr int SW = (NFFT == 480 && B == 1) ? 0 : 1;
     constexpr i32 EPI3 = -28378;
+    lane = fft_lane(lane);
+    CA_FFT_ROLLED
     for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
-        int2 *f = x + blk * NFFT + g * 3 * M + j;
-        cpx f0 = ld(f);
-        cpx a = c_mul(ld(f + M), tw[j * TWS]);
-        cpx b = c_mul(ld(f + 2 * M), tw[2 * j * TWS]);
+        const int e = blk * NFFT + g * 3 * M + j;
+        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M);
+        cpx f0 = ld(f0p);
+        cpx a = c_mul(ld(f1p), tw[j * TWS]);
+        cpx b = c_mul(ld(f2p), tw[2 * j * TWS]);
         cpx s3 = c_add(a, b);
         cpx s0 = c_sub(a, b);
         cpx f1{sub32(f0.r, s3.r >> 1), sub32(f0.i, s3.i >> 1)};
         s0.r = CA_SMUL(s0.r, EPI3);
         s0.i = CA_SMUL(s0.i, EPI3);
-        st(f, c_add(f0, s3));
-        st(f + 2 * M, cpx{add32(f1.r, s0.i), sub32(f1.i, s0.r)});
-        st(f + M, cpx{sub32(f1.r, s0.i), add32(f1.i, s0.r)});
+        st(f0p, c_add(f0, s3));
+        st(f2p, cpx{add32(f1.r, s0.i), sub32(f1.i, s0.r)});
+        st(f1p, cpx{sub32(f1.r, s0.i), add32(f1.i, s0.r)});
     }
 }
 
@@ -182,40 +290,59 @@ CA_DEV void fft_radix5(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:245-322
     constexpr int G = NFFT / (5 * M);
     constexpr int TWS = G * (480 / NFFT);
     constexpr int CNT = B * NFFT / 5;
+    constexpr int SW = (NFFT == 480 && B == 1) ? 0 : 1;
     constexpr i32 YAR = 10126, YAI = -31164, YBR = -26510, YBI = -19261;
+    lane = fft_lane(lane);
+    CA_FFT_ROLLED
     for (int idx = lane; idx < CNT; idx += LANES) {
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, u = r % M;
-        int2 *f = x + blk * NFFT + g * 5 * M + u;
-        cpx s0 = ld(f);
-        cpx s1 = c_mul(ld(f + M), tw[u * TWS]);
-        cpx s2 = c_mul(ld(f + 2 * M), tw[2 * u * TWS]);
-        cpx s3 = c_mul(ld(f + 3 * M), tw[3 * u * TWS]);
-        cpx s4 = c_mul(ld(f + 4 * M), tw[4 * u * TWS]);
+        const int e = blk * NFFT + g * 5 * M + u;
+        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M), *f3p = x + fsw<SW>(e + 3 * M),
+             *f4p = x + fsw<SW>(e + 4 * M);
+        cpx s0 = ld(f0p);
+        cpx s1 = c_mul(ld(f1p), tw[u * TWS]);
+        cpx s2 = c_mul(ld(f2p), tw[2 * u * TWS]);
+        cpx s3 = c_mul(ld(f3p), tw[3 * u * TWS]);
+        cpx s4 = c_mul(ld(f4p), tw[4 * u * TWS]);
         cpx s7 = c_add(s1, s4), s10 = c_sub(s1, s4);
         cpx s8 = c_add(s2, s3), s9 = c_sub(s2, s3);
-        st(f, cpx{add32(s0.r, add32(s7.r, s8.r)), add32(s0.i, add32(s7.i, s8.i))});
+        st(f0p, cpx{add32(s0.r, add32(s7.r, s8.r)), add32(s0.i, add32(s7.i, s8.i))});
         cpx s5, s6, s11, s12;
         s5.r = add32(add32(s0.r, CA_SMUL(s7.r, YAR)), CA_SMUL(s8.r, YBR));
         s5.i = add32(add32(s0.i, CA_SMUL(s7.i, YAR)), CA_SMUL(s8.i, YBR));
         s6.r = add32(CA_SMUL(s10.i, YAI), CA_SMUL(s9.i, YBI));
         s6.i = sub32(neg32(CA_SMUL(s10.r, YAI)), CA_SMUL(s9.r, YBI));
-        st(f + M, c_sub(s5, s6));
-        st(f + 4 * M, c_add(s5, s6));
+        st(f1p, c_sub(s5, s6));
+        st(f4p, c_add(s5, s6));
         s11.r = add32(add32(s0.r, CA_SMUL(s7.r, YBR)), CA_SMUL(s8.r, YAR));
         s11.i = add32(add32(s0.i, CA_SMUL(s7.i, YBR)), CA_SMUL(s8.i, YAR));
         s12.r = add32(neg32(CA_SMUL(s10.i, YBI)), CA_SMUL(s9.i, YAI));
         s12.i = sub32(CA_SMUL(s10.r, YBI), CA_SMUL(s9.r, YAI));
-        st(f + 2 * M, c_add(s11, s12));
-        st(f + 3 * M, c_sub(s11, s12));
+        st(f2p, c_add(s11, s12));
+        st(f3p, c_sub(s11, s12));
     }
 }
 
-// In-place FFT of B blocks of (480 >> SHIFT) bit-reversed points (opus_fft_impl, kiss_fft.c:532-578).
+// Where point e of the scratch lives: the long single transform is bank-swizzled, everything else plain.
+template <int SHIFT, int B> CA_DEV int fft_at(int e) { return fsw<(SHIFT == 0 && B == 1) ? 0 : 1>(e); }
+template <int SHIFT, int B> CA_DEV void fft_put(int2 *x, int e, cpx v) { st(x + fft_at<SHIFT, B>(e), v); }
+template <int SHIFT, int B> CA_DEV cpx fft_get(const int2 *x, int e) { return ld(x + fft_at<SHIFT, B>(e)); }
+
+// In-place FFT of B blocks of (480 >> SHIFT) bit-reversed points (opus_fft_impl, kiss_fft.c:532-578); the points are
+// addressed through fft_put / fft_get.
 template <int SHIFT, int B>
 CA_DEV void fft_wave(int2 *x, const u32 *tw, int lane)
 {
     constexpr int NFFT = 480 >> SHIFT;
+    if constexpr (SHIFT == 0 && B == 1) {
+        // swizzled layout (fsw<0>): points written by fft_put<0, 1> / the MDCT pre-rotations, read back with fft_get<0, 1>
+        fft_first8<0>(x, lane);                 wave_sync();
+        fft_radix4<NFFT, B, 8>(x, tw, lane);    wave_sync();
+        fft_radix3<NFFT, B, 32>(x, tw, lane);   wave_sync();
+        fft_radix5<NFFT, B, 96>(x, tw, lane);   wave_sync();
+        return;
+    }
     fft_radix4_first<NFFT, B>(x, lane);
     wave_sync();
     if constexpr (SHIFT == 0) {
@@ -242,45 +369,68 @@ CA_DEV void fft_wave(int2 *x, const u32 *tw, int lane)
 // goes to dst[(k*B + b) * dstride] -- the interleaved layout of compute_mdcts (celt_encoder.c:441).
 // T holds the tables for this SHIFT. dst may be LDS or global; it may alias sin
 // (all reads of sin complete before the first write to dst).      Reference: mdct.c:121-259.
+// fold + pre-rotation of input point i of one block (mdct.c:155-231): the value the FFT takes at position bitrev[i]
+template <int SHIFT>
+CA_DEV cpx mdct_fwd_pre(const i32 *in, int i, const MdctTab &T)
+{
+    constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2;
+    constexpr int OV = 120, OV2 = 60, Q = 30;
+    constexpr int SCALE_SHIFT = (8 - SHIFT) - 1;                     // st->scale_shift - 1
+    const int a = OV2 + 2 * i, b = N2 - 1 + OV2 - 2 * i;
+    i32 re, im;
+    if (i < Q) {                                                      // mdct.c:162-175
+        i32 w1 = T.window[OV2 + 2 * i], w2 = T.window[OV2 - 1 - 2 * i];
+        re = add32(mul16_32_q15(w2, in[a + N2]), mul16_32_q15(w1, in[b]));
+        im = sub32(mul16_32_q15(w1, in[a]), mul16_32_q15(w2, in[b - N2]));
+    } else if (i < N4 - Q) {                                          // mdct.c:178-189
+        re = in[b];
+        im = in[a];
+    } else {                                                          // mdct.c:190-203
+        int k = i - (N4 - Q);
+        i32 w1 = T.window[2 * k], w2 = T.window[OV - 1 - 2 * k];
+        re = add32(neg32(mul16_32_q15(w1, in[a - N2])), mul16_32_q15(w2, in[b]));
+        im = add32(mul16_32_q15(w2, in[a]), mul16_32_q15(w1, in[b + N2]));
+    }
+    u32 t = T.trig[i];                                                // mdct.c:206-231
+    i32 t0 = lo16(t), t1 = hi16(t);
+    i32 yr = sub32(CA_SMUL(re, t0), CA_SMUL(im, t1));
+    i32 yi = add32(CA_SMUL(im, t0), CA_SMUL(re, t1));
+    return cpx{pshr32(mul16_32_q16(17476, yr), SCALE_SHIFT), pshr32(mul16_32_q16(17476, yi), SCALE_SHIFT)};
+}
+
+// Lane schedule of the pre-rotation of the long transform: inputs i and i + 120 land on neighbouring points (bitrev[i + 120]
+// == bitrev[i] + 1 for i in [0, 120) and [240, 360)), so one lane produces both and stores them as ONE 16-byte unit; 240
+// such pairs, 60 per trip (the lanes of a trip read consecutive inputs: same coalescing as a plain sweep).
+enum { FFT_PAIRS = 240, FFT_PAIR_STEP = LANES >= 60 ? 60 : LANES };
+CA_DEV int fft_pair_input(int n) { return n < 120 ? n : n + 120; }
+
 template <int SHIFT, int B>
 CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, const MdctTab &T, int lane)
 {
     const u32 *trig = T.trig;
     const i16 *bitrev = T.bitrev;
     constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
-    constexpr int OV = 120, OV2 = 60, Q = 30;
-    constexpr int SCALE_SHIFT = (8 - SHIFT) - 1;                     // st->scale_shift - 1
-    for (int idx = lane; idx < B * N4; idx += LANES) {
-        int blk = idx / N4, i = idx % N4;
-        const i32 *in = sin + blk * N2;
-        int a = OV2 + 2 * i, b = N2 - 1 + OV2 - 2 * i;
-        i32 re, im;
-        if (i < Q) {                                                  // mdct.c:162-175
-            i32 w1 = T.window[OV2 + 2 * i], w2 = T.window[OV2 - 1 - 2 * i];
-            re = add32(mul16_32_q15(w2, in[a + N2]), mul16_32_q15(w1, in[b]));
-            im = sub32(mul16_32_q15(w1, in[a]), mul16_32_q15(w2, in[b - N2]));
-        } else if (i < N4 - Q) {                                      // mdct.c:178-189
-            re = in[b];
-            im = in[a];
-        } else {                                                      // mdct.c:190-203
-            int k = i - (N4 - Q);
-            i32 w1 = T.window[2 * k], w2 = T.window[OV - 1 - 2 * k];
-            re = add32(neg32(mul16_32_q15(w1, in[a - N2])), mul16_32_q15(w2, in[b]));
-            im = add32(mul16_32_q15(w2, in[a]), mul16_32_q15(w1, in[b + N2]));
+    if constexpr (SHIFT == 0 && B == 1) {
+        CA_FFT_ROLLED
+        for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
+            const int n = n0 + lane;
+            if (lane < FFT_PAIR_STEP && n < FFT_PAIRS) {
+                const int i = fft_pair_input(n);
+                const cpx a = mdct_fwd_pre<SHIFT>(sin, i, T), b = mdct_fwd_pre<SHIFT>(sin, i + 120, T);
+                st2(f2 + fsw<0>(bitrev[i]), a, b);
+            }
         }
-        u32 t = trig[i];                                              // mdct.c:206-231
-        i32 t0 = lo16(t), t1 = hi16(t);
-        i32 yr = sub32(CA_SMUL(re, t0), CA_SMUL(im, t1));
-        i32 yi = add32(CA_SMUL(im, t0), CA_SMUL(re, t1));
-        yr = pshr32(mul16_32_q16(17476, yr), SCALE_SHIFT);
-        yi = pshr32(mul16_32_q16(17476, yi), SCALE_SHIFT);
-        f2[blk * NFFT + bitrev[i]] = make_int2(yr, yi);
+    } else {
+        for (int idx = lane; idx < B * N4; idx += LANES) {
+            int blk = idx / N4, i = idx % N4;
+            fft_put<SHIFT, B>(f2, blk * NFFT + bitrev[i], mdct_fwd_pre<SHIFT>(sin + blk * N2, i, T));
+        }
     }
     wave_sync();
     fft_wave<SHIFT, B>(f2, T.tw, lane);
     for (int idx = lane; idx < B * N4; idx += LANES) {                  // mdct.c:237-257
         int blk = idx / N4, i = idx % N4;
-        cpx f = ld(f2 + blk * NFFT + i);
+        cpx f = fft_get<SHIFT, B>(f2, blk * NFFT + i);
         u32 t = trig[i];
         i32 t0 = lo16(t), t1 = hi16(t);
         dst[((2 * i) * B + blk) * dstride] = sub32(CA_SMUL(f.i, t1), CA_SMUL(f.r, t0));
@@ -299,15 +449,29 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
     const i16 *bitrev = T.bitrev;
     constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
     constexpr int OV = 120, OV2 = 60;
-    for (int idx = lane; idx < B * N4; idx += LANES) {                  // mdct.c:283-304
-        int blk = idx / N4, i = idx % N4;
+    auto pre = [&](int blk, int i) {                                    // mdct.c:283-304
         i32 x1 = src[((2 * i) * B + blk) * sstride];
         i32 x2 = src[((N2 - 1 - 2 * i) * B + blk) * sstride];
         u32 t = trig[i];
         i32 t0 = lo16(t), t1 = hi16(t);
         i32 yr = add32(CA_SMUL(x2, t0), CA_SMUL(x1, t1));
         i32 yi = sub32(CA_SMUL(x1, t0), CA_SMUL(x2, t1));
-        f2[blk * NFFT + bitrev[i]] = make_int2(yi, yr);              // re/im swapped: FFT as IFFT
+        return cpx{yi, yr};                                             // re/im swapped: FFT as IFFT
+    };
+    if constexpr (SHIFT == 0 && B == 1) {
+        CA_FFT_ROLLED
+        for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {         // pairs (i, i + 120): see mdct_forward_wave
+            const int n = n0 + lane;
+            if (lane < FFT_PAIR_STEP && n < FFT_PAIRS) {
+                const int i = fft_pair_input(n);
+                st2(f2 + fsw<0>(bitrev[i]), pre(0, i), pre(0, i + 120));
+            }
+        }
+    } else {
+        for (int idx = lane; idx < B * N4; idx += LANES) {
+            int blk = idx / N4, i = idx % N4;
+            fft_put<SHIFT, B>(f2, blk * NFFT + bitrev[i], pre(blk, i));
+        }
     }
     wave_sync();
     fft_wave<SHIFT, B>(f2, T.tw, lane);
@@ -316,7 +480,7 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
     // trig[k], trig[N4+k], which is what each lane computes here.
     for (int idx = lane; idx < B * N4; idx += LANES) {
         int blk = idx / N4, k = idx % N4;
-        cpx f = ld(f2 + blk * NFFT + k);
+        cpx f = fft_get<SHIFT, B>(f2, blk * NFFT + k);
         i32 re = f.i, im = f.r;
         u32 t = trig[k];
         i32 t0 = lo16(t), t1 = hi16(t);

@@ -1,13 +1,18 @@
 // mdct_kernels.hip -- batched CELT MDCT forward / backward for gfx950 (BASELINE config #2).
 //
-// One 64-lane wavefront per (frame, channel) transform; workgroup = one wave; the grid is persistent
-// (grid-stride over transforms) so the LDS table staging is paid once per workgroup.
-// Data path per transform:  HBM --16 B/lane coalesced--> LDS --fold/rotate/FFT in LDS--> LDS --16 B/lane--> HBM.
+// One 64-lane wavefront per (frame, channel) transform, one transform per one-wave workgroup (nothing is staged per
+// workgroup, the dispatcher balances). Data path per transform: the fold / pre-rotation reads the input row straight
+// from HBM, the butterfly stages run in the wavefront's LDS scratch (480 complex points, bank-swizzled: mdct_dev.h),
+// the post-rotation writes the coefficients straight to HBM; the 5 KB of tables are read through L1.
 //
 // Replaces clt_mdct_forward_c / clt_mdct_backward_c (opus-fix/celt/mdct.c:121,263) as driven by
 // compute_mdcts (celt/celt_encoder.c:418-461) and celt_synthesis (celt/celt_decoder.c:323-346).
 #include "mdct_dev.h"
 #include "opusgpu_internal.h"
+#include <stdlib.h>
+#ifndef OPUSGPU_MDCT_OCC_DEFAULT
+#define OPUSGPU_MDCT_OCC_DEFAULT 0
+#endif
 
 namespace ca {
 
@@ -21,9 +26,11 @@ struct __align__(16) MdctFftLds {
     __align__(16) int2 f2[480];
 };
 
-template <int SHIFT>
-__global__ __launch_bounds__(64) void mdct_forward_kernel(const i32 *__restrict__ sig, i32 *__restrict__ freq,
-                                                          int ntransforms)
+// OCC = wavefronts per SIMD the register budget must admit (second __launch_bounds__ argument): 8 = all 32 wavefront slots of a
+// CU, so that the 8 192 transforms of config #2 (32 per CU) are resident in ONE round instead of 24 + 8 (opusgpu_mdct_occupancy()).
+template <int SHIFT, int OCC>
+__global__ __launch_bounds__(64, OCC) void mdct_forward_kernel(const i32 *__restrict__ sig, i32 *__restrict__ freq,
+                                                               int ntransforms)
 {
     constexpr int B = 1 << SHIFT;
     __shared__ MdctFftLds S;
@@ -35,8 +42,8 @@ __global__ __launch_bounds__(64) void mdct_forward_kernel(const i32 *__restrict_
     }
 }
 
-template <int SHIFT>
-__global__ __launch_bounds__(64) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *sig, int ntransforms)
+template <int SHIFT, int OCC>
+__global__ __launch_bounds__(64, OCC) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *sig, int ntransforms)
 {
     constexpr int B = 1 << SHIFT;
     __shared__ MdctFftLds S;
@@ -104,12 +111,12 @@ __global__ __launch_bounds__(64) void fft_kernel(const int2 *__restrict__ fin, i
         const int2 *src = fin + (size_t)t * NFFT;
         for (int i = lane; i < NFFT; i += 64) {
             const int2 v = src[i];
-            S.x[T.bitrev[i]] = make_int2(mul16_32_q16(17476, v.x) >> SCALE_SHIFT, mul16_32_q16(17476, v.y) >> SCALE_SHIFT);
+            fft_put<SHIFT, 1>(S.x, T.bitrev[i], cpx{mul16_32_q16(17476, v.x) >> SCALE_SHIFT, mul16_32_q16(17476, v.y) >> SCALE_SHIFT});
         }
         wave_sync();
         fft_wave<SHIFT, 1>(S.x, T.tw, lane);
         int2 *dst = fout + (size_t)t * NFFT;
-        for (int i = lane; i < NFFT; i += 64) dst[i] = S.x[i];
+        for (int i = lane; i < NFFT; i += 64) { const cpx v = fft_get<SHIFT, 1>(S.x, i); dst[i] = make_int2(v.r, v.i); }
         wave_sync();
     }
 }
@@ -124,6 +131,14 @@ static int grid_for(int ntransforms, int waves_per_cu)
 
 using namespace ca;
 
+// register budget of the long-transform batch kernels: OPUSGPU_MDCT_OCC = 8 -> the <= 64-VGPR build (8 wavefronts per SIMD),
+// anything else -> the compiler's own budget. Read per call so that a bench can compare the two.
+static int opusgpu_mdct_occupancy(void)
+{
+    const char *e = getenv("OPUSGPU_MDCT_OCC");
+    return e ? atoi(e) : OPUSGPU_MDCT_OCC_DEFAULT;
+}
+
 extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq, int n_frames, int channels,
                                           int shift, void *stream)
 {
@@ -135,8 +150,9 @@ extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq,
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = nt;        // one transform per one-wave workgroup: nothing is staged per workgroup, the dispatcher balances
-    if (shift == 0) hipLaunchKernelGGL(mdct_forward_kernel<0>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
-    else            hipLaunchKernelGGL(mdct_forward_kernel<3>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    if (shift == 0 && opusgpu_mdct_occupancy() == 8) hipLaunchKernelGGL((mdct_forward_kernel<0, 8>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    else if (shift == 0) hipLaunchKernelGGL((mdct_forward_kernel<0, 1>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    else                 hipLaunchKernelGGL((mdct_forward_kernel<3, 1>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
     return opusgpu_check_launch();
 }
 
@@ -151,8 +167,9 @@ extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = nt;
-    if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
-    else            hipLaunchKernelGGL(mdct_backward_kernel<3>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    if (shift == 0 && opusgpu_mdct_occupancy() == 8) hipLaunchKernelGGL((mdct_backward_kernel<0, 8>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    else if (shift == 0) hipLaunchKernelGGL((mdct_backward_kernel<0, 1>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    else                 hipLaunchKernelGGL((mdct_backward_kernel<3, 1>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     return opusgpu_check_launch();
 }
 
@@ -195,9 +212,9 @@ extern "C" void opusgpu_opus_fft(const void *cfg, const void *fin, void *fout)
         if (d_in) (void)hipFree(d_in);
         return;
     }
-    (void)hipMemcpy(d_in, fin, bytes, hipMemcpyHostToDevice);
-    int rc = opusgpu_fft_batch(d_in, d_out, 1, shift, nullptr);
-    if (rc == OPUSGPU_OK && hipMemcpy(fout, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    int rc = opusgpu_copy(d_in, fin, bytes, hipMemcpyHostToDevice);
+    if (rc == OPUSGPU_OK) rc = opusgpu_fft_batch(d_in, d_out, 1, shift, nullptr);
+    if (rc == OPUSGPU_OK) rc = opusgpu_copy(fout, d_out, bytes, hipMemcpyDeviceToHost);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     opusgpu_set_last_error(rc);
@@ -229,16 +246,17 @@ extern "C" void opusgpu_clt_mdct_forward(const void *l, int32_t *in, int32_t *ou
         if (d_in) (void)hipFree(d_in);
         return;
     }
-    (void)hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_out, out, out_elems * 4, hipMemcpyHostToDevice);   // keep the gaps when stride > 1
-    switch (shift) {
+    int rc = opusgpu_copy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (rc == OPUSGPU_OK) rc = opusgpu_copy(d_out, out, out_elems * 4, hipMemcpyHostToDevice);   // keep the gaps when stride > 1
+    if (rc == OPUSGPU_OK) switch (shift) {
     case 0: hipLaunchKernelGGL(mdct_forward_single_kernel<0>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     case 1: hipLaunchKernelGGL(mdct_forward_single_kernel<1>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     case 2: hipLaunchKernelGGL(mdct_forward_single_kernel<2>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     default: hipLaunchKernelGGL(mdct_forward_single_kernel<3>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     }
-    opusgpu_set_last_error(opusgpu_check_launch());
-    (void)hipMemcpy(out, d_out, out_elems * 4, hipMemcpyDeviceToHost);
+    if (rc == OPUSGPU_OK) rc = opusgpu_check_launch();
+    if (rc == OPUSGPU_OK) rc = opusgpu_copy(out, d_out, out_elems * 4, hipMemcpyDeviceToHost);
+    opusgpu_set_last_error(rc);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
 }
@@ -256,16 +274,17 @@ extern "C" void opusgpu_clt_mdct_backward(const void *l, int32_t *in, int32_t *o
         if (d_in) (void)hipFree(d_in);
         return;
     }
-    (void)hipMemcpy(d_in, in, in_elems * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(d_out, out, out_bytes, hipMemcpyHostToDevice);
-    switch (shift) {
+    int rc = opusgpu_copy(d_in, in, in_elems * 4, hipMemcpyHostToDevice);
+    if (rc == OPUSGPU_OK) rc = opusgpu_copy(d_out, out, out_bytes, hipMemcpyHostToDevice);
+    if (rc == OPUSGPU_OK) switch (shift) {
     case 0: hipLaunchKernelGGL(mdct_backward_single_kernel<0>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     case 1: hipLaunchKernelGGL(mdct_backward_single_kernel<1>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     case 2: hipLaunchKernelGGL(mdct_backward_single_kernel<2>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     default: hipLaunchKernelGGL(mdct_backward_single_kernel<3>, dim3(1), dim3(64), 0, 0, d_in, d_out, stride); break;
     }
-    opusgpu_set_last_error(opusgpu_check_launch());
-    (void)hipMemcpy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    if (rc == OPUSGPU_OK) rc = opusgpu_check_launch();
+    if (rc == OPUSGPU_OK) rc = opusgpu_copy(out, d_out, out_bytes, hipMemcpyDeviceToHost);
+    opusgpu_set_last_error(rc);
     (void)hipFree(d_in);
     (void)hipFree(d_out);
 }

@@ -15,3 +15,23 @@ extern "C" int opusgpu_lane_frames(void);
 extern "C" int *opusgpu_bad_record_counter(void);
 // records per wavefront of the lane-per-record SILK analysis kernels that keep no per-lane LDS: 64, 32, 16 or 8 (OPUSGPU_SILK_LANES)
 extern "C" int opusgpu_silk_lanes_per_block(void);
+// hipMemcpy of a per-call hook with its status mapped: OPUSGPU_OK or OPUSGPU_INTERNAL_ERROR
+static inline int opusgpu_copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    return hipMemcpy(dst, src, bytes, kind) == hipSuccess ? OPUSGPU_OK : OPUSGPU_INTERNAL_ERROR;
+}
+
+// quant_all_bands(encode = 0) as a per-call hook: the record the host entry (quant_bands_hook.hip) hands to the decoder's lane
+// build (celt_dec_kernel.hip), and the launcher. In: pulses, tf_res, the scalars, seed, the range decoder's fields + the packet
+// bytes; out: X (both channels), collapse_masks, seed, the decoder's fields.
+struct opusgpu_qab_dec_record {
+    int16_t X[2 * 960];
+    int32_t pulses[21], tf_res[21];
+    int32_t shortBlocks, spread, dual_stereo, intensity, total_bits, balance, codedBands;
+    uint32_t seed;
+    uint32_t ec_storage, ec_end_offs, ec_end_window, ec_offs, ec_rng, ec_val, ec_ext;
+    int32_t ec_nend_bits, ec_nbits_total, ec_rem, ec_error, pad;
+    unsigned char collapse_masks[2 * 21 + 6];
+    unsigned char buf[1280];
+};
+extern "C" int opusgpu_launch_quant_all_bands_dec(opusgpu_qab_dec_record *d_rec);

@@ -48,11 +48,13 @@ extern "C" int32_t opusgpu_celt_pitch_xcorr(const int16_t *x, const int16_t *y, 
         hipMalloc(&d_m, 4) != hipSuccess)
         rc = OPUSGPU_ALLOC_FAIL;
     if (rc == OPUSGPU_OK) {
-        (void)hipMemcpy(d_x, x, xb, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_y, y, yb, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_m, &h_m, 4, hipMemcpyHostToDevice);         // maxcorr starts at 1 (pitch.c:224)
-        hipLaunchKernelGGL(ca::pitch_xcorr_kernel, dim3((max_pitch + 255) / 256), dim3(256), 0, 0, d_x, d_y, d_c, len, max_pitch, d_m);
-        rc = opusgpu_check_launch();
+        rc = opusgpu_copy(d_x, x, xb, hipMemcpyHostToDevice);
+        if (rc == OPUSGPU_OK) rc = opusgpu_copy(d_y, y, yb, hipMemcpyHostToDevice);
+        if (rc == OPUSGPU_OK) rc = opusgpu_copy(d_m, &h_m, 4, hipMemcpyHostToDevice);         // maxcorr starts at 1 (pitch.c:224)
+        if (rc == OPUSGPU_OK) {
+            hipLaunchKernelGGL(ca::pitch_xcorr_kernel, dim3((max_pitch + 255) / 256), dim3(256), 0, 0, d_x, d_y, d_c, len, max_pitch, d_m);
+            rc = opusgpu_check_launch();
+        }
         if (rc == OPUSGPU_OK && (hipMemcpy(xcorr, d_c, cb, hipMemcpyDeviceToHost) != hipSuccess ||
                                  hipMemcpy(&h_m, d_m, 4, hipMemcpyDeviceToHost) != hipSuccess))
             rc = OPUSGPU_INTERNAL_ERROR;

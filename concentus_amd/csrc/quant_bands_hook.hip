@@ -67,15 +67,47 @@ extern "C" void opusgpu_quant_all_bands(int encode, const void *m, int start, in
                                         int *tf_res, int32_t total_bits, int32_t balance, void *ec, int LM, int codedBands, uint32_t *seed,
                                         int arch)
 {
-    (void)collapse_masks; (void)seed; (void)arch;
-    if (!m || !X || !bandE || !pulses || !tf_res || !ec) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+    (void)arch;
+    if (!m || !X || (encode && !bandE) || !pulses || !tf_res || !ec) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
     const ref_celt_mode_head *mh = (const ref_celt_mode_head *)m;
     ref_ec_ctx *e = (ref_ec_ctx *)ec;
-    if (encode != 1 || !Y || start != 0 || end != 21 || LM != 3 || mh->Fs != 48000 || mh->overlap != 120 || mh->nbEBands != 21 ||
+    if ((encode != 0 && encode != 1) || !Y || start != 0 || end != 21 || LM != 3 || mh->Fs != 48000 || mh->overlap != 120 || mh->nbEBands != 21 ||
         e->storage > 1275 || !e->buf || (shortBlocks != 0 && shortBlocks != 8)) {
         opusgpu_set_last_error(OPUSGPU_UNIMPLEMENTED);
         return;
     }
+    if (!encode) {
+        // decoder side (celt_decoder.c:977): the range DEcoder reads ec->buf, X / Y receive the decoded normalised bands,
+        // collapse_masks and *seed are outputs the caller uses afterwards (anti_collapse, st->rng)
+        if (!collapse_masks || !seed) { opusgpu_set_last_error(OPUSGPU_BAD_ARG); return; }
+        opusgpu_qab_dec_record *hp = (opusgpu_qab_dec_record *)calloc(1, sizeof(opusgpu_qab_dec_record)), *d = nullptr;
+        if (!hp) { opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL); return; }
+        for (int k = 0; k < 21; k++) { hp->pulses[k] = pulses[k]; hp->tf_res[k] = tf_res[k]; }
+        hp->shortBlocks = shortBlocks; hp->spread = spread; hp->dual_stereo = dual_stereo; hp->intensity = intensity;
+        hp->total_bits = total_bits; hp->balance = balance; hp->codedBands = codedBands; hp->seed = *seed;
+        hp->ec_storage = e->storage; hp->ec_end_offs = e->end_offs; hp->ec_end_window = e->end_window; hp->ec_offs = e->offs;
+        hp->ec_rng = e->rng; hp->ec_val = e->val; hp->ec_ext = e->ext; hp->ec_nend_bits = e->nend_bits;
+        hp->ec_nbits_total = e->nbits_total; hp->ec_rem = e->rem; hp->ec_error = e->error;
+        memcpy(hp->buf, e->buf, e->storage);
+        int rc = hipMalloc(&d, sizeof(*hp)) == hipSuccess ? OPUSGPU_OK : OPUSGPU_ALLOC_FAIL;
+        if (rc == OPUSGPU_OK) rc = opusgpu_copy(d, hp, sizeof(*hp), hipMemcpyHostToDevice);
+        if (rc == OPUSGPU_OK) rc = opusgpu_launch_quant_all_bands_dec(d);
+        if (rc == OPUSGPU_OK) rc = opusgpu_copy(hp, d, sizeof(*hp), hipMemcpyDeviceToHost);
+        if (d) (void)hipFree(d);
+        opusgpu_set_last_error(rc);
+        if (rc == OPUSGPU_OK) {
+            memcpy(X, hp->X, sizeof(int16_t) * 960);
+            memcpy(Y, hp->X + 960, sizeof(int16_t) * 960);
+            memcpy(collapse_masks, hp->collapse_masks, 42);
+            *seed = hp->seed;
+            e->end_offs = hp->ec_end_offs; e->end_window = hp->ec_end_window; e->offs = hp->ec_offs; e->rng = hp->ec_rng;
+            e->val = hp->ec_val; e->ext = hp->ec_ext; e->nend_bits = hp->ec_nend_bits; e->nbits_total = hp->ec_nbits_total;
+            e->rem = hp->ec_rem; e->error = hp->ec_error;
+        }
+        free(hp);
+        return;
+    }
+    (void)collapse_masks; (void)seed;
     static_assert(sizeof(((ca::QabRecord *)nullptr)->buf) >= 1276, "range coder buffer");
     ca::QabRecord *hp = (ca::QabRecord *)calloc(1, sizeof(ca::QabRecord));      // 6.4 KB: kept off a codec thread's stack
     if (!hp) { opusgpu_set_last_error(OPUSGPU_ALLOC_FAIL); return; }

@@ -163,7 +163,14 @@ extern "C" int opusgpu_silk_encode_frame_FIX(void *psEnc, int32_t *pnBytesOut, v
         opusgpu_set_last_error(OPUSGPU_BAD_ARG);
         return -1;
     }
-    if (rd_int(sCmn + OPUSGPU_REF_OFF_SLP, OPUSGPU_REF_OFF_LP_MODE) != 0 || (!prefill && rd_int(sCmn, OPUSGPU_REF_OFF_LBRR_ENABLED) != 0)) {
+    // Everything a later stage would refuse is refused HERE, before the first write to *psEnc, so that OPUSGPU_UNIMPLEMENTED
+    // always means "state untouched -- the caller may run the reference's own function on this frame instead" (a wrap shim
+    // does exactly that: oracle/ref_gpuframe_wrap.c): a bandwidth-transition low-pass (silk_LP_variable_cutoff, sLP.mode != 0),
+    // in-band LBRR, 12 kHz (the pitch estimator's 2/3 resampler is not provided: find_pitch_lags_record_ok), and a frame
+    // length the shell coder's 16-sample blocks do not divide (encode_pulses; 10 ms at 12 kHz is the only such case and is
+    // already out with 12 kHz).
+    if (rd_int(sCmn + OPUSGPU_REF_OFF_SLP, OPUSGPU_REF_OFF_LP_MODE) != 0 || (!prefill && rd_int(sCmn, OPUSGPU_REF_OFF_LBRR_ENABLED) != 0) ||
+        fs_kHz == 12 || (frame_length & 15) != 0) {
         opusgpu_set_last_error(OPUSGPU_UNIMPLEMENTED);
         return -1;
     }

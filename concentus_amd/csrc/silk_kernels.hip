@@ -470,8 +470,8 @@ extern "C" void opusgpu_silk_burg_modified_c(int32_t *res_nrg, int *res_nrg_Q, i
         if (d_in) (void)hipFree(d_in);
         return;
     }
-    (void)hipMemcpy(d_in, &h_in, sizeof(h_in), hipMemcpyHostToDevice);
-    int rc = opusgpu_silk_burg_modified_batch(d_in, d_out, 1, nullptr);
+    int rc = opusgpu_copy(d_in, &h_in, sizeof(h_in), hipMemcpyHostToDevice);
+    if (rc == OPUSGPU_OK) rc = opusgpu_silk_burg_modified_batch(d_in, d_out, 1, nullptr);
     if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     (void)hipFree(d_in);
     (void)hipFree(d_out);

@@ -76,14 +76,22 @@ SYMBOLS = [
     ("opusgpu_exp_rotation1", None, [_vp, _i, _i, _i, _i]),
     ("opusgpu_renormalise_vector", None, [_vp, _i, _i, _i]),
     ("opusgpu_quant_all_bands", None, [_i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, C.c_int32, C.c_int32, _vp, _i, _i, _vp, _i]),
+    ("opusgpu_ec_enc_script", _i, [_vp, _vp, _i]),
+    ("opusgpu_ec_dec_script", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_NSQ", None, [_vp] * 13 + [_i, _i]),
     ("opusgpu_silk_NSQ_del_dec", None, [_vp] * 13 + [_i, _i]),
+]
+
+# include/opusgpu_diag.h: the stage-stamp builds, in a library of their own (tools/stage_profile*.py only)
+DIAG_LIB_PATH = os.path.join(_HERE, "libopusgpu_diag.so")
+DIAG_SYMBOLS = [
     ("opusgpu_decode_lane_diag", _i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_back_lane_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("opusgpu_encode_batch_diag", _i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, C.c_size_t, _vp, _vp]),
 ]
 
 _lib = None
+_diag = None
 
 
 class OpusGpuError(RuntimeError):
@@ -108,6 +116,22 @@ def load():
                 fn.argtypes = args
         _lib = lib
     return _lib
+
+
+def load_diag():
+    """The diagnostic library (stage stamps); raises if it has not been built (`make -C concentus_amd/csrc diag`)."""
+    global _diag
+    if _diag is None:
+        load()
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise ImportError("concentus_amd: %s is missing -- `make -C concentus_amd/csrc diag`" % DIAG_LIB_PATH)
+        lib = C.CDLL(DIAG_LIB_PATH)
+        for name, res, args in DIAG_SYMBOLS:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _diag = lib
+    return _diag
 
 
 def strerror(code):

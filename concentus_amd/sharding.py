@@ -19,6 +19,8 @@ class PendingGather:
     (out, lens, rng) on the destination rank (None elsewhere). The exchange runs on the backend's own stream, so kernels
     launched between gather_packets(...) and wait() overlap it."""
 
+    width = None                    # row width of the gathered slab (after trimming), set by gather_packets
+
     def __init__(self, works, finish):
         self._works, self._finish = works, finish
 
@@ -33,9 +35,14 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
     """Gather the per-rank packet slabs / lengths / final ranges to rank `dst`.
     Shards may differ in size by one frame, so every rank pads to the largest shard first. `sizes` = the shard sizes of
     all ranks when the caller knows them (they follow from shard_range); otherwise they are exchanged first.
-    `trim`: send only the first max(lens) bytes of every packet row (rounded up to 16) instead of the whole stride -- a
-    VBR slab is mostly padding (mean packet ~320 B in a 1500-byte row); costs one device->host read of the maximum. The
-    gathered slab then has that trimmed row width.
+    `trim`: send only the first W bytes of every packet row (rounded up to 16) instead of the whole stride -- a VBR slab is
+    mostly padding (mean packet ~320 B in a 1500-byte row). The gathered slab then has that trimmed row width.
+      trim=True   W = the longest packet of this exchange over all ranks: one all_reduce(MAX) and one device->host read --
+                  a host synchronisation per call, meant for the first exchange of a job (see trim_width());
+      trim=<int>  W given by the caller -- the CBR packet size, or trim_width() of an earlier exchange: NO host read, nothing
+                  on the critical path of the step. The lengths travel with the rows, so the receiver can always tell whether a
+                  packet was longer than W (PendingGather.truncated / the `lens` returned): a caller that re-uses an earlier
+                  width on new input must check that and repeat the exchange of that step with trim=False.
     Returns (out, lens, rng) concatenated in rank order on `dst`, None elsewhere; with async_op=True a PendingGather."""
     import torch
     import torch.distributed as dist
@@ -51,11 +58,13 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
         raise ValueError("gather_packets: sizes do not describe this job")
     n_max = max(sizes)
     width = out.shape[1] if out.dim() == 2 else None
-    if trim and width is not None:
-        w = (lens.max() if lens.numel() else torch.zeros((), dtype=lens.dtype, device=lens.device)).to(torch.int64).reshape(1)
-        dist.all_reduce(w, op=dist.ReduceOp.MAX)              # one width for the job; the only host read of the exchange
-        w = min(width, max(16, (int(w.item()) + 15) & ~15))
+    if trim is not False and trim is not None and width is not None:
+        if trim is True:
+            w = trim_width(lens, width)
+        else:
+            w = min(width, max(16, (int(trim) + 15) & ~15))   # the caller's bound: no collective, no host read
         out = out[:, :w]
+        width = w
 
     def pad(t):
         if t.shape[0] == n_max:
@@ -81,8 +90,27 @@ def gather_packets(out, lens, rng, world=None, dst=0, sizes=None, trim=False, as
         return tuple(torch.cat([b[:sizes[r]] for r, b in enumerate(bufs)], dim=0) for _t, bufs in bufs_all)
 
     if async_op:
-        return PendingGather(works, finish)
+        pg = PendingGather(works, finish)
+        pg.width = width
+        return pg
     return finish()
+
+
+def trim_width(lens, stride):
+    """Row width (a multiple of 16, at most `stride`) that holds the longest packet of `lens` on ANY rank: one
+    all_reduce(MAX) + one device->host read. Call it once -- on the first (warm-up) step of a job or per change of
+    input -- and pass the result as gather_packets(trim=<int>) afterwards."""
+    import torch
+    import torch.distributed as dist
+    w = (lens.max() if lens.numel() else torch.zeros((), dtype=lens.dtype, device=lens.device)).to(torch.int64).reshape(1)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    return min(int(stride), max(16, (int(w.item()) + 15) & ~15))
+
+
+def truncated(lens, width):
+    """True if any packet of a gathered (or local) `lens` is longer than the row width it travelled with."""
+    return bool(lens.numel()) and int(lens.max().item()) > int(width)
 
 
 def mixed_counts(n_units, silk_eighths=1):

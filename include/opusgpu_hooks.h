@@ -76,14 +76,32 @@ void opusgpu_silk_NSQ_del_dec(const void *psEncC, void *NSQ, void *psIndices, co
  * reference has no RTCD slot for it (plain extern, celt/bands.h): a build that wants the GPU version renames / --wraps the
  * symbol to this one. `ec` is the tree's ec_ctx INCLUDING its trailing EC_DIFF field (celt/entcode.h:63-94,
  * 56 bytes on x86-64): buf[0 .. storage) is copied to the device, the range coder runs there, and every field plus the
- * buffer come back. Supported: encode == 1, the static 48 kHz mode (m->Fs 48000, overlap 120, nbEBands 21), start 0, end 21,
+ * buffer come back. Supported: the static 48 kHz mode (m->Fs 48000, overlap 120, nbEBands 21), start 0, end 21,
  * LM 3, stereo (Y != NULL), storage <= 1275; anything else -> OPUSGPU_UNIMPLEMENTED in opusgpu_get_last_error() and nothing
- * is touched. As in the reference's non-RESYNTH build the caller's X, Y, collapse_masks and *seed carry no information the
- * encoder reads afterwards (celt_encoder.c:2130-2160); they are left as they were. */
+ * is touched.
+ *   encode == 1 (celt_encoder.c:2130): as in the reference's non-RESYNTH build the caller's X, Y, collapse_masks and *seed carry
+ *     no information the encoder reads afterwards (celt_encoder.c:2130-2160); they are left as they were.
+ *   encode == 0 (celt_decoder.c:977; bandE may be NULL as there): ec is the range DEcoder, its buffer is only read; X and Y
+ *     receive the decoded normalised bands (bins [0, 800) of each channel, the bins of the 21 bands), collapse_masks[42] and
+ *     *seed are written, every ec_ctx field comes back -- the decoder's lane kernel run for one stream. */
 void opusgpu_quant_all_bands(int encode, const void *m, int start, int end, int16_t *X, int16_t *Y, unsigned char *collapse_masks,
                              const int32_t *bandE, int *pulses, int shortBlocks, int spread, int dual_stereo, int intensity,
                              int *tf_res, int32_t total_bits, int32_t balance, void *ec, int LM, int codedBands, uint32_t *seed,
                              int arch);
+
+/* ec_enc_* / ec_dec_* -- opus-fix/celt/entenc.c:62-508, celt/entdec.c:93-317, celt/laplace.c:38-134. The reference has no hook
+ * slot for its range coder (plain externs, celt/entenc.h, celt/entdec.h) and one symbol is a few dozen instructions, so the
+ * boundary is a SCRIPT: the calls the caller would have made on `ec` (the tree's ec_enc / ec_dec incl. EC_DIFF, storage <= 1280),
+ * listed as ops[n][4] = {opcode, a, b, c}, run back to back on the device in one call; `ec` (and, encoding, its buffer) comes back
+ * as the reference's functions would have left it, `out[i]` receives the value decoder call i returns. Opcodes and argument
+ * order: concentus_amd/csrc/ec_script.h (0 ec_encode(fl,fh,ft) 1 ec_encode_bin 2 ec_enc_bit_logp(val,logp) 3 ec_enc_uint(fl,ft)
+ * 4 ec_enc_bits(fl,bits) 5 ec_enc_patch_initial_bits(val,nbits) 6 ec_enc_shrink(size) 7 ec_enc_done 8 ec_laplace_encode(value,fs,
+ * decay) 9 ec_enc_icdf; 16 ec_decode(ft) 17 ec_decode_bin 18 ec_dec_update(fl,fh,ft) 19 ec_dec_bit_logp 20 ec_dec_uint
+ * 21 ec_dec_bits 22 ec_laplace_decode(fs,decay) 23 ec_tell 24 ec_tell_frac 25 ec_dec_icdf). Returns OPUSGPU_OK, or
+ * OPUSGPU_BAD_ARG if any argument is one the reference's celt_assert()s reject (nothing is run then). tests/test_ec_script_gpu.py
+ * replays celt/tests/test_unit_entropy.c through these entry points beside the compiled reference. */
+int opusgpu_ec_enc_script(void *ec, const int32_t *ops, int n_ops);
+int opusgpu_ec_dec_script(void *ec, const int32_t *ops, int n_ops, int32_t *out);
 
 /* silk_find_LPC_FIX(psEncC, NLSF_Q15, x, minInvGain_Q30) -- opus-fix/silk/fixed/find_LPC_FIX.c:37-151 (declared in
  * silk/fixed/main_FIX.h, called at silk/fixed/find_pred_coefs_FIX.c:136): reads psEncC->subfr_length / nb_subfr /
@@ -200,7 +218,10 @@ void opusgpu_silk_prefilter_FIX(void *psEnc, const void *psEncCtrl, int32_t xw_Q
  * psRangeEnc is the tree's ec_enc (celt/entcode.h:63-94 incl. its trailing EC_DIFF), storage <= 1280. The frame hook runs the
  * reference function's sequence with every computing call replaced by the hook of the same name above and the bitrate loop's
  * decisions by opusgpu_silk_rate_control_batch (include/opusgpu_silk.h); it returns 0, or -1 with opusgpu_get_last_error() set --
- * OPUSGPU_UNIMPLEMENTED for a frame inside a bandwidth transition (sLP.mode != 0, silk_LP_variable_cutoff) or with in-band LBRR.
+ * OPUSGPU_UNIMPLEMENTED for a frame inside a bandwidth transition (sLP.mode != 0, silk_LP_variable_cutoff), with in-band LBRR, or
+ * at 12 kHz (the pitch estimator's 2/3 resampler is not provided). UNIMPLEMENTED is decided before the first write to *psEnc: the
+ * encoder state is untouched and a wrap shim hands the frame to __real_silk_encode_frame_FIX (INTEGRATION.md,
+ * oracle/ref_gpuframe_wrap.c; the reference's caller only silk_assert()s the return value, silk/enc_API.c:499).
  * Link-level drop-in: -Wl,--wrap=silk_encode_frame_FIX; tests/test_hooks_gpu.py runs the unmodified reference
  * encoder with exactly that redirection and compares its packets with the plain reference's. */
 #define OPUSGPU_REF_OFF_INPUT_BUF 5144                 /* silk_encoder_state.inputBuf */

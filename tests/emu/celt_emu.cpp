@@ -400,3 +400,30 @@ extern "C" void emu_silk_rate_control(opusgpu_silk_rate_ctl *ctl, const int32_t 
 {
     for (long r = 0; r < n; r++) ca::silk_rate_control_step_dev(ctl[r], nBits[r]);
 }
+
+// ---- range coder scripts (csrc/ec_script.h) on the host build: the same device code the hooks opusgpu_ec_enc_script /
+// opusgpu_ec_dec_script run, for the CPU tier (tests/test_ec_script_cpu.py). ec = the 11 fields in the order of refcap's ec_pack:
+// storage end_offs end_window nend_bits nbits_total offs rng val ext rem error.
+#include "../../concentus_amd/csrc/ec_script.h"
+extern "C" int emu_ec_enc_script(int32_t *ec, unsigned char *buf, const int32_t *ops, int n)
+{
+    RangeEnc e;
+    e.buf = buf; e.storage = (u32)ec[0]; e.end_offs = (u32)ec[1]; e.end_window = (u32)ec[2]; e.nend_bits = ec[3]; e.nbits_total = ec[4];
+    e.offs = (u32)ec[5]; e.rng = (u32)ec[6]; e.val = (u32)ec[7]; e.ext = (u32)ec[8]; e.rem = ec[9]; e.error = ec[10];
+    if (!ec_enc_script_ok(ops, n)) return -1;
+    ec_enc_run_script(e, ops, n);
+    ec[0] = (int32_t)e.storage; ec[1] = (int32_t)e.end_offs; ec[2] = (int32_t)e.end_window; ec[3] = e.nend_bits; ec[4] = e.nbits_total;
+    ec[5] = (int32_t)e.offs; ec[6] = (int32_t)e.rng; ec[7] = (int32_t)e.val; ec[8] = (int32_t)e.ext; ec[9] = e.rem; ec[10] = e.error;
+    return 0;
+}
+extern "C" int emu_ec_dec_script(int32_t *ec, const unsigned char *buf, const int32_t *ops, int n, int32_t *out)
+{
+    RangeDec d;
+    d.buf = buf; d.storage = (u32)ec[0]; d.end_offs = (u32)ec[1]; d.end_window = (u32)ec[2]; d.nend_bits = ec[3]; d.nbits_total = ec[4];
+    d.offs = (u32)ec[5]; d.rng = (u32)ec[6]; d.val = (u32)ec[7]; d.ext = (u32)ec[8]; d.rem = ec[9]; d.error = ec[10];
+    if (!ec_dec_script_ok(ops, n)) return -1;
+    ec_dec_run_script(d, ops, n, out);
+    ec[1] = (int32_t)d.end_offs; ec[2] = (int32_t)d.end_window; ec[3] = d.nend_bits; ec[4] = d.nbits_total;
+    ec[5] = (int32_t)d.offs; ec[6] = (int32_t)d.rng; ec[7] = (int32_t)d.val; ec[8] = (int32_t)d.ext; ec[9] = d.rem; ec[10] = d.error;
+    return 0;
+}

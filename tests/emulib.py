@@ -52,6 +52,8 @@ def lib():
         hdrs = [os.path.join(ROOT, "concentus_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "concentus_amd", "csrc")) if f.endswith(".h")]
         newest = max(os.path.getmtime(f) for f in hdrs + [src])
         if not os.path.exists(PATH) or os.path.getmtime(PATH) < newest:
+            if any(k.startswith(("ROCP", "ROCPROFILER", "HSA_TOOLS")) for k in os.environ):
+                raise RuntimeError("%s must be built before the profiler starts (a plain python3 run does it)" % PATH)
             subprocess.check_call(["g++", "-O2", "-fwrapv", "-std=c++17", "-shared", "-fPIC", "-w", "-o", PATH, src])
         _lib = C.CDLL(PATH)
         assert _lib.emu_sizeof_state() == C.sizeof(State)

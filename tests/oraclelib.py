@@ -12,6 +12,8 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(PATH):
+            if any(k.startswith(("ROCP", "ROCPROFILER", "HSA_TOOLS")) for k in os.environ):
+                raise RuntimeError("%s must be built before the profiler starts (a plain python3 run does it)" % PATH)
             subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
         _lib = C.CDLL(PATH)
     return _lib

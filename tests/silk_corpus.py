@@ -14,6 +14,7 @@ later call re-opens instead of re-encoding. Nothing here is imported by the prod
 """
 import ctypes as C
 import os
+import shutil
 import sys
 
 import numpy as np
@@ -378,6 +379,14 @@ _LAYOUT = {
 }
 
 
+_TOOL_ENV = ("ROCP", "ROCPROFILER", "HSA_TOOLS", "ROCTRACER", "OMNITRACE")
+
+
+def under_profiler():
+    """True when this process was started by rocprofv3 (its tool libraries are preloaded into every child)."""
+    return any(k.startswith(_TOOL_ENV) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+
+
 def _files(cache, kind, n, mode):
     out = {}
     for name, sz in _LAYOUT[kind]:
@@ -403,9 +412,18 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
                          "%s%s_%d_%s_%d%s" % (kind, "_v2" if kind.startswith("chain") else "", n, "-".join(map(str, complexities)), seed,
                                               "" if variant == "wb20" else "_" + variant))
-    os.makedirs(cache, exist_ok=True)
     done = os.path.join(cache, "done")
     if not os.path.exists(done):
+        if under_profiler():
+            # the capture runs worker interpreters (and, for a stale capture library, make / gcc): never from a process the
+            # profiler has instrumented -- tools/round_profile*.sh build every corpus in a plain python3 step first
+            raise RuntimeError("silk_corpus: %s is not built and this process runs under rocprofv3; build it first with "
+                               "`python3 tests/silk_corpus.py %d %s`" % (cache, n, kind))
+        # built in a directory of its own and renamed into place: two processes asking for the same corpus at the same
+        # time each build a private copy, the first rename wins, the loser's copy is dropped
+        final, cache = cache, "%s.tmp.%d" % (cache, os.getpid())
+        shutil.rmtree(cache, ignore_errors=True)
+        os.makedirs(cache)
         for f in _files(cache, kind, n, "w+").values():
             f.flush()
         jobs, row = [], 0
@@ -421,10 +439,24 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
                 _capture_segment(j)
         else:
             import multiprocessing as mp
-            with mp.get_context("spawn").Pool(workers) as pool:
-                for _ in pool.imap_unordered(_capture_segment, jobs):
-                    pass
-        open(done, "w").write("ok\n")
+            # the workers are CPU-only children: no profiler / tool preloads in their environment
+            saved = {k: os.environ.pop(k) for k in list(os.environ) if k == "LD_PRELOAD" or k.startswith(_TOOL_ENV)}
+            try:
+                pool = mp.get_context("spawn").Pool(workers)
+                try:
+                    for _ in pool.imap_unordered(_capture_segment, jobs):
+                        pass
+                finally:
+                    pool.close()          # let the workers exit by themselves (terminate() = SIGTERM, which a
+                    pool.join()           # profiler's signal handler reports as "Aborted")
+            finally:
+                os.environ.update(saved)
+        open(os.path.join(cache, "done"), "w").write("ok\n")
+        try:
+            os.rename(cache, final)
+        except OSError:
+            shutil.rmtree(cache, ignore_errors=True)          # somebody else finished the same corpus first
+        cache = final
     return _files(cache, kind, n, "r")
 
 

@@ -34,6 +34,21 @@ def test_header_symbols_all_exported():
     assert not missing, missing
 
 
+def test_diag_library_is_separate():
+    """The stage-stamp diagnostic builds live in libopusgpu_diag.so (include/opusgpu_diag.h), not in the product library."""
+    lib = _ensure_built()
+    src = open(os.path.join(ROOT, "include", "opusgpu_diag.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"\b(opusgpu_\w+)\s*\(", src))
+    assert declared == {name for name, _, _ in lib.DIAG_SYMBOLS}
+    out = subprocess.check_output(["nm", "-D", "--defined-only", lib.LIB_PATH], text=True)
+    assert not [l for l in out.splitlines() if "_diag" in l], "diagnostic code in the product library"
+    if os.path.exists(lib.DIAG_LIB_PATH):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", lib.DIAG_LIB_PATH], text=True)
+        exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+        assert declared <= exported
+
+
 def test_python_binding_covers_header():
     lib = _ensure_built()
     bound = {name for name, _, _ in lib.SYMBOLS}

@@ -524,10 +524,89 @@ def test_quant_all_bands_hook_on_the_reference_encoders_own_calls(L, ref):
         st = int(e.storage)
         assert np.array_equal(buf[:st], want_buf[:st]), (r, np.nonzero(buf[:st] != want_buf[:st])[0][:8])
     assert seen_short == {0, 8}
-    e2 = reflib.EcCtx()
-    L.opusgpu_quant_all_bands(0, mode, 0, 21, p(X), p(Y), p(cm), p(bandE), p(pulses), 0, 2, 0, 0, p(tf_res), 100, 0, C.byref(e2), 3, 21,
-                              C.byref(seed), 0)
-    assert L.opusgpu_get_last_error() == -5                      # decode side: not through this hook
+
+
+def test_quant_all_bands_hook_decode_side_on_the_reference_decoders_own_calls(L, ref):
+    """opusgpu_quant_all_bands(encode = 0, ...) against quant_all_bands of the compiled reference ON THE CALLS THE REFERENCE DECODER
+    ITSELF MAKES (celt_decoder.c:977): oracle/_ref/libopus_ref_celtcap.so records the arguments and the range decoder before each
+    call and, after it, the decoded normalised bands, the collapse masks, the LCG seed and the range decoder while opus_decode()
+    runs over packets of several rates (32 kb/s: folding, noise fill, intensity stereo; 96 / 128 kb/s; transient frames).
+    Compared: X / Y over the coded bins, all 42 collapse masks, *seed, every ec_ctx field."""
+    import encode_cases as ec
+    cap_path = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_celtcap.so")
+    if not os.path.exists(cap_path):
+        pytest.skip("oracle/_ref/libopus_ref_celtcap.so did not travel")
+    cap = C.CDLL(cap_path)
+    if not hasattr(cap, "refcap_start_qab_dec"):
+        pytest.skip("capture library predates the decoder-side capture")
+    cap.opus_encoder_create.restype = C.c_void_p
+    cap.opus_decoder_create.restype = C.c_void_p
+    cap.opus_encoder_ctl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    cap.opus_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int, C.c_int]
+    gm = ec.golden_module()
+    cap.refcap_start_qab_dec(4096)
+    nframes = 0
+    for kind, br, vbr, cx, seed in (("noise", 96000, 1, 10, 81), ("music", 32000, 1, 10, 82), ("gmusic", 128000, 0, 5, 13371337),
+                                    ("music", 40000, 1, 8, 83), ("noise", 36000, 0, 10, 84)):
+        pcm = gm.synth_pcm(kind, 12, seed)
+        err = C.c_int()
+        enc = C.c_void_p(cap.opus_encoder_create(48000, 2, 2051, C.byref(err)))
+        dec = C.c_void_p(cap.opus_decoder_create(48000, 2, C.byref(err)))
+        for req, v in ((4002, br), (4006, vbr), (4020, 0), (4010, cx), (4036, 16)):
+            cap.opus_encoder_ctl(enc, req, v)
+        out = (C.c_ubyte * 1500)()
+        dpcm = np.zeros((960, 2), np.int16)
+        for f in range(pcm.shape[0]):
+            fr = np.ascontiguousarray(pcm[f])
+            nb = cap.opus_encode(enc, p(fr), 960, out, 1500)
+            assert nb > 0
+            assert cap.opus_decode(dec, out, nb, p(dpcm), 960, 0) == 960
+            nframes += 1
+    n = cap.refcap_count_qab_dec()
+    assert n == nframes == 60
+    sz = cap.refcap_sizeof_qab_dec()
+    raw = np.zeros((n, sz), np.uint8)
+    cap.refcap_get_qab_dec(p(raw))
+    mode = reflib.lib().opus_custom_mode_create(48000, 960, C.byref(C.c_int()))
+    o = 0
+    fields = {}
+    for name, nbytes in (("pulses", 84), ("tf_res", 84), ("ints", 24), ("tb", 8), ("seeds", 8), ("ec_in", 44), ("ec_out", 44),
+                         ("buf", 1280), ("X_out", 1920), ("Y_out", 1920), ("cm_out", 42)):
+        fields[name] = (o, nbytes)
+        o += nbytes
+    assert o <= sz
+    get = lambda r, k, dt: np.ascontiguousarray(raw[r, fields[k][0]:fields[k][0] + fields[k][1]]).view(dt).copy()
+    seen_short, seen_dual, folded = set(), set(), 0
+    for r in range(n):
+        pulses, tf_res = get(r, "pulses", np.int32), get(r, "tf_res", np.int32)
+        shortBlocks, spread, dual, intensity, LM, coded = [int(v) for v in get(r, "ints", np.int32)]
+        total_bits, balance = [int(v) for v in get(r, "tb", np.int32)]
+        seed_in, seed_out = [int(v) for v in get(r, "seeds", np.uint32)]
+        ein, eout = get(r, "ec_in", np.int32), get(r, "ec_out", np.int32)
+        buf = get(r, "buf", np.uint8)
+        seen_short.add(shortBlocks)
+        seen_dual.add(dual)
+        folded += int((pulses[:coded] <= 0).any())
+        e = reflib.EcCtx()
+        e.buf = buf.ctypes.data_as(C.POINTER(C.c_ubyte))
+        (e.storage, e.end_offs, e.end_window, e.nend_bits, e.nbits_total, e.offs, e.rng, e.val, e.ext, e.rem, e.error) = \
+            [int(v) & 0xffffffff if i in (0, 1, 2, 5, 6, 7, 8) else int(v) for i, v in enumerate(ein)]
+        e.EC_DIFF = 0
+        X, Y = np.full(960, 0x5555, np.int16), np.full(960, 0x5555, np.int16)
+        cm = np.full(42, 0xEE, np.uint8)
+        seed = C.c_uint32(seed_in)
+        L.opusgpu_quant_all_bands(0, mode, 0, 21, p(X), p(Y), p(cm), None, p(pulses), shortBlocks, spread, dual, intensity,
+                                  p(tf_res), total_bits, balance, C.byref(e), LM, coded, C.byref(seed), 0)
+        assert L.opusgpu_get_last_error() == 0, r
+        got = np.array([e.storage, e.end_offs, e.end_window, e.nend_bits, e.nbits_total, e.offs, e.rng, e.val, e.ext, e.rem, e.error],
+                       dtype=np.int64) & 0xffffffff
+        assert np.array_equal(got, eout.astype(np.int64) & 0xffffffff), (r, got, eout)
+        assert seed.value == seed_out, (r, seed.value, seed_out)
+        assert np.array_equal(cm, get(r, "cm_out", np.uint8)), (r, cm, get(r, "cm_out", np.uint8))
+        wx, wy = get(r, "X_out", np.int16), get(r, "Y_out", np.int16)
+        assert np.array_equal(X[:800], wx[:800]), (r, np.nonzero(X[:800] != wx[:800])[0][:8])
+        assert np.array_equal(Y[:800], wy[:800]), (r, np.nonzero(Y[:800] != wy[:800])[0][:8])
+    assert seen_short == {0, 8} and folded > 0, (seen_short, seen_dual, folded)
 
 
 GPUFRAME = os.path.join(ROOT, "oracle", "_ref", "libopus_ref_gpuframe.so")
@@ -560,6 +639,9 @@ def _encode_all(lib, pcm, fs, frame, ctls, max_bytes=1500):
     ("nb 12k cbr cx3", 8000, 160, ((4002, 12000), (4006, 0), (4010, 3)), 1500, 1),
     ("wb 10 ms vbr cx8 squeezed", 16000, 160, ((4002, 40000), (4006, 1), (4020, 0), (4010, 8)), 40, 3),
     ("wb 40 ms vbr cx7", 16000, 640, ((4002, 28000), (4006, 1), (4020, 0), (4010, 7)), 1500, 3),
+    # 12 kHz (mediumband) lies outside the hook's operating region: it must say OPUSGPU_UNIMPLEMENTED with the encoder state
+    # untouched, the wrap shim then runs the reference's own function on the frame -- same packets, no failures
+    ("mb 12 kHz vbr cx6: every frame declined", 12000, 240, ((4002, 20000), (4006, 1), (4020, 0), (4010, 6)), 1500, 1),
 ])
 def test_reference_encoder_with_its_silk_frame_function_replaced_emits_the_same_packets(L, name, fs, frame, ctls, max_bytes, mask):
     """The drop-in claim at packet level: opus_encode() of the UNMODIFIED reference, linked with --wrap so that every call of
@@ -571,7 +653,12 @@ def test_reference_encoder_with_its_silk_frame_function_replaced_emits_the_same_
     if not (reflib.available() and os.path.exists(GPUFRAME)):
         pytest.skip("oracle/_ref did not travel")
     nframes = 60 * 320 // frame if fs == 16000 else 60
-    pcm = silk_corpus.synth_voice(nframes * frame * (16000 // fs) + 16000, 424242)[16000:][::16000 // fs]      # skip the leading pause
+    if fs == 12000:
+        v = silk_corpus.synth_voice(nframes * 320 + 16000, 424242)[16000:].astype(np.float64)                   # 16 kHz -> 12 kHz, linear
+        t = np.arange(nframes * frame) * (16000.0 / 12000.0)
+        pcm = np.interp(t, np.arange(len(v)), v).astype(np.int16)
+    else:
+        pcm = silk_corpus.synth_voice(nframes * frame * (16000 // fs) + 16000, 424242)[16000:][::16000 // fs]  # skip the leading pause
     common = ((4012, 0), (4016, 0), (4014, 0), (4036, 16))
     want = _encode_all(C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libopus_ref.so")), pcm, fs, frame, ctls + common, max_bytes)
     hooked = C.CDLL(GPUFRAME)
@@ -579,6 +666,11 @@ def test_reference_encoder_with_its_silk_frame_function_replaced_emits_the_same_
     got = _encode_all(hooked, pcm, fs, frame, ctls + common, max_bytes)
     assert hooked.refgpu_failures() == 0, (name, hooked.refgpu_failures(), hooked.refgpu_first_error())
     assert hooked.refgpu_calls(0) >= nframes * (frame // (fs // 50) if frame > fs // 50 else 1), "every SILK frame went through the hook"
+    hooked.refgpu_fallbacks.restype = C.c_int
+    if fs == 12000:
+        assert hooked.refgpu_fallbacks() == hooked.refgpu_calls(0), "12 kHz frames are declined before any state is touched"
+    else:
+        assert hooked.refgpu_fallbacks() == 0, "inside the operating region nothing falls back to the reference"
     if mask & 2:
         assert hooked.refgpu_calls(1) >= nframes
     diff = [k for k in range(len(want)) if want[k] != got[k]]

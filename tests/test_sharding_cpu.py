@@ -44,7 +44,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import emulib
     import encode_cases as ec
-    from concentus_amd.sharding import gather_packets, shard_range
+    from concentus_amd.sharding import gather_packets, shard_range, trim_width, truncated
     pcm, pk, ln, rg = ec.load_case("noise_vbr_indep")          # 24 frames; world 2 -> 12 + 12, world 5 -> uneven
     n = pcm.shape[0] - 1                                        # 23: uneven split
     lo, hi = shard_range(n, rank, world)
@@ -63,9 +63,18 @@ def _worker(rank, world, port, q):
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     pending = gather_packets(t_out, t_lens, t_rng, world, sizes=sizes, trim=True, async_op=True)
     res2 = pending.wait()
+    # ... and the steady-state form: the width learnt once (one collective + host read), then passed as a number so that
+    # the exchange itself synchronises with nothing; a width that is too small must be detectable from the lengths
+    w = trim_width(t_lens, t_out.shape[1])
+    p3 = gather_packets(t_out, t_lens, t_rng, world, sizes=sizes, trim=w, async_op=True)
+    res3 = p3.wait()
+    p4 = gather_packets(t_out, t_lens, t_rng, world, sizes=sizes, trim=64, async_op=True)
+    res4 = p4.wait()
     if rank == 0:
         try:
-            for what, rr in (("sharded", res), ("sharded, trimmed + async", res2)):
+            assert p3.width == w == pending.width and w % 16 == 0 and w >= int(ln[:n].max()) and not truncated(res3[1], p3.width)
+            assert p4.width == 64 and res4[0].shape[1] == 64 and truncated(res4[1], p4.width)
+            for what, rr in (("sharded", res), ("sharded, trimmed + async", res2), ("sharded, width given", res3)):
                 o, l, r = (t.numpy() for t in rr)
                 assert o.shape[0] == n and (o.shape[1] == 1280 if what == "sharded" else o.shape[1] >= int(ln[:n].max()))
                 ec.assert_packets_equal(o, l, r.view(np.uint32), pk[:n], ln[:n], rg[:n], what)
@@ -73,7 +82,7 @@ def _worker(rank, world, port, q):
         except AssertionError as e:
             q.put("FAIL: %s" % e)
     else:
-        assert res is None and res2 is None
+        assert res is None and res2 is None and res3 is None and res4 is None
     dist.barrier()
     dist.destroy_process_group()
 

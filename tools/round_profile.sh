@@ -19,6 +19,7 @@ for w in mdct decode; do
   python3 $R/tools/pmc_traffic.py $O/${w}_pmc_fetch $O/${w}_pmc_write $O/traffic_$w.json > /dev/null
 done
 for w in mdct decode silk silk_deldec silk_lpc mixed celt_streams; do
+  case $w in silk*|mixed) python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $O/prepare_$w.err || { echo "$w prepare failed"; continue; };; esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/prof_$w.err
   echo "$w rc=$?"
 done

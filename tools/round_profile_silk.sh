@@ -7,7 +7,10 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for w in silk_frames silk_frames_cbr silk_analysis silk_pred silk_nlsf; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 > $O/bench_prof_$w.json 2> $O/prof_$w.err
+  # corpus capture (worker interpreters) and any stale checker library are built by a PLAIN python3 run first: nothing
+  # under the profiler may start child processes (bench.py refuses to, tests/silk_corpus.py under_profiler)
+  python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_prepare_$w.json 2> $O/prepare_$w.err || { echo "$w prepare failed"; continue; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_prof_$w.json 2> $O/prof_$w.err
   echo "$w rc=$?"; cut -c1-200 $O/bench_prof_$w.json
 done
 w=silk_frames

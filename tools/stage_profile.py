@@ -35,8 +35,9 @@ lens = torch.zeros(n, dtype=torch.int32, device="cuda")
 rg = torch.zeros(n, dtype=torch.int32, device="cuda")
 st = torch.zeros((4096, NS), dtype=torch.int64, device="cuda")
 L = ca.lib.load()
+D = ca.lib.load_diag()
 ws = torch.empty((L.opusgpu_encode_workspace_bytes(n),), dtype=torch.uint8, device="cuda")
-g = L.opusgpu_encode_batch_diag(C.byref(cfg), d.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
+g = D.opusgpu_encode_batch_diag(C.byref(cfg), d.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
                                 ws.data_ptr(), ws.numel(), st.data_ptr(), None)
 torch.cuda.synchronize()
 assert g == 0, g
@@ -48,7 +49,7 @@ print(json.dumps(res, indent=1))
 if len(sys.argv) > 3 and sys.argv[3] == "lane":
     # the back phase again, one lane per frame, on the same FrameMid records: cycles per wavefront (64 frames)
     st2 = torch.zeros((4096, NS), dtype=torch.int64, device="cuda")
-    g = L.opusgpu_back_lane_diag(C.byref(cfg), ws.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
+    g = D.opusgpu_back_lane_diag(C.byref(cfg), ws.data_ptr(), out.data_ptr(), stride, lens.data_ptr(), rg.data_ptr(), n,
                                  st2.data_ptr(), None)
     torch.cuda.synchronize()
     assert g == 0, g

@@ -18,10 +18,11 @@ pcm = torch.from_numpy(np.random.default_rng(3).integers(-8192, 8192, size=(n, 9
 pk, ln, _ = ca.encode_independent(pcm)
 dec = ca.OpusDecoderBatch(n)
 L = ca.lib.load()
+D = ca.lib.load_diag()
 st = torch.zeros((4096, 32), dtype=torch.int64, device="cuda")
 ret = torch.zeros(n, dtype=torch.int32, device="cuda")
 rng = torch.zeros(n, dtype=torch.int32, device="cuda")
-rc = L.opusgpu_decode_lane_diag(dec._states.data_ptr(), pk.data_ptr(), pk.shape[1], ln.data_ptr(), ret.data_ptr(), rng.data_ptr(), n,
+rc = D.opusgpu_decode_lane_diag(dec._states.data_ptr(), pk.data_ptr(), pk.shape[1], ln.data_ptr(), ret.data_ptr(), rng.data_ptr(), n,
                                 st.data_ptr(), None)
 torch.cuda.synchronize()
 assert rc == 0 and (ret.cpu().numpy() == 960).all()
