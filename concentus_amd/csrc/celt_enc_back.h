@@ -449,6 +449,9 @@ enum { LDS_COL = 64 };          // elements between consecutive entries of one l
 // (i16)a * (i16)b as ONE full-rate instruction: the 24-bit multiplier on the sign-extended low halves (SDWA selects)
 CA_DEV i32 mul16x16_lo(i32 a, i32 b)
 {
+#if defined(CA_HOST_EMU)
+    return (i32)(i16)a * (i32)(i16)b;
+#endif
     i32 r;
     asm("v_mul_i32_i24_sdwa %0, sext(%1), sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0"
         : "=v"(r) : "v"(a), "v"(b));

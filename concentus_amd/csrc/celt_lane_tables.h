@@ -35,7 +35,12 @@ struct LdsTables {
     CA_LDS_TABLES(X)
 #undef X
 };
-__shared__ LdsTables g_lds_tables;
+#if defined(CA_HOST_EMU)
+#define CA_SHARED static            // the lane build on a CPU (tests/emu/celt_lane_emu.cpp): the workgroup's LDS is a plain array
+#else
+#define CA_SHARED __shared__
+#endif
+CA_SHARED LdsTables g_lds_tables;
 // Per-lane scratch of the 64 frames of the workgroup, [element][lane] (30 KB in one block). Every lane owns ONE column,
 // and the two wavefronts of a workgroup (OPUSGPU_LANE_FRAMES=32) run independently, so an array may only ever be
 // addressed with the element size its region is laid out for -- a 16-bit view of the 32-bit region would land in other
@@ -46,10 +51,18 @@ __shared__ LdsTables g_lds_tables;
 // Stages that run while the PVQ search is idle (band re-arrangement, TF analysis) use the 16-bit part as one array of up
 // to LANE_SCRATCH_N bins through g_lds_pvq16.
 enum { LANE_SCRATCH_N = 144 };
-__shared__ __attribute__((aligned(16))) int16_t g_lds_scratch[(LANE_SCRATCH_N + 2 * 48) * 64];
+CA_SHARED __attribute__((aligned(16))) int16_t g_lds_scratch[(LANE_SCRATCH_N + 2 * 48) * 64];
 #define g_lds_pvq16 (ca::g_lds_scratch)
 #define g_lds_xs (ca::g_lds_scratch + 96 * 64)
 #define g_lds_pvq32 (reinterpret_cast<int32_t *>(ca::g_lds_scratch + LANE_SCRATCH_N * 64))
+#if defined(CA_HOST_EMU)
+static inline void fill_lds_tables()
+{
+#define X(T, NAME, N) for (int k = 0; k < N; k++) g_lds_tables.NAME##_[k] = NAME[k];
+    CA_LDS_TABLES(X)
+#undef X
+}
+#else
 __device__ __forceinline__ void fill_lds_tables()
 {
 #define X(T, NAME, N) for (int k = threadIdx.x; k < N; k += blockDim.x) g_lds_tables.NAME##_[k] = NAME[k];
@@ -57,6 +70,7 @@ __device__ __forceinline__ void fill_lds_tables()
 #undef X
     __syncthreads();
 }
+#endif
 }  // namespace ca
 #define CLT_tell_frac_correction g_lds_tables.CLT_tell_frac_correction_
 #define CLT_pvq_u_data g_lds_tables.CLT_pvq_u_data_

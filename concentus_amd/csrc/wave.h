@@ -178,6 +178,13 @@ CA_DEV uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlan
 //   LdsCol<T>  one lane's column of an [element][64] LDS array (address space 3, stride 64 elements)
 //   Priv<T>    an array in this lane's private memory (stride 1)
 #if defined(CA_LANE_FRAME)
+// (with CA_HOST_EMU as well -- tests/emu/celt_lane_emu.cpp, host clang -- the qualifiers stay in the types and mean nothing to
+// the x86 back end: the lane build's own code paths run on a CPU, one "lane" of a 64-column LDS image)
+#if defined(CA_HOST_EMU)
+#define CA_MEMBER inline
+#else
+#define CA_MEMBER __device__ __forceinline__
+#endif
 #define CA_AS_LDS __attribute__((address_space(3)))
 #define CA_AS_GLB __attribute__((address_space(1)))
 namespace ca {
@@ -185,16 +192,16 @@ typedef CA_AS_GLB int16_t x16_t;
 typedef int v4i __attribute__((ext_vector_type(4)));      // 16 bytes moved by one instruction through an address-space-qualified pointer
 template <class T> struct LdsCol {
     CA_AS_LDS T *p;
-    __device__ __forceinline__ CA_AS_LDS T &operator[](int j) const { return p[j * 64]; }
-    __device__ __forceinline__ LdsCol operator+(int o) const { LdsCol r; r.p = p + o * 64; return r; }
+    CA_MEMBER CA_AS_LDS T &operator[](int j) const { return p[j * 64]; }
+    CA_MEMBER LdsCol operator+(int o) const { LdsCol r; r.p = p + o * 64; return r; }
 };
-template <class T> __device__ __forceinline__ LdsCol<T> lds_col(CA_AS_LDS T *p) { LdsCol<T> r; r.p = p; return r; }
+template <class T> CA_MEMBER LdsCol<T> lds_col(CA_AS_LDS T *p) { LdsCol<T> r; r.p = p; return r; }
 template <class T> struct Priv {
     T *p;
-    __device__ __forceinline__ T &operator[](int j) const { return p[j]; }
-    __device__ __forceinline__ Priv operator+(int o) const { Priv r; r.p = p + o; return r; }
+    CA_MEMBER T &operator[](int j) const { return p[j]; }
+    CA_MEMBER Priv operator+(int o) const { Priv r; r.p = p + o; return r; }
 };
-template <class T> __device__ __forceinline__ Priv<T> priv(T *p) { Priv<T> r; r.p = p; return r; }
+template <class T> CA_MEMBER Priv<T> priv(T *p) { Priv<T> r; r.p = p; return r; }
 }
 #else
 namespace ca { typedef int16_t x16_t; }
@@ -208,10 +215,10 @@ namespace ca {
 template <class T> struct LP {
     T *p;
     int s;
-    __device__ __forceinline__ T &operator[](int j) const { return p[j * s]; }
-    __device__ __forceinline__ LP operator+(int o) const { LP r; r.p = p + o * s; r.s = s; return r; }
+    CA_MEMBER T &operator[](int j) const { return p[j * s]; }
+    CA_MEMBER LP operator+(int o) const { LP r; r.p = p + o * s; r.s = s; return r; }
 };
-template <class T> __device__ __forceinline__ LP<T> lp_make(T *p, int stride) { LP<T> r; r.p = p; r.s = stride; return r; }
+template <class T> CA_MEMBER LP<T> lp_make(T *p, int stride) { LP<T> r; r.p = p; r.s = stride; return r; }
 #else
 template <class T> using LP = T *;
 template <class T> CA_DEV LP<T> lp_make(T *p, int) { return p; }

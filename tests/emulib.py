@@ -7,7 +7,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "tests", "emu", "libcelt_emu.so")
+LANE_PATH = os.path.join(ROOT, "tests", "emu", "libcelt_lane_emu.so")
+HOST_CLANG = "/opt/rocm/lib/llvm/bin/clang++"         # the lane build's address-space qualifiers and ext vectors need clang
 _lib = None
+_lane = None
 
 
 class Config(C.Structure):
@@ -58,3 +61,19 @@ def lib():
         _lib = C.CDLL(PATH)
         assert _lib.emu_sizeof_state() == C.sizeof(State)
     return _lib
+
+
+def lane_lib():
+    """Host build of the LANE-PER-FRAME variant of the sources (tests/emu/celt_lane_emu.cpp): the code paths of
+    celt_back_lane_kernel / celt_decode_lane_kernel on a CPU, one frame at a time in one column of a 64-column LDS image."""
+    global _lane
+    if _lane is None:
+        src = os.path.join(ROOT, "tests", "emu", "celt_lane_emu.cpp")
+        d = os.path.join(ROOT, "concentus_amd", "csrc")
+        newest = max(os.path.getmtime(f) for f in [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")] + [src])
+        if not os.path.exists(LANE_PATH) or os.path.getmtime(LANE_PATH) < newest:
+            if any(k.startswith(("ROCP", "ROCPROFILER", "HSA_TOOLS")) for k in os.environ):
+                raise RuntimeError("%s must be built before the profiler starts" % LANE_PATH)
+            subprocess.check_call([HOST_CLANG, "-O1", "-fwrapv", "-std=c++17", "-shared", "-fPIC", "-w", "-o", LANE_PATH, src])
+        _lane = C.CDLL(LANE_PATH)
+    return _lane

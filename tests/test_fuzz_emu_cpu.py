@@ -16,10 +16,16 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", 
                                 reason="oracle/_ref not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303])
-def test_random_settings_match_reference(seed):
+@pytest.mark.parametrize("seed,lane", [(101, False), (202, False), (303, False), (404, True), (505, True), (606, True)])
+def test_random_settings_match_reference(seed, lane):
+    """lane = True: the lane-per-frame variant of the sources (tests/emu/celt_lane_emu.cpp: what celt_back_lane_kernel /
+    celt_decode_lane_kernel run), in a random column of the LDS image"""
     gm = ec.golden_module()
-    emu = emulib.lib()
+    if lane and not os.path.exists(emulib.HOST_CLANG):
+        pytest.skip("host clang of the ROCm image not present")
+    emu = emulib.lane_lib() if lane else emulib.lib()
+    enc_fn = emu.emu_lane_celt_encode_frames if lane else emu.emu_celt_encode_frames_split
+    dec_fn = emu.emu_lane_celt_decode_frames if lane else emu.emu_celt_decode_frames
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     rng = np.random.default_rng(seed)
     for _t in range(20):
@@ -39,7 +45,9 @@ def test_random_settings_match_reference(seed):
         r2 = np.zeros(n, np.uint32)
         st = emulib.fresh_states(n // fps) if fps > 1 else None
         pcmc = np.ascontiguousarray(pcm)
-        emu.emu_celt_encode_frames_split(C.byref(cfg), p(st) if st is not None else None, p(pcmc), n, fps, p(out), 1280, p(lens), p(r2))
+        if lane:
+            emu.emu_lane_set_slot(int(rng.integers(0, 64)))
+        assert enc_fn(C.byref(cfg), p(st) if st is not None else None, p(pcmc), n, fps, p(out), 1280, p(lens), p(r2)) == 0
         ec.assert_packets_equal(out, lens, r2, pk, ln, rg, str(what))
         if (ln > 1).all():
             pkc, lnc = np.ascontiguousarray(pk), np.ascontiguousarray(ln.astype(np.int32))
@@ -47,5 +55,5 @@ def test_random_settings_match_reference(seed):
             got = np.zeros((n, 960, 2), np.int16)
             gr = np.zeros(n, np.uint32)
             gret = np.zeros(n, np.int32)
-            emu.emu_celt_decode_frames(p(pkc), pkc.shape[1], p(lnc), n, fps, p(got), p(gr), p(gret))
+            assert dec_fn(p(pkc), pkc.shape[1], p(lnc), n, fps, p(got), p(gr), p(gret)) == 0
             assert np.array_equal(gret, wret) and np.array_equal(gr, wr) and np.array_equal(got, want), what

@@ -37,3 +37,4 @@ for f in glob.glob("$O/stats_*/**/*kernel_stats.csv", recursive=True):
     for i, row in enumerate(csv.DictReader(open(f))):
         if i < 8: print("   %-70s calls %s avg %.1f us  %s%%" % (row["Name"][:70], row["Calls"], float(row["AverageNs"]) / 1e3, row["Percentage"]))
 PY
+cd $R && timeout -k 10 200 python3 tools/stage_profile.py 16384 noise lane > $O/stage_profile.txt 2>&1; tail -4 $O/stage_profile.txt | cut -c1-1500
