@@ -2,6 +2,7 @@
 // stamps (-DCA_STAGE_TIMING). Never used for reported throughput; the per-stage cycle totals of each
 // wavefront go to a buffer of their own and feed no output.
 #define CA_LANE_FRAME 1
+#define CA_LANE_SLOTS 264             // 16-bit slots of a lane's LDS column (celt_enc_front.h LS_SLOTS, celt_enc_lane.h)
 #define CA_STAGE_TIMING 1
 #include "celt_lane_tables.h"
 #include "celt_enc.h"
@@ -19,9 +20,7 @@ __global__ __launch_bounds__(64) void celt_back_lane_diag_kernel(opusgpu_celt_co
     const int n = blockIdx.x * 64 + threadIdx.x;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + threadIdx.x);
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + threadIdx.x);
-    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + threadIdx.x);
+    F.col = (CA_AS_LDS i16 *)(g_lds_scratch + threadIdx.x);
     unsigned long long acc[NSTAGES];
     for (int k = 0; k < NSTAGES; k++) acc[k] = 0;
     StageClock clk;

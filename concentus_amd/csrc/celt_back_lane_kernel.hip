@@ -2,9 +2,11 @@
 //
 // The back phase is a serial chain of ~160 small steps per frame; with one
 // wavefront per frame most of its vector instructions carry 1-16 useful lanes. This build compiles the
-// same sources with LANES == 1 (wave.h, CA_LANE_FRAME): 64 frames share a wavefront, every instruction
-// does work for all of them, the per-frame working set lives in private memory.
+// sources with LANES == 1 (wave.h, CA_LANE_FRAME): 64 frames share a wavefront, every instruction does work
+// for all of them. The per-frame working set is NOT in private memory (round 3, celt_enc_lane.h): a lane owns
+// a column of 264 16-bit slots of the workgroup's LDS, its rows in HBM and registers.
 #define CA_LANE_FRAME 1
+#define CA_LANE_SLOTS 264             // 16-bit slots of a lane's LDS column (celt_enc_front.h LS_SLOTS, celt_enc_lane.h)
 #include "celt_lane_tables.h"
 #include "celt_enc.h"
 #include "opusgpu_internal.h"
@@ -29,9 +31,7 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_c
     const int n = blockIdx.x * 64 + slot;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
-    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + slot);
+    F.col = (CA_AS_LDS i16 *)(g_lds_scratch + slot);
     opusgpu_celt_state *st = states ? states + n : nullptr;
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;
@@ -51,9 +51,7 @@ void celt_back_lane16_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states
     const int n = blockIdx.x * 64 + slot;
     if (n >= nframes) return;
     BackLds F;
-    F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
-    F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + slot);
+    F.col = (CA_AS_LDS i16 *)(g_lds_scratch + slot);
     opusgpu_celt_state *st = states ? states + n : nullptr;
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;

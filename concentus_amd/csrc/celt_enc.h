@@ -78,10 +78,8 @@ CA_DEV void load_state(FrameCtx &fc, L &F, const opusgpu_celt_state *st, int C)
 
 // Writes the stream state back (st_out may equal the input state: everything read from it -- the
 // prefilter history in particular -- has been consumed by the time this runs).
-template <class L>
-CA_DEV void store_state(const FrameCtx &fc, L &F, opusgpu_celt_state *st)
+CA_DEV void store_state_scalars(const FrameCtx &fc, opusgpu_celt_state *st)
 {
-    const int C = fc.C;
     // prefilter_mem <- last 1024 samples of [history | unfiltered new]  (celt_encoder.c:1179-1187):
     // new[j] = j < 64 ? old[960 + j] : xf_unfiltered[j - 64]. The unfiltered samples were overwritten by the
     // MDCT output, so the kernel keeps them in HBM: see celt_encode_frame (hist_new).
@@ -110,12 +108,21 @@ CA_DEV void store_state(const FrameCtx &fc, L &F, opusgpu_celt_state *st)
         st->spec_avg = fc.spec_avg;
         st->reserved[0] = fc.stereo_narrow;
     }
+}
+
+#if !defined(CA_LANE_FRAME)
+template <class L>
+CA_DEV void store_state(const FrameCtx &fc, L &F, opusgpu_celt_state *st)
+{
+    const int C = fc.C;
+    store_state_scalars(fc, st);
     for (int k = lane(); k < C * NB; k += LANES) {
         st->oldBandE[k] = F.oldBandE[k];
         st->oldLogE[k] = F.oldLogE[k];
         st->oldLogE2[k] = F.oldLogE2[k];
     }
 }
+#endif
 
 // ---- hand-off record between the two kernels (HBM, one per frame in flight, pointer-free) ----------
 struct FrameMid {
@@ -141,6 +148,12 @@ struct FrameMid {
     i16 pad16[2];
     i16 X[2 * FRAME];
 };
+
+}  // namespace ca
+#if defined(CA_LANE_FRAME)
+#include "celt_enc_lane.h"
+#endif
+namespace ca {
 
 // Scalars that travel between the phases next to the range-coder state and the FrameCtx.
 struct MidScalars {
@@ -448,9 +461,21 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
     i32 temporal_vbr = 0;
     for (int mdct_pass = secondMdct ? 0 : 1;;) {
         CA_STAMP(5);
-        compute_mdcts_wave(F, fc, mdct_pass == 0 ? 0 : shortBlocks);
-        CA_STAMP(30);
-        band_energies_wave(F, fc, mdct_pass == 0 ? F.bandLogE2 : F.bandLogE);
+        if constexpr (L::XF_CHANNELS == 1) {
+            // one coefficient buffer: a channel is transformed, measured and (except in the long-block pre-pass, whose only
+            // product is bandLogE2) normalised before the next one takes the buffer. Normalising here is speculative -- the
+            // transient patch below may order the frame transformed again, which simply repeats all of this with short blocks --
+            // and exact: a band's gain depends on that channel's own band energy only (bands.c:146-168).
+            for (int c = 0; c < C; c++) {
+                compute_mdct_channel(F, c, mdct_pass == 0 ? 0 : shortBlocks);
+                band_energies_channel(F, c, mdct_pass == 0 ? F.bandLogE2 : F.bandLogE);
+                if (mdct_pass != 0) normalise_bands_channel(F, c);
+            }
+        } else {
+            compute_mdcts_wave(F, fc, mdct_pass == 0 ? 0 : shortBlocks);
+            CA_STAMP(30);
+            band_energies_wave(F, fc, mdct_pass == 0 ? F.bandLogE2 : F.bandLogE);
+        }
         CA_STAMP(31);
         if (mdct_pass == 0) {
             for (int k = lane(); k < C * NB; k += LANES) F.bandLogE2[k] = (i16)(F.bandLogE2[k] + (shl16(LM, 10) >> 1));
@@ -464,7 +489,8 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
             tf_estimate = 3277;                                  // QCONST16(.2f,14)
             break;
         }
-        CA_TAP("freq", F.xf, sizeof(F.xf)); CA_TAP("bandE", F.bandE, sizeof(F.bandE)); CA_TAP("bandLogE", F.bandLogE, sizeof(F.bandLogE));
+        if constexpr (L::XF_CHANNELS != 1) CA_TAP("freq", F.xf, sizeof(F.xf));
+        CA_TAP("bandE", F.bandE, sizeof(F.bandE)); CA_TAP("bandLogE", F.bandLogE, sizeof(F.bandLogE));
         {   // temporal VBR (celt_encoder.c:1803-1819)
             i32 follow = -10240;
             i32 frame_avg = 0;
@@ -515,7 +541,7 @@ CA_DEVFN void celt_encode_front_phase(L &F, const opusgpu_celt_config &cfg, cons
 
     CA_STAMP(5);
     // 10. normalise
-    normalise_bands_wave(F, fc);
+    if constexpr (L::XF_CHANNELS != 1) normalise_bands_wave(F, fc);
 
     if constexpr (!L::IN_IS_GLOBAL) CA_TAP("X", F.in, 2 * FRAME * 2);
     CA_STAMP(6);
@@ -581,6 +607,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
 #if defined(CA_LANE_FRAME)
     F.x16 = (x16_t *)const_cast<i16 *>(mid->X);
     F.packet = out;
+    F.mid = const_cast<FrameMid *>(mid);
 #endif
     enc.buf = F.packet + 1;
     enc.storage = uni(mid->ec_storage); enc.end_offs = uni(mid->ec_end_offs); enc.end_window = uni(mid->ec_end_window);
@@ -592,6 +619,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         i16 *X = frame_X(F);
         for (int k = lane(); k < 2 * FRAME; k += LANES) X[k] = mid->X[k];
 #endif
+#if !defined(CA_LANE_FRAME)
         for (int k = lane(); k < 2 * NB; k += LANES) {
             F.bandE[k] = mid->bandE[k];
             F.bandLogE[k] = mid->bandLogE[k];
@@ -600,6 +628,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
             F.oldLogE[k] = mid->oldLogE[k];
             F.oldLogE2[k] = mid->oldLogE2[k];
         }
+#endif
         for (int k = lane(); k < 32; k += LANES) F.packet[1 + k] = mid->packet_head[k];
     }
     i32 tell;
@@ -613,23 +642,47 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         else if (effectiveBytes < 100) lambda = 4;
         else lambda = 3;
         lambda *= 2;
+#if defined(CA_LANE_FRAME)
+        tf_select = tf_analysis_lane(F, isTransient, lambda, tf_estimate, tf_chan);
+    } else {
+        F.tf_bits = isTransient ? (1u << NB) - 1 : 0u;
+        tf_select = 0;
+    }
+    // the column is free from here to the PVQ walk: the energies move in (celt_enc_lane.h, slot map)
+    {
+        const Col loge = mcol(F, M_LOGE), olde = mcol(F, M_OLDE);
+        CA_UNROLL_LANE
+        for (int k = 0; k < 2 * NB; k++) { loge[k] = mid->bandLogE[k]; olde[k] = mid->oldBandE[k]; }
+    }
+#else
         tf_select = tf_analysis_wave(F, isTransient, lambda, tf_estimate, tf_chan);
     } else {
         for (int i = lane(); i < end; i += LANES) F.tf_res[i] = isTransient;
         wave_sync();
         tf_select = 0;
     }
+#endif
 
     CA_TRACE("tf done tf_select=%d", tf_select); CA_TRACE("");
     CA_STAMP(7);
     // 12. coarse energy
+#if defined(CA_LANE_FRAME)
+    quant_coarse_energy_lane(F, fc, enc, (u32)total_bits, nbAvailableBytes, cfg.complexity >= 4, cfg.loss_rate);
+#else
     quant_coarse_energy_wave(F, fc, enc, (u32)total_bits, nbAvailableBytes, cfg.complexity >= 4, cfg.loss_rate);
+#endif
 
     CA_TRACE("coarse done tell=%d", ec_tell(enc)); CA_TRACE("");
+#if !defined(CA_LANE_FRAME)
     CA_TAP("oldBandE_after_coarse", F.oldBandE, sizeof(F.oldBandE)); CA_TAP("error", F.error, sizeof(F.error));
+#endif
     CA_STAMP(8);
     // 13. tf_encode, spread, dynalloc, trim
+#if defined(CA_LANE_FRAME)
+    tf_encode_lane(F, enc, isTransient, tf_select);
+#else
     tf_encode_wave(F, enc, isTransient, tf_select);
+#endif
     if (ec_tell(enc) + 4 <= total_bits) {
         if (shortBlocks || cfg.complexity < 3 || nbAvailableBytes < 10 * C) {
             fc.spread_decision = cfg.complexity == 0 ? SPREAD_NONE : SPREAD_NORMAL;
@@ -641,6 +694,9 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     i32 tot_boost;
     // opus_encode() hands int16 input over with lsb_depth 16; opus_encode_native takes the min with the ctl value
     // (src/opus_encoder.c:2022, :1034)
+#if defined(CA_LANE_FRAME)
+    const i32 maxDepth = dynalloc_analysis_lane(F, imin(16, cfg.lsb_depth), isTransient, celt_vbr, constrained_vbr, effectiveBytes, &tot_boost);
+#else
     const i32 maxDepth = dynalloc_analysis_wave(F, fc, imin(16, cfg.lsb_depth), isTransient, celt_vbr, constrained_vbr,
                                                 effectiveBytes, &tot_boost);
     for (int i = lane(); i < NB; i += LANES) {                                     // init_caps (celt.c:246-256)
@@ -648,6 +704,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         F.cap[i] = ((CLT_cache_caps50[NB * (2 * LM + C - 1) + i] + 64) * C * Nb) >> 2;
     }
     wave_sync();
+#endif
     int dynalloc_logp = 6;
     total_bits <<= BITRES;
     i32 total_boost = 0;
@@ -657,7 +714,11 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         int quanta = imin(width << BITRES, imax(6 << BITRES, width));
         int dynalloc_loop_logp = dynalloc_logp;
         int boost = 0, j;
+#if defined(CA_LANE_FRAME)
+        const int off_i = mcol(F, M_OFFSETS)[i], cap_i = alloc_cap(i);
+#else
         const int off_i = uni(F.offsets[i]), cap_i = uni(F.cap[i]);
+#endif
         for (j = 0; tell + (dynalloc_loop_logp << BITRES) < total_bits - total_boost && boost < cap_i; j++) {
             int flag = j < off_i;
             ec_enc_bit_logp(enc, flag, (u32)dynalloc_loop_logp);
@@ -668,7 +729,11 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
             dynalloc_loop_logp = 1;
         }
         if (j) dynalloc_logp = imax(2, dynalloc_logp - 1);
+#if defined(CA_LANE_FRAME)
+        mcol(F, M_OFFSETS)[i] = (i16)boost;                                        // < cap + quanta <= 28 424
+#else
         st0(&F.offsets[i], boost);
+#endif
     }
     wave_sync();
     int dual_stereo = 0;
@@ -734,7 +799,11 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     const int anti_collapse_rsv = isTransient && LM >= 2 && bits >= ((LM + 2) << BITRES) ? (1 << BITRES) : 0;
     bits -= anti_collapse_rsv;
     const int signalBandwidth = end - 1;
+#if defined(CA_LANE_FRAME)
+    AllocOut ao = compute_allocation_lane(F, enc, alloc_trim, fc.intensity, dual_stereo, bits, fc.lastCodedBands, signalBandwidth);
+#else
     AllocOut ao = compute_allocation_wave(F, enc, C, alloc_trim, fc.intensity, dual_stereo, bits, fc.lastCodedBands, signalBandwidth);
+#endif
     fc.intensity = ao.intensity;
     dual_stereo = ao.dual_stereo;
     const int codedBands = ao.codedBands;
@@ -742,10 +811,17 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     else fc.lastCodedBands = codedBands;
 
     CA_TRACE("alloc done codedBands=%d", codedBands); CA_TRACE("");
+#if !defined(CA_LANE_FRAME)
     CA_TAP("pulses", F.pulses, sizeof(F.pulses)); CA_TAP("fine_quant", F.fine_quant, sizeof(F.fine_quant)); CA_TAP("tf_res", F.tf_res, sizeof(F.tf_res));
+#endif
     CA_STAMP(11);
     // 16. fine energy
+#if defined(CA_LANE_FRAME)
+    quant_fine_energy_lane(F, enc);
+    park_energy_state_lane(F);                     // the PVQ walk takes slots 0..239 of the column
+#else
     quant_fine_energy_wave(F, enc, C);
+#endif
 
     CA_STAMP(12);
     // 17. PVQ
@@ -759,6 +835,22 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         int anti_collapse_on = fc.consec_transient < 2;
         ec_enc_bits(enc, (u32)anti_collapse_on, 1);
     }
+#if defined(CA_LANE_FRAME)
+    quant_energy_finalise_lane(F, enc, nbCompressedBytes * 8 - ec_tell(enc));
+    fc.prefilter_period = pitch_index;
+    fc.prefilter_gain = gain1;
+    fc.prefilter_tapset = prefilter_tapset;
+    if (st_out) {
+        // energy histories of the stream (celt_encoder.c:2215-2238), straight from the hand-off record to the state
+        for (int k = 0; k < C * NB; k++) {
+            const i16 ob = silence ? (i16)-28672 : mid->oldBandE[k];
+            const i16 ol = mid->oldLogE[k];
+            st_out->oldBandE[k] = ob;
+            if (!isTransient) { st_out->oldLogE2[k] = ol; st_out->oldLogE[k] = ob; }
+            else { st_out->oldLogE2[k] = mid->oldLogE2[k]; st_out->oldLogE[k] = (i16)imin(ol, ob); }
+        }
+    }
+#else
     quant_energy_finalise_wave(F, enc, nbCompressedBytes * 8 - ec_tell(enc), C);
     if (silence)
         for (int k = lane(); k < C * NB; k += LANES) F.oldBandE[k] = -28672;
@@ -771,6 +863,7 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
     } else {
         for (int k = lane(); k < C * NB; k += LANES) F.oldLogE[k] = (i16)imin(F.oldLogE[k], F.oldBandE[k]);
     }
+#endif
     if (isTransient || transient_got_disabled) fc.consec_transient++;
     else fc.consec_transient = 0;
     fc.rng = enc.rng;
@@ -787,7 +880,11 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
         // opus_packet_pad to max_data_bytes: a CELT CBR packet already has that size (ret == max_data_bytes)
         if (ret != max_data_bytes) enc.error = -1;
     }
+#if defined(CA_LANE_FRAME)
+    if (st_out) store_state_scalars(fc, st_out);
+#else
     if (st_out) store_state(fc, F, st_out);
+#endif
     if (lane() == 0)
         for (int k = ret; k < ((ret + 3) & ~3); k++) F.packet[k] = 0;               // deterministic pad bytes
     wave_sync();

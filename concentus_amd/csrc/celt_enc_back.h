@@ -277,6 +277,17 @@ CA_DEVFN void quant_energy_finalise_wave(L &F, RangeEnc &enc, int bits_left, int
 }
 
 // ---- PVQ ---------------------------------------------------------------------------------------------
+// what quant_all_bands reads per band, wherever the build keeps it
+#if defined(CA_LANE_FRAME)
+template <class L> CA_DEV i32 frame_pulses(L &F, int i) { return lds_col(F.col)[LS_PULSES + i]; }
+template <class L> CA_DEV int frame_tf_change(L &F, int i) { return (CLT_tf_select_table + LM3 * 8)[F.tf_sel + (int)((F.tf_bits >> i) & 1u)]; }
+template <class L> CA_DEV i32 frame_bandE(L &F, int k) { return F.mid->bandE[k]; }
+#else
+template <class L> CA_DEV i32 frame_pulses(L &F, int i) { return uni(F.pulses[i]); }
+template <class L> CA_DEV int frame_tf_change(L &F, int i) { return uni(F.tf_res[i]); }
+template <class L> CA_DEV i32 frame_bandE(L &F, int k) { return uni(F.bandE[k]); }
+#endif
+
 struct BandCtx {                 // uniform; cf. struct band_ctx (bands.c:623-635)
     int i, intensity, spread, tf_change;
     i32 remaining_bits;
@@ -373,7 +384,7 @@ template <class L, class PI>
 CA_DEVFN void encode_pulses_wave(L &F, RangeEnc &ec, int N, int K, PI y)
 {
     u32 idx;
-    if (LANES == 1) {
+    if constexpr (LANES == 1) {
         // one lane owns the frame: icwrs as the reference walks it (cwrs.c:440-456), no suffix-sum array
         int j = N - 1;
         idx = (u32)(y[j] < 0);
@@ -871,7 +882,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
         if (stereo) {
             if (itheta == 0) {
                 // intensity_stereo (bands.c:336-360)
-                i32 bl = uni(F.bandE[i]), br = uni(F.bandE[i + NB]);
+                i32 bl = frame_bandE(F, i), br = frame_bandE(F, i + NB);
                 int shift = celt_zlog2(imax(bl, br)) - 13;
                 i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
                 i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
@@ -925,7 +936,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
             for (int j = lane(); j < N; j += LANES) Y[j] = (i16)(-Y[j]);
         wave_sync();
         {
-            i32 bl = uni(F.bandE[i]), br = uni(F.bandE[i + NB]);
+            i32 bl = frame_bandE(F, i), br = frame_bandE(F, i + NB);
             int shift = celt_zlog2(imax(bl, br)) - 13;
             i32 left = (i16)vshr32(bl, shift), right = (i16)vshr32(br, shift);
             i32 norm = (i16)(1 + celt_sqrt(add32(1, add32(mul16_16(left, left), mul16_16(right, right)))));
@@ -1236,7 +1247,7 @@ template <class L>
 CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM)
 {
     CA_STAMP_F(F, 22);
-    CA_AS_LDS i16 *const S = F.lds_pvq16;                      // slot 0 of this lane's column
+    CA_AS_LDS i16 *const S = F.col;                            // slot 0 of this lane's column
     const int Nband = N;
     int N_B = (int)((u32)N / (u32)B);
     const int longBlocks = B == 1;
@@ -1333,15 +1344,19 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
             const int sbits = b - mbits;
             ctx.remaining_bits -= sc.qalloc;
             const int mid_first = mbits >= sbits;
-            i32 *fr = F.pstack[sp];
-            fr[0] = mid_first ? xoff + N : xoff;
-            fr[1] = mid_first ? sbits : mbits;
-            fr[2] = N;
-            fr[3] = B;
-            fr[4] = LM;
-            fr[5] = ctx.remaining_bits;
-            fr[6] = mid_first ? mbits : sbits;
-            fr[7] = mid_first ? (itheta != 0) : (itheta != 16384);
+            // park the second child: {xoff, N, B, LM, re-balance allowed} packed, its bits, and (first child's bits - remaining_bits
+            // at the split): rebalance (bands.c:961-981) = that + remaining_bits when the child is revived
+            {
+                const u32 w0 = (u32)(mid_first ? xoff + N : xoff) | ((u32)N << 8) | ((u32)B << 16) | ((u32)(LM + 1) << 21)
+                             | ((u32)(mid_first ? (itheta != 0) : (itheta != 16384)) << 23);
+                const u32 w1 = (u32)(mid_first ? sbits : mbits), w2 = (u32)((mid_first ? mbits : sbits) - ctx.remaining_bits);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    F.ps0[k] = sp == k ? w0 : F.ps0[k];
+                    F.ps1[k] = sp == k ? w1 : F.ps1[k];
+                    F.ps2[k] = sp == k ? w2 : F.ps2[k];
+                }
+            }
             sp++;
             if (!mid_first) xoff += N;
             b = mid_first ? mbits : sbits;
@@ -1370,21 +1385,27 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
                 }
                 alg_quant_lane(F, ec, leaf, cnt, N, K, ctx.spread, B);
             } else {
-                i16 *xb = F.xbig;
-                for (int k = 0; k < N; k++) xb[k] = src[k * LDS_COL];
-                alg_quant_body(F, ec, priv(xb), priv((i16 *)F.s.pvq.y), priv((i16 *)F.s.pvq.xabs), priv((i32 *)F.s.pvq.iy), N, K, ctx.spread, B);
+                // a leaf wider than the column's leaf slots (an unsplit wide band: a handful of pulses over 64..176 bins; N is a
+                // multiple of eight): searched in place in the band buffer by the generic body, its search state (2*iy, |x|, iy:
+                // 3 N 16-bit values) in bins of X this frame has already coded -- bands below this one are dead in both channels
+                // (resynth == 0) and the first band with such a leaf starts at bin 320 of a channel
+                x16_t *const gs = F.x16;
+                CA_COUNT("lane.wide_leaf", N);
+                alg_quant_body(F, ec, lds_col(const_cast<CA_AS_LDS i16 *>(src)), gs, gs + N, gs + 2 * N, N, K, ctx.spread, B);
             }
         }
         if (sp == 0) break;
         sp--;
-        const i32 *fr = F.pstack[sp];
-        xoff = fr[0];
-        b = fr[1];
-        N = fr[2];
-        B = fr[3];
-        LM = fr[4];
-        const i32 rebalance = fr[6] - (fr[5] - ctx.remaining_bits);
-        if (rebalance > 3 << BITRES && fr[7]) b += rebalance - (3 << BITRES);
+        const u32 w0 = sp == 0 ? F.ps0[0] : sp == 1 ? F.ps0[1] : sp == 2 ? F.ps0[2] : F.ps0[3];
+        const u32 w1 = sp == 0 ? F.ps1[0] : sp == 1 ? F.ps1[1] : sp == 2 ? F.ps1[2] : F.ps1[3];
+        const u32 w2 = sp == 0 ? F.ps2[0] : sp == 1 ? F.ps2[1] : sp == 2 ? F.ps2[2] : F.ps2[3];
+        xoff = (int)(w0 & 255u);
+        N = (int)((w0 >> 8) & 255u);
+        B = (int)((w0 >> 16) & 31u);
+        LM = (int)((w0 >> 21) & 3u) - 1;
+        b = (i32)w1;
+        const i32 rebalance = (i32)w2 + ctx.remaining_bits;
+        if (rebalance > 3 << BITRES && ((w0 >> 23) & 1u)) b += rebalance - (3 << BITRES);
     }
 }
 #endif
@@ -1414,11 +1435,11 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
         int b;
         if (i <= codedBands - 1) {
             i32 curr_balance = balance / imin(3, codedBands - i);
-            b = imax(0, imin(16383, imin(remaining_bits + 1, uni(F.pulses[i]) + curr_balance)));
+            b = imax(0, imin(16383, imin(remaining_bits + 1, frame_pulses(F, i) + curr_balance)));
         } else {
             b = 0;
         }
-        ctx.tf_change = uni(F.tf_res[i]);
+        ctx.tf_change = frame_tf_change(F, i);
         if (dual_stereo && i == intensity) dual_stereo = 0;
 
         // plan the jobs
@@ -1471,7 +1492,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
             quant_band_wave(F, ec, ctx, jx, N, jb, B, LM);
 #endif
         }
-        balance += uni(F.pulses[i]) + tell;
+        balance += frame_pulses(F, i) + tell;
     }
 }
 

@@ -43,7 +43,7 @@ template <class P, class V> CA_DEV void st0(P p, V v) { if (lane() == 0) *p = v;
 //         wave), which lets 16 waves share a CU and overlap their serial, latency-bound chains.
 // The hand-off between them is the pointer-free FrameMid record in HBM (celt_enc.h).
 struct __attribute__((aligned(16))) FrontLds {
-    enum { IN_IS_GLOBAL = 0 };
+    enum { IN_IS_GLOBAL = 0, XF_CHANNELS = 2 };
     i32 in[2][FRAME + OVL];        // overlap + pre-emphasised (then comb-filtered) signal; finally X[2][960] (i16)
     i32 xf[2][FRAME];              // dc-rejected PCM (i16) -> unfiltered pre-emphasised samples -> MDCT coefficients
     union {
@@ -63,28 +63,32 @@ struct __attribute__((aligned(16))) FrontLds {
     void *diag;                    // StageClock* in the diagnostic build, unused otherwise
 };
 
-struct __attribute__((aligned(16))) BackLds {
 #if defined(CA_LANE_FRAME)
-    // lane-per-frame build: the working set is private memory, so the two big sequentially walked arrays
-    // stay where they already are in HBM (per-lane sequential access is what the L1/L2 lines are good at)
-    // (the pointer types carry the address space, see wave.h: reloaded from this private struct a generic pointer
-    // would turn every access into a FLAT instruction)
-    x16_t *x16;                    // -> FrameMid::X of this frame (transformed in place), HBM
+// Lane-per-frame build: NO per-frame arrays in private memory (celt_enc_lane.h). What a lane owns is a column of the
+// workgroup's LDS scratch ([slot][lane], LS_SLOTS 16-bit slots), its rows in HBM, and a handful of scalars; this struct only
+// carries the pointers (their TYPES carry the address space, wave.h) and the scalars, all of which live in registers.
+enum { LS_SLOTS = 264, LS_PULSES = 240 };      // slots 0..239: band buffers of the PVQ walk / staging of the stages before it
+struct FrameMid;
+struct BackLds {
+    x16_t *x16;                    // -> FrameMid::X of this frame (consumed band by band), HBM
     u8 *packet;                    // -> the output slab of this frame
-    CA_AS_LDS i16 *lds_pvq16;      // -> this lane's column of the workgroup's LDS PVQ scratch ([element][lane])
-    CA_AS_LDS i32 *lds_pvq32;
-    CA_AS_LDS i16 *lds_xs;         // -> this lane's column of the leaf copy of X ([element][lane])
-    i16 xbig[176];                 // a leaf too large for the LDS column (an unsplit wide band), for the generic search
+    CA_AS_LDS i16 *col;            // -> slot 0 of this lane's column
+    FrameMid *mid;                 // -> the frame's hand-off record: inputs, and parking space for what must survive the PVQ walk
+    void *diag;                    // StageClock* in the diagnostic build
+    u32 tf_bits;                   // tf_res decision per band (bit i); tf_change(i) = tf_select_table[LM][tf_sel + bit]
+    int tf_sel;
+    // parked second children of split partitions (quant_band_lane): three packed words each, selected by explicit compares --
+    // a run-time index would put them in memory
+    u32 ps0[4], ps1[4], ps2[4];
+};
 #else
+struct __attribute__((aligned(16))) BackLds {
     i16 x16[2 * FRAME];            // normalised bands X[c*960 + j]
-#endif
     union {
         struct { i16 tmp[176]; i16 tmp1[176]; } tf;
         struct { i16 y[176]; i32 iy[176]; i16 xabs[176]; } pvq;
     } s;
-#if !defined(CA_LANE_FRAME)
     u8 packet[1280];
-#endif
     i32 bandE[2 * NB];
     i16 bandLogE[2 * NB], bandLogE2[2 * NB], error[2 * NB];
     i16 oldBandE[2 * NB], oldLogE[2 * NB], oldLogE2[2 * NB];
@@ -98,13 +102,14 @@ struct __attribute__((aligned(16))) BackLds {
     void *diag;
     i32 pstack[4][8];              // parked second children of split partitions (quant_band_wave)
 };
+#endif
 
 // Working sets of the two halves of the split front phase. The [2][1080] time signal is not staged in LDS
 // there: phase 1 produces it (comb filter output) and phase 2 consumes it (MDCT fold) exactly once, so both
 // go straight to the HBM hand-off buffer, and the normalised bands X are written straight into FrameMid.
 // 14.4 KB / 12.7 KB instead of 22.8 KB -> 11 / 12 waves per CU instead of 7.
 struct __attribute__((aligned(16))) Front1Lds {
-    enum { IN_IS_GLOBAL = 1 };
+    enum { IN_IS_GLOBAL = 1, XF_CHANNELS = 2 };
     i32 *in_g;                     // -> in_ws[2][1080] of this frame
     i32 xf[2][FRAME];
     union {
@@ -119,10 +124,14 @@ struct __attribute__((aligned(16))) Front1Lds {
 };
 
 struct __attribute__((aligned(16))) Front2Lds {
-    enum { IN_IS_GLOBAL = 1 };
+    // XF_CHANNELS 1 (round 3): ONE channel's MDCT coefficients at a time. Transform, band energies and normalisation of a
+    // channel need nothing of the other one, so the channels go through the same buffer one after the other and the
+    // normalised bands leave for FrameMid::X at once (celt_encode_front_phase). 8.7 KB instead of 12.5 KB of LDS per
+    // wavefront: four wavefronts per SIMD (the register budget's limit) instead of three.
+    enum { IN_IS_GLOBAL = 1, XF_CHANNELS = 1 };
     i32 *in_g;                     // -> in_ws[2][1080] of this frame (read only here)
     i16 *x_g;                      // -> FrameMid::X of this frame
-    i32 xf[2][FRAME];
+    i32 xf[1][FRAME];
     union {
         int2 f2[480];
     } s;
@@ -879,57 +888,95 @@ CA_DEVFN TransientOut transient_analysis_wave(L &F, const FrameCtx &fc)
 }
 
 // ---- MDCTs of one frame (compute_mdcts, celt_encoder.c:418-461): in -> xf (as freq) ------------------
+// where channel c's coefficients live: its own row, or THE row of a one-channel working set
+template <class L> CA_DEV i32 *xf_row(L &F, int c) { return F.xf[L::XF_CHANNELS == 1 ? 0 : c]; }
+
 template <class L>
-CA_DEVFN void compute_mdcts_wave(L &F, const FrameCtx &fc, int shortBlocks)
+CA_DEVFN void compute_mdct_channel(L &F, int c, int shortBlocks)
 {
-    for (int c = 0; c < fc.C; c++) {
-        if (shortBlocks) {
-            const MdctTab T = mdct_global_tab<3>();
-            mdct_forward_wave<3, 8>(tsig(F, c), F.s.f2, F.xf[c], 1, T, lane());
-        } else {
-            const MdctTab T = mdct_global_tab<0>();
-            mdct_forward_wave<0, 1>(tsig(F, c), F.s.f2, F.xf[c], 1, T, lane());
-        }
+    if (shortBlocks) {
+        const MdctTab T = mdct_global_tab<3>();
+        mdct_forward_wave<3, 8>(tsig(F, c), F.s.f2, xf_row(F, c), 1, T, lane());
+    } else {
+        const MdctTab T = mdct_global_tab<0>();
+        mdct_forward_wave<0, 1>(tsig(F, c), F.s.f2, xf_row(F, c), 1, T, lane());
     }
 }
 
-// ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
 template <class L>
-CA_DEVFN void band_energies_wave(L &F, const FrameCtx &fc, i16 *bandLogE)
+CA_DEVFN void compute_mdcts_wave(L &F, const FrameCtx &fc, int shortBlocks)
 {
-    // one lane per (channel, band): 42 independent reductions of 8..176 bins run side by side instead of 42
-    // wave reductions one after the other (sums wrap, so the order of the adds is free)
-    for (int t = lane(); t < fc.C * NB; t += LANES) {
-        const int c = t / NB, b = t - c * NB;
-        const int j0 = CLT_eband5ms[b] << LM3, j1 = CLT_eband5ms[b + 1] << LM3;
-        const i32 *X = F.xf[c];
+    for (int c = 0; c < fc.C; c++) compute_mdct_channel(F, c, shortBlocks);
+}
+
+// ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
+// Channel c alone, over all 64 lanes: a band's two reductions (largest magnitude, then the sum of squares at the shift that
+// magnitude fixes) are split into chunks of eight bins -- 100 chunks per channel, one lane each -- and combined per band by
+// the band's own lane: 8 + 22 dependent steps per reduction instead of the 176 of the widest band (maxima compose exactly,
+// the sums wrap, so the order of the adds is free). The partial results sit in the FFT scratch, idle between transforms.
+template <class L>
+CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
+{
+    const i32 *X = xf_row(F, c);
+    i32 *red = reinterpret_cast<i32 *>(F.s.f2);                 // [0,100) chunk max, [100,200) chunk min, [200,300) chunk sums, [300,321) band shift
+    constexpr int NCH = 100;                                    // CLT_eband5ms[NB] chunks of eight bins (LM 3)
+    for (int ch = lane(); ch < NCH; ch += LANES) {
         i32 mx = 0, mn = 0;
-#pragma unroll 4
-        for (int j = j0; j < j1; j++) { mx = imax(mx, X[j]); mn = imin(mn, X[j]); }
-        i32 maxval = imax(mx, neg32(mn));
-        i32 E = 1;
-        if (maxval > 0) {
-            int shift = celt_ilog2(maxval) - 14 + (((CLT_logN400[b] >> 3) + LM3 + 1) >> 1);
-            i32 sum = 0;
-#pragma unroll 4
-            for (int j = j0; j < j1; j++) {
-                i32 v = shift > 0 ? (i16)(X[j] >> shift) : (i16)shl32(X[j], -shift);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const i32 v = X[8 * ch + u]; mx = imax(mx, v); mn = imin(mn, v); }
+        red[ch] = mx;
+        red[NCH + ch] = mn;
+    }
+    wave_sync();
+    for (int b = lane(); b < NB; b += LANES) {
+        i32 mx = 0, mn = 0;
+        for (int ch = CLT_eband5ms[b]; ch < CLT_eband5ms[b + 1]; ch++) { mx = imax(mx, red[ch]); mn = imin(mn, red[NCH + ch]); }
+        const i32 maxval = imax(mx, neg32(mn));
+        // shift of the band, or "no energy" (bands.c:108-126)
+        red[3 * NCH + b] = maxval > 0 ? celt_ilog2(maxval) - 14 + (((CLT_logN400[b] >> 3) + LM3 + 1) >> 1) : 0x7fff;
+    }
+    wave_sync();
+    for (int ch = lane(); ch < NCH; ch += LANES) {
+        const int shift = red[3 * NCH + CLT_bin2band[ch]];
+        i32 sum = 0;
+        if (shift != 0x7fff) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i32 x = X[8 * ch + u];
+                const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
                 sum = mac16_16(sum, v, v);
             }
+        }
+        red[2 * NCH + ch] = sum;
+    }
+    wave_sync();
+    for (int b = lane(); b < NB; b += LANES) {
+        const int shift = red[3 * NCH + b];
+        i32 E = 1;
+        if (shift != 0x7fff) {
+            i32 sum = 0;
+            for (int ch = CLT_eband5ms[b]; ch < CLT_eband5ms[b + 1]; ch++) sum = add32(sum, red[2 * NCH + ch]);
             E = add32(1, vshr32(celt_sqrt(sum), -shift));
         }
-        F.bandE[t] = E;
-        bandLogE[t] = (i16)(celt_log2(shl32(E, 2)) - shl16(CLT_eMeans[b], 6));
+        F.bandE[c * NB + b] = E;
+        bandLogE[c * NB + b] = (i16)(celt_log2(shl32(E, 2)) - shl16(CLT_eMeans[b], 6));
     }
     wave_sync();
 }
 
+template <class L>
+CA_DEVFN void band_energies_wave(L &F, const FrameCtx &fc, i16 *bandLogE)
+{
+    for (int c = 0; c < fc.C; c++) band_energies_channel(F, c, bandLogE);
+}
+
 // ---- normalise_bands (bands.c:146-168): xf (freq) -> X (int16, aliases `in`) ------------------------
 template <class L>
-CA_DEVFN void normalise_bands_wave(L &F, const FrameCtx &fc)
+CA_DEVFN void normalise_bands_channel(L &F, int c)
 {
     i16 *X = frame_X(F);
-    for (int k = lane(); k < fc.C * NB; k += LANES) {
+    const i32 *xf = xf_row(F, c);
+    for (int k = c * NB + lane(); k < (c + 1) * NB; k += LANES) {
         i32 bE = F.bandE[k];
         int shift = celt_zlog2(bE) - 13;
         i32 E = (i16)vshr32(bE, shift);                                              // opus_val16 E
@@ -937,12 +984,17 @@ CA_DEVFN void normalise_bands_wave(L &F, const FrameCtx &fc)
         F.normshift[k] = (i8)shift;
     }
     wave_sync();
-    for (int c = 0; c < fc.C; c++)
-        for (int j = lane(); j < (CLT_eband5ms[NB] << LM3); j += LANES) {
-            int b = CLT_bin2band[j >> 3] + c * NB;
-            X[c * FRAME + j] = (i16)mul16_16_q15(vshr32(F.xf[c][j], F.normshift[b] - 1), F.normg[b]);
-        }
+    for (int j = lane(); j < (CLT_eband5ms[NB] << LM3); j += LANES) {
+        int b = CLT_bin2band[j >> 3] + c * NB;
+        X[c * FRAME + j] = (i16)mul16_16_q15(vshr32(xf[j], F.normshift[b] - 1), F.normg[b]);
+    }
     wave_sync();
+}
+
+template <class L>
+CA_DEVFN void normalise_bands_wave(L &F, const FrameCtx &fc)
+{
+    for (int c = 0; c < fc.C; c++) normalise_bands_channel(F, c);
 }
 
 }  // namespace ca

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64, 3) void celt_front1_kernel(opusgpu_celt_config 
     }
 }
 
-__global__ __launch_bounds__(64, 3) void celt_front2_kernel(opusgpu_celt_config cfg, FrameMid *__restrict__ mid,
+// (64, 4): the one-channel working set (8.7 KB of LDS) admits 18 wavefronts per CU; the register budget is set for 16
+__global__ __launch_bounds__(64, 4) void celt_front2_kernel(opusgpu_celt_config cfg, FrameMid *__restrict__ mid,
                                                             i32 *__restrict__ in_ws, int nframes)
 {
     __shared__ Front2Lds F;
@@ -181,7 +182,9 @@ extern "C" int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_stat
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_DC_REJECT, s);
             opusgpu_launch_dc_reject(st ? st + first : nullptr, d_pcm + first * FRAME * cfg->channels, mid, n, s);
             opusgpu_timing_end(slot, s);
-            const int gf1 = n < cus * 11 ? n : cus * 11, gf2 = n < cus * 12 ? n : cus * 12;   // 14.4 / 12.7 KB LDS per workgroup
+            // persistent grids sized to what a CU holds: 13.9 KB of LDS per workgroup (11) / 8.7 KB at <= 128 VGPRs (16)
+            static const int f2_waves = getenv("OPUSGPU_FRONT2_WAVES") ? atoi(getenv("OPUSGPU_FRONT2_WAVES")) : 16;
+            const int gf1 = n < cus * 11 ? n : cus * 11, gf2 = n < cus * f2_waves ? n : cus * f2_waves;
             slot = opusgpu_timing_begin(OPUSGPU_KERNEL_CELT_FRONT1, s);
             hipLaunchKernelGGL(celt_front1_kernel, dim3(gf1), dim3(64), 0, s, *cfg, st ? st + first : nullptr, mid, in_ws, n);
             opusgpu_timing_end(slot, s);

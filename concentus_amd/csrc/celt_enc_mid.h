@@ -620,8 +620,12 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
         trim = (i16)(trim + imax(-1024, mul16_16_q15(24576, logXC)));
         fc.stereo_saving = (i16)imin(fc.stereo_saving + 64, -(logXC2 >> 1));
     }
+#if defined(CA_LANE_FRAME)
+    diff = alloc_trim_diff_lane(F);                                                 // celt_enc_lane.h: bandLogE lives in the lane's column
+#else
     for (int c = 0; c < C; c++)
         for (int i = 0; i < end - 1; i++) diff += F.bandLogE[i + c * NB] * (i32)(2 + 2 * i - end);
+#endif
     diff /= C * (end - 1);
     trim = (i16)(trim - imax(-512, imin(512, ((diff + 1024) >> 2) / 6)));
     // surround_trim = 0

@@ -50,8 +50,13 @@ CA_SHARED LdsTables g_lds_tables;
 //   then 48 32-bit slots   PVQ search state iy                           g_lds_pvq32
 // Stages that run while the PVQ search is idle (band re-arrangement, TF analysis) use the 16-bit part as one array of up
 // to LANE_SCRATCH_N bins through g_lds_pvq16.
+// The encoder's back kernel (celt_back_lane_kernel.hip) defines CA_LANE_SLOTS 264 and lays the column out itself
+// (celt_enc_front.h LS_*, celt_enc_lane.h M_*): 16-bit slots throughout.
 enum { LANE_SCRATCH_N = 144 };
-CA_SHARED __attribute__((aligned(16))) int16_t g_lds_scratch[(LANE_SCRATCH_N + 2 * 48) * 64];
+#if !defined(CA_LANE_SLOTS)
+#define CA_LANE_SLOTS (LANE_SCRATCH_N + 2 * 48)
+#endif
+CA_SHARED __attribute__((aligned(16))) int16_t g_lds_scratch[CA_LANE_SLOTS * 64];
 #define g_lds_pvq16 (ca::g_lds_scratch)
 #define g_lds_xs (ca::g_lds_scratch + 96 * 64)
 #define g_lds_pvq32 (reinterpret_cast<int32_t *>(ca::g_lds_scratch + LANE_SCRATCH_N * 64))

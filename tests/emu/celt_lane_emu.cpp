@@ -8,8 +8,15 @@
 #define CA_LANE_FRAME 1
 #include <stdlib.h>
 #include <string.h>
+#include <map>
+#include <string>
 extern "C" void emu_tap(const char *, const void *, int) {}
-extern "C" void emu_count(const char *, long) {}
+// event counters (CA_COUNT): the tests check that the lane build's rare paths are actually reached
+static std::map<std::string, std::pair<long, long>> g_counts;
+extern "C" void emu_count(const char *name, long n) { auto &c = g_counts[name]; c.first++; c.second += n; }
+extern "C" void emu_lane_counts_reset(void) { g_counts.clear(); }
+extern "C" long emu_lane_count(const char *name) { auto it = g_counts.find(name); return it == g_counts.end() ? 0 : it->second.first; }
+#define CA_LANE_SLOTS 264                  // as celt_back_lane_kernel.hip (the decoder part uses the first 240)
 #include "../../concentus_amd/csrc/celt_lane_tables.h"
 #include "../../concentus_amd/csrc/celt_enc.h"
 #include "../../concentus_amd/csrc/celt_dec.h"
@@ -51,13 +58,11 @@ extern "C" int emu_lane_celt_encode_frames(const opusgpu_celt_config *cfg, opusg
         lds_poison();
         BackLds F;
         memset(&F, 0xAB, sizeof(F));
-        F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + g_slot);
-        F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + g_slot);
-        F.lds_xs = (CA_AS_LDS i16 *)(g_lds_xs + g_slot);
+        F.col = (CA_AS_LDS i16 *)(g_lds_scratch + g_slot);
         FrameResult r = celt_encode_back(F, *cfg, mid, st, out + (size_t)n * out_stride);
         out_len[n] = r.bytes;
         out_rng[n] = r.final_range;
-        clean &= lds_neighbours_untouched(240);
+        clean &= lds_neighbours_untouched(LS_SLOTS);
     }
     free(F1);
     free(mid);

@@ -53,3 +53,33 @@ def test_lane_build_decoder_matches_reference_pcm(case):
     assert emu.emu_lane_celt_decode_frames(p(pk), pk.shape[1], p(ln), n, fps, p(pcm), p(rng), p(ret)) == 0
     assert (ret == 960).all() and np.array_equal(rng, rg)
     assert np.array_equal(pcm, want), "PCM differs at frame %d" % int(np.nonzero((pcm != want).reshape(n, -1).any(1))[0][0])
+
+
+def test_rare_lane_paths_are_reached_and_match_the_reference():
+    """The paths that only the lane build has and that ordinary frames seldom take -- a leaf too wide for the column (search state in
+    the frame's already-coded bins of X), the extra TF level of transient frames (band fetched twice), the intra pass of coarse
+    energy winning (bytes restored from the column) or being forced -- must occur in this corpus, and every packet must equal the
+    live reference's."""
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librefdrv.so")):
+        pytest.skip("oracle/_ref not built")
+    gm = ec.golden_module()
+    emu = emulib.lane_lib()
+    emu.emu_lane_count.restype = C.c_long
+    emu.emu_lane_count.argtypes = [C.c_char_p]
+    emu.emu_lane_counts_reset()
+    rng = np.random.default_rng(77)
+    for kind, br, vbr, cvbr, cx, fps, n, scale in (("music", 32000, 1, 0, 10, 16, 32, 1), ("edge", 64000, 1, 0, 10, 1, 16, 1), ("noise", 40000, 0, 0, 5, 8, 32, 1),
+                                                   ("music", 36000, 1, 1, 10, 16, 32, 1), ("noise", 48000, 1, 0, 10, 1, 32, 1), ("music", 96000, 1, 0, 3, 4, 16, 1),
+                                                   ("noise", 33000, 0, 0, 10, 1, 32, 4), ("music", 128000, 1, 0, 10, 16, 32, 1), ("edge", 32000, 0, 0, 8, 4, 16, 1)):
+        pcm = gm.synth_pcm(kind, n, int(rng.integers(1, 1 << 30)))
+        if scale != 1:
+            pcm = (pcm.astype(np.int32) // scale).astype(np.int16)
+        # bursts make transient frames (short blocks + the extra TF level)
+        pcm = pcm.copy()
+        pcm[1::3, 400:520] = (pcm[1::3, 400:520].astype(np.int32) * 6).clip(-32768, 32767).astype(np.int16)
+        pk, ln, rg = gm.ref_encode(gm._Cfg(2, br, vbr, cvbr, cx, 16, 0, 1500), pcm, fps, threads=4)
+        out, lens, r2 = run_lane_emu(pcm, fps, (br, vbr, cvbr, cx), slot=int(rng.integers(0, 64)))
+        ec.assert_packets_equal(out, lens, r2, pk, ln, rg, "%s %d" % (kind, br))
+    seen = {k: emu.emu_lane_count(k.encode()) for k in ("lane.wide_leaf", "lane.tf_extra_level", "lane.coarse_intra_restored")}
+    assert all(v > 0 for v in seen.values()), seen
