@@ -11,13 +11,15 @@
 namespace ca {
 
 __global__ __launch_bounds__(64) void silk_encode_bits_kernel(const opusgpu_silk_bits_in *__restrict__ recs, opusgpu_ec_state *__restrict__ ecs,
-                                                              opusgpu_silk_bits_out *__restrict__ outs, int n_rec, int *__restrict__ bad_records)
+                                                              opusgpu_silk_bits_out *__restrict__ outs, int n_rec, int *__restrict__ bad_records,
+                                                              const int *__restrict__ rows)
 {
     __shared__ NlsfTablesLds tables;
     nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
     __syncthreads();
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
+    if (rows) r = rows[r];                                     // the bitrate loop's second passes: a list of frames, in place
     const opusgpu_silk_bits_in &in = recs[r];
     opusgpu_ec_state &st = ecs[r];
     opusgpu_silk_bits_out o;
@@ -59,6 +61,17 @@ extern "C" int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, 
     if (!d_in || !d_ec || !d_out) return OPUSGPU_BAD_ARG;
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
-    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_ec, d_out, n, bad);
+    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_ec, d_out, n, bad, (const int *)nullptr);
+    return opusgpu_check_launch();
+}
+
+// records d_rows[0 .. m) of the arrays, in place: silk_chain.hip's bitrate loop
+extern "C" int opusgpu_silk_encode_bits_rows(const opusgpu_silk_bits_in *d_in, opusgpu_ec_state *d_ec, opusgpu_silk_bits_out *d_out, const int *d_rows,
+                                             int m, hipStream_t stream)
+{
+    if (m <= 0) return m < 0 ? OPUSGPU_BAD_ARG : OPUSGPU_OK;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, d_in, d_ec, d_out, m, bad, d_rows);
     return opusgpu_check_launch();
 }

@@ -76,10 +76,11 @@ struct NsqScratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
 
 __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__restrict__ recs, opusgpu_nsq_state *__restrict__ states,
                                                       opusgpu_nsq_out *__restrict__ outs, NsqScratch *__restrict__ ws, int n_rec,
-                                                      int *__restrict__ bad_records)
+                                                      int *__restrict__ bad_records, const int *__restrict__ rows)
 {
-    const int r = blockIdx.x * 64 + threadIdx.x;
+    int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
+    if (rows) r = rows[r];                                     // the bitrate loop's second passes: a list of frames, in place
     const opusgpu_nsq_in &in = recs[r];
     opusgpu_nsq_state &NSQ = states[r];
     if (!nsq_record_ok(in, NSQ.lagPrev)) {                     // state untouched, no pulses
@@ -442,7 +443,18 @@ extern "C" int opusgpu_silk_nsq_batch(const opusgpu_nsq_in *d_in, opusgpu_nsq_st
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
     hipLaunchKernelGGL(silk_nsq_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
-                       (NsqScratch *)d_workspace, n, bad);
+                       (NsqScratch *)d_workspace, n, bad, (const int *)nullptr);
+    return opusgpu_check_launch();
+}
+
+// records d_rows[0 .. m) of the arrays, in place (workspace sized for the whole arrays): silk_chain.hip's bitrate loop
+extern "C" int opusgpu_silk_nsq_rows(const opusgpu_nsq_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_out *d_out, const int *d_rows, int m,
+                                     void *d_workspace, hipStream_t stream)
+{
+    if (m <= 0) return m < 0 ? OPUSGPU_BAD_ARG : OPUSGPU_OK;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_nsq_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, d_in, d_state, d_out, (NsqScratch *)d_workspace, m, bad, d_rows);
     return opusgpu_check_launch();
 }
 

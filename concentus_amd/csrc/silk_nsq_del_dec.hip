@@ -52,13 +52,14 @@ CA_DEV i16 sat16(i32 v) { return (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 
 
 __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_dd_in *__restrict__ recs, opusgpu_nsq_state *states,
                                                               opusgpu_nsq_dd_out *__restrict__ outs, dd::Scratch *ws, int n_rec,
-                                                              int *__restrict__ bad_records)
+                                                              int *__restrict__ bad_records, const int *__restrict__ rows)
 {
     using namespace dd;
     __shared__ i32 ring[ROWS * 64];
     const int ln = threadIdx.x, k = ln & 3, quad = ln & ~3;
-    const int r = blockIdx.x * 16 + (ln >> 2);
+    int r = blockIdx.x * 16 + (ln >> 2);
     if (r >= n_rec) return;                       // whole quads leave together
+    if (rows) r = rows[r];                        // the bitrate loop's second passes: a list of frames, in place
     const opusgpu_nsq_in &in = recs[r].base;
     const int nst = recs[r].nStatesDelayedDecision, warping_Q16 = recs[r].warping_Q16;
     opusgpu_nsq_state &NSQ = states[r];
@@ -468,6 +469,18 @@ extern "C" int opusgpu_silk_nsq_del_dec_batch(const opusgpu_nsq_dd_in *d_in, opu
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
     hipLaunchKernelGGL(silk_nsq_del_dec_kernel, dim3((n + 15) / 16), dim3(64), 0, (hipStream_t)stream, d_in, d_state, d_out,
-                       (dd::Scratch *)d_workspace, n, bad);
+                       (dd::Scratch *)d_workspace, n, bad, (const int *)nullptr);
+    return opusgpu_check_launch();
+}
+
+// records d_rows[0 .. m) of the arrays, in place (workspace sized for the whole arrays): silk_chain.hip's bitrate loop
+extern "C" int opusgpu_silk_nsq_del_dec_rows(const opusgpu_nsq_dd_in *d_in, opusgpu_nsq_state *d_state, opusgpu_nsq_dd_out *d_out, const int *d_rows,
+                                             int m, void *d_workspace, hipStream_t stream)
+{
+    if (m <= 0) return m < 0 ? OPUSGPU_BAD_ARG : OPUSGPU_OK;
+    int *bad = opusgpu_bad_record_counter();
+    if (!bad) return OPUSGPU_ALLOC_FAIL;
+    hipLaunchKernelGGL(silk_nsq_del_dec_kernel, dim3((m + 15) / 16), dim3(64), 0, stream, d_in, d_state, d_out, (dd::Scratch *)d_workspace, m, bad,
+                       d_rows);
     return opusgpu_check_launch();
 }

@@ -8,9 +8,9 @@ the first pass of a frame, and the bitrate loop around quantiser and coder (:263
 C ABI, opusgpu_silk_encode_frames_batch (concentus_amd/csrc/silk_chain.hip): the eight batched kernels back to back and, between
 them, small kernels that complete the next records from the outputs of the earlier stages -- field to field, no arithmetic, exactly
 along the edges that tests/test_silk_chain_cpu.py pins against the unmodified reference. What the caller provides per frame are the
-records' remaining fields: the input buffer, the VAD results, the configuration and the states the previous frame left behind. The
-loop (run(..., rate_ctl=...)) is host-side plumbing over opusgpu_silk_rate_control_batch: gather the frames that ask for another
-pass, quantise + code them again from their entry states, scatter them back.
+records' remaining fields: the input buffer, the VAD results, the configuration and the states the previous frame left behind. With
+run(..., rate_ctl=...) the loop runs as well, also inside ONE call of the C ABI (opusgpu_silk_encode_frames_cbr_batch): the frames that
+ask for another pass are listed on the device and quantiser + coder run over that list in place; nothing here touches a record.
 
 Geometry is fixed per chain object (all frames of a batch share fs_kHz / nb_subfr, as one encoder configuration does)."""
 import ctypes as C
@@ -80,10 +80,8 @@ class SilkAnalysisChain:
             S._check(t, S.SIZES[size], name)
             if t.shape[0] != n:
                 raise ValueError("%s: %d records for %d frames" % (name, t.shape[0], n))
-        if rate_ctl is not None:
-            if bits_in is None or ec_state is None:
-                raise ValueError("rate_ctl needs bits_in and ec_state: the loop measures the coder")
-            nsq_entry, ec_entry = nsq_state.clone(), ec_state.clone()       # sNSQ_copy / sRangeEnc_copy (encode_frame_FIX.c:272-273)
+        if rate_ctl is not None and (bits_in is None or ec_state is None):
+            raise ValueError("rate_ctl needs bits_in and ec_state: the loop measures the coder")
 
         def new(size, zero=False):
             return (torch.zeros if zero else torch.empty)((n, S.SIZES[size]), dtype=torch.uint8, device=dev)
@@ -98,8 +96,19 @@ class SilkAnalysisChain:
         bufs = ChainBufs(*[C.c_void_p(t.data_ptr() if t is not None else None) for t in (
             pitch_in, pitch_out, shape_in, shape_out, fpc_in, fpc_out, gains_in, gains_out, prefilter_in, prefilter_state, prefilter_out,
             q_in, nsq_state, q_out, bits_in, ec_state if bits_in is not None else None, bits_out, ws)], C.c_size_t(ws.numel()))
-        rc = L.opusgpu_silk_encode_frames_batch(C.byref(bufs), self.fs_kHz, self.nb_subfr, 1 if del_dec else 0, n, _lib.current_stream_handle())
-        _lib.check(rc, "opusgpu_silk_encode_frames_batch")
+        if rate_ctl is None:
+            rc = L.opusgpu_silk_encode_frames_batch(C.byref(bufs), self.fs_kHz, self.nb_subfr, 1 if del_dec else 0, n, _lib.current_stream_handle())
+            _lib.check(rc, "opusgpu_silk_encode_frames_batch")
+        else:
+            # the whole of silk_encode_frame_FIX, loop included, in one call of the C ABI (csrc/silk_chain.hip)
+            S._check(rate_ctl, S.SIZES["silk_rate_ctl"], "rate_ctl")
+            lws = S._scratch(dev, L.opusgpu_silk_encode_frames_cbr_workspace_bytes(n), "silk_cbr_loop")
+            passes = C.c_int(0)
+            rc = L.opusgpu_silk_encode_frames_cbr_batch(C.byref(bufs), C.c_void_p(rate_ctl.data_ptr()), self.fs_kHz, self.nb_subfr,
+                                                        1 if del_dec else 0, n, C.c_void_p(lws.data_ptr()), C.c_size_t(lws.numel()),
+                                                        C.byref(passes), _lib.current_stream_handle())
+            _lib.check(rc, "opusgpu_silk_encode_frames_cbr_batch")
+            self.last_loop_iterations = passes.value
         out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out,
                "pulses": q_out[:, :320].view(torch.int8)}
         if del_dec:
@@ -107,60 +116,13 @@ class SilkAnalysisChain:
         if bits_in is not None:
             out["bits_out"] = bits_out
         if rate_ctl is not None:
-            R = S.RateCtl
-            for name in ("GainsUnq_Q16", "Gains_Q16", "lastGainIndexPrev", "LastGainIndex", "Lambda_Q10", "GainsIndices"):
-                mv(rate_ctl, R, name, gains_out, GO, name)
-            self._rate_loop(rate_ctl, q_in, nsq_state, nsq_entry, ec_state, ec_entry, bits_in, del_dec, out)
             out["rate_ctl"] = rate_ctl
+        # a record that fails the device-side checks yields zeroed outputs and is counted -- say so instead of
+        # returning it like a good frame
+        bad = S.bad_records()
+        if bad:
+            raise _lib.OpusGpuError(-1, "SilkAnalysisChain.run: %d record(s) failed the device-side checks (status fields of the *_out records)" % bad)
         return out
-
-    def _rate_loop(self, rate_ctl, q_in, nsq_state, nsq_entry, ec_state, ec_entry, bits_in, del_dec, out):
-        """encode_frame_FIX.c:276-423 over the batch: one opusgpu_silk_rate_control_batch step after every pass decides per frame; the
-        frames that need another pass are gathered, quantised + coded from their entry states, and scattered back."""
-        import torch
-        mv, R, Q, B = self._move, S.RateCtl, S.NsqIn, S.SilkBitsIn
-        f0, _ = _off(R, "done")
-        po, _ = _off(B, "pulses")
-        so, _ = _off(B, "Seed")
-        nsq_low = ec_low = None                                             # sNSQ_copy2 / sRangeEnc_copy2 + ec_buf_copy, allocated on first use
-        for _ in range(8):                                                  # iter 0 .. maxIter: at most 7 passes, each followed by a step
-            S.silk_rate_control(rate_ctl, ec_state)
-            flags = rate_ctl[:, f0:f0 + 16].contiguous().view(torch.int32)  # done, recode, save2, restore2
-            keep = flags[:, 2].nonzero().squeeze(1)
-            if keep.numel():
-                if nsq_low is None:
-                    nsq_low, ec_low = torch.zeros_like(nsq_state), torch.zeros_like(ec_state)
-                nsq_low[keep] = nsq_state[keep]
-                ec_low[keep] = ec_state[keep]
-            back = flags[:, 3].nonzero().squeeze(1)
-            if back.numel():
-                nsq_state[back] = nsq_low[back]
-                ec_state[back] = ec_low[back]
-            rows = flags[:, 1].nonzero().squeeze(1)
-            if rows.numel() == 0:
-                return
-            ctl = rate_ctl[rows]
-            q = q_in[rows]
-            mv(q, Q, "Gains_Q16", ctl, R, "Gains_Q16")
-            mv(q, Q, "Lambda_Q10", ctl, R, "Lambda_Q10")
-            nsq, ec, b = nsq_entry[rows], ec_entry[rows], bits_in[rows]
-            if del_dec:
-                dd_out = S.silk_NSQ_del_dec(q, nsq)
-                pulses = dd_out[:, :320]
-                b[:, so:so + 4] = dd_out[:, 320:324]
-                out["Seed"][rows] = dd_out[:, 320:324].contiguous().view(torch.int32)[:, 0]
-            else:
-                pulses = S.silk_NSQ(q, nsq).view(torch.uint8)
-            b[:, po:po + 320] = pulses
-            mv(b, B, "GainsIndices", ctl, R, "GainsIndices")
-            bits_out = S.silk_encode_bits(b, ec)
-            nsq_state[rows] = nsq
-            ec_state[rows] = ec
-            bits_in[rows] = b
-            q_in[rows] = q
-            out["pulses"][rows] = pulses.view(torch.int8)
-            out["bits_out"][rows] = bits_out
-        raise RuntimeError("silk rate loop: frames still asking for a pass after maxIter")
 
 
 CHAIN_FED_FIELDS = {       # the record fields run() fills: a caller (and the test) may leave them zero

@@ -451,6 +451,22 @@ typedef struct opusgpu_silk_chain_bufs {
 
 int opusgpu_silk_encode_frames_batch(const opusgpu_silk_chain_bufs *bufs, int fs_kHz, int nb_subfr, int del_dec, int n, void *hip_stream);
 
+/* ---- silk_encode_frame_FIX WITH its bitrate loop for a batch of frames, one call (encode_frame_FIX.c:176-423) --------------------
+ * opusgpu_silk_encode_frames_batch, then the reference's `for( iter = 0; ; iter++ )` loop (:276-423) on the device: a rate-control
+ * step over the batch after every pass (opusgpu_silk_rate_control_batch); its decisions are carried out by a kernel -- keep / restore
+ * the lower-bracket copy of coder + quantiser state (:389-395, :361-368), put the frames that go again back to the state they
+ * entered with (:283-289) and on a list -- and quantiser + coder run again over that list IN PLACE (index indirection, no gathered
+ * copies). The host reads one number per iteration (the length of the list) and stops when it is zero.
+ * bufs as above with bits_in / ec_state / bits_out set; d_ctl: n records with maxBits, useCBR, condCoding, nb_subfr, frame_length set
+ * and the rest zero -- they return LastGainIndex, GainsIndices, Lambda_Q10 and `passes` per frame; nsq_state / ec_state / q_out
+ * (pulses, Seed) / bits_in end as silk_encode_frame_FIX leaves them. d_loop_workspace: opusgpu_silk_encode_frames_cbr_workspace_bytes(n)
+ * bytes of device memory (the per-frame copies the reference keeps on its stack). *passes (may be NULL): iterations that re-coded
+ * at least one frame. */
+size_t opusgpu_silk_encode_frames_cbr_workspace_bytes(int n);
+int opusgpu_silk_encode_frames_cbr_batch(const opusgpu_silk_chain_bufs *bufs, opusgpu_silk_rate_ctl *d_ctl, int fs_kHz, int nb_subfr,
+                                         int del_dec, int n, void *d_loop_workspace, size_t loop_workspace_bytes, int *passes,
+                                         void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,3 +23,11 @@ bash tools/prof_celt.sh $TAG/celt > $O/celt_summary_stdout.txt 2>&1; tail -30 $O
 python3 tools/pmc_traffic.py $O/celt/pmc_fetch $O/celt/pmc_write $O/traffic_celt.json
 python3 tools/pmc_db.py $O/celt 65536 $O/pmc_celt.json > /dev/null
 cd $R && timeout -k 10 200 python3 tools/stage_profile.py 16384 noise lane > $O/stage_profile.txt 2>&1; tail -3 $O/stage_profile.txt | cut -c1-1200
+cd $R && timeout -k 10 400 python3 bench.py --workload silk_frames_cbr --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_silk_cbr.json 2> $O/bench_silk_cbr.err; python3 - <<PY
+import json
+try:
+    d = json.load(open("$O/bench_silk_cbr.json"))
+    print("silk_frames_cbr: %.3f M frames/s, %.2f ms/step, parity %s" % (d["value"] / 1e6, d["ms_per_step"], d["parity_checked"]))
+except Exception as e:
+    print("silk_frames_cbr failed", e); print(open("$O/bench_silk_cbr.err").read()[-1500:])
+PY
