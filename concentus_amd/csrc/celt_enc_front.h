@@ -920,12 +920,24 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
     const i32 *X = xf_row(F, c);
     i32 *red = reinterpret_cast<i32 *>(F.s.f2);                 // [0,100) chunk max, [100,200) chunk min, [200,300) chunk sums, [300,321) band shift
     constexpr int NCH = 100;                                    // CLT_eband5ms[NB] chunks of eight bins (LM 3)
-    for (int ch = lane(); ch < NCH; ch += LANES) {
-        i32 mx = 0, mn = 0;
+    if constexpr (LANES == 64) {
+        // one BIN per lane (consecutive lanes read consecutive words: no bank conflicts), a chunk = eight neighbouring lanes,
+        // combined with three xor-shuffles
+        for (int j = lane(); j < 8 * NCH; j += LANES) {
+            const i32 v = X[j];
+            i32 mx = imax(0, v), mn = imin(0, v);
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const i32 v = X[8 * ch + u]; mx = imax(mx, v); mn = imin(mn, v); }
-        red[ch] = mx;
-        red[NCH + ch] = mn;
+            for (int m = 1; m < 8; m <<= 1) { mx = imax(mx, shfl_xor(mx, m)); mn = imin(mn, shfl_xor(mn, m)); }
+            if ((j & 7) == 0) { red[j >> 3] = mx; red[NCH + (j >> 3)] = mn; }
+        }
+    } else {
+        for (int ch = lane(); ch < NCH; ch += LANES) {
+            i32 mx = 0, mn = 0;
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const i32 v = X[8 * ch + u]; mx = imax(mx, v); mn = imin(mn, v); }
+            red[ch] = mx;
+            red[NCH + ch] = mn;
+        }
     }
     wave_sync();
     for (int b = lane(); b < NB; b += LANES) {
@@ -936,18 +948,33 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
         red[3 * NCH + b] = maxval > 0 ? celt_ilog2(maxval) - 14 + (((CLT_logN400[b] >> 3) + LM3 + 1) >> 1) : 0x7fff;
     }
     wave_sync();
-    for (int ch = lane(); ch < NCH; ch += LANES) {
-        const int shift = red[3 * NCH + CLT_bin2band[ch]];
-        i32 sum = 0;
-        if (shift != 0x7fff) {
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const i32 x = X[8 * ch + u];
+    if constexpr (LANES == 64) {
+        for (int j = lane(); j < 8 * NCH; j += LANES) {
+            const int shift = red[3 * NCH + CLT_bin2band[j >> 3]];
+            i32 sum = 0;
+            if (shift != 0x7fff) {
+                const i32 x = X[j];
                 const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
-                sum = mac16_16(sum, v, v);
+                sum = mul16_16(v, v);
             }
+#pragma unroll
+            for (int m = 1; m < 8; m <<= 1) sum = add32(sum, shfl_xor(sum, m));
+            if ((j & 7) == 0) red[2 * NCH + (j >> 3)] = sum;
         }
-        red[2 * NCH + ch] = sum;
+    } else {
+        for (int ch = lane(); ch < NCH; ch += LANES) {
+            const int shift = red[3 * NCH + CLT_bin2band[ch]];
+            i32 sum = 0;
+            if (shift != 0x7fff) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const i32 x = X[8 * ch + u];
+                    const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
+                    sum = mac16_16(sum, v, v);
+                }
+            }
+            red[2 * NCH + ch] = sum;
+        }
     }
     wave_sync();
     for (int b = lane(); b < NB; b += LANES) {
