@@ -20,6 +20,10 @@ One "step" = one pass of the hot path over one batch of synthetic frames already
                   device, concentus_amd/silk_chain.py); parity per frame against the reference's own results.
   silk_frames_cbr the same on frames captured from a constant-bitrate encoder, with silk_encode_frame_FIX's bitrate loop: a rate-control
                   step after every pass, frames over / under budget quantised + coded again (about four passes per frame)
+  silk_streams    STREAMS MODE of the CBR chain: 65 536 streams, every step encodes two CONSECUTIVE frames of every stream with the
+                  inter-frame state (x_buf, prevLag, smoothers, NLSFs, gain index, the prefilter / quantiser states ...) carried on the
+                  device (opusgpu_silk_stream_carry_in / _out); the capture supplies the state before the first frame and, per frame,
+                  only what is computed outside silk_encode_frame_FIX (samples, VAD results, maxBits, the packet's coder).
   silk_analysis   the five analysis calls of silk_encode_frame_FIX between the VAD and the quantiser (silk_find_pitch_lags_FIX,
                   silk_noise_shape_analysis_FIX, silk_find_pred_coefs_FIX, silk_process_gains_FIX, silk_prefilter_FIX), 65 536
                   distinct captured records each; value = frames/s through all five.
@@ -70,7 +74,7 @@ CLOCK_HZ = 2.4e9                   # MI355X_MICROARCH.md: 2.4 GHz peak engine cl
 BYTES_FWD = 2 * 1080 * 4 + 2 * 960 * 4                   # 16 320 B / stereo frame  
 BYTES_BWD = 2 * 960 * 4 + 2 * 1080 * 4 + 2 * 120 * 4     # 17 280 B / stereo frame
 PCM_BYTES = 960 * 2 * 2                                   # 3 840 B / stereo frame
-WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "silk_frames", "silk_frames_cbr", "decode", "mixed"]
+WORKLOADS = ["celt", "celt_streams", "mdct", "silk", "silk_deldec", "silk_lpc", "silk_nlsf", "silk_pred", "silk_analysis", "silk_frames", "silk_frames_cbr", "silk_streams", "decode", "mixed"]
 
 
 def parse(argv=None):
@@ -276,6 +280,37 @@ def _pool_run(work, n):
         with ThreadPoolExecutor(threads) as ex:
             list(ex.map(lambda t: work(t * per, min(n, (t + 1) * per)), range(threads)))
     return run
+
+
+def cpu_baseline_silk_encoder(complexity=7):
+    """The reference's own opus_encode() as a 16 kHz mono VOIP constant-bitrate SILK encoder (32 kb/s, 20 ms frames) on synthetic
+    speech, one encoder per host thread (oracle/ref_driver.c refdrv_silk_encode_loop) -- the whole encoder, i.e. silk_encode_frame_FIX
+    plus what surrounds it (input filters, resampler, VAD, packet assembly). kind "reference"."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import silk_corpus
+    drv = _refdrv()
+    if drv is None or not hasattr(drv, "refdrv_silk_encode_loop"):
+        return _no_ref()
+    drv.refdrv_silk_encode_loop.restype = C.c_long
+    drv.refdrv_silk_encode_loop.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    cores = host_threads()
+    nfr = 1000
+    pcm = np.ascontiguousarray(silk_corpus.synth_voice(nfr * 320, 4242))
+    rates = []
+    for threads in (1, cores):
+        loops, t = 1, 0.0
+        while True:
+            t0 = time.perf_counter()
+            assert drv.refdrv_silk_encode_loop(_p(pcm), nfr, 320, 16000, 32000, 0, complexity, loops, threads) > 0
+            t = time.perf_counter() - t0
+            if t > 3.0 or loops >= 64:
+                break
+            loops *= 2
+        rates.append(nfr * loops * threads / t)
+    return {"value": round(rates[1], 1), "unit": "frames/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
+            "sample": "opus-fix opus_encode() as a 16 kHz mono VOIP CBR 32 kb/s SILK encoder (complexity %d) over 1 000 frames of synthetic speech, "
+                      "repeated >= 3 s, one encoder per thread at 1 and %d threads; the WHOLE encoder (input filters, VAD, packet assembly included); "
+                      "1 thread: %.0f frames/s" % (complexity, cores, rates[0])}
 
 
 def cpu_baseline_silk(bi, ni, st0):
@@ -854,6 +889,91 @@ def main(argv=None):
             if not cbr:
                 parity = {"checked": F, "note": "every frame: every stage's output record, pulses, Seed, all of silk_nsq_state and silk_prefilter_state_FIX, "
                                            "and the range coder (every field, every byte written) vs what the reference computed for the same frame"}
+    elif a.workload == "silk_streams":
+        NS = a.frames or 65536                     # streams per GPU
+        T = 2                                      # consecutive frames per stream and step
+        F = NS * T
+        steps = a.steps or 3
+        warm = a.warmup if a.warmup is not None else 1
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import silk_corpus
+        from concentus_amd import silk as S
+        from concentus_amd.silk_chain import SilkAnalysisChain, CHAIN_FED_FIELDS, CARRIED_FIELDS
+        from test_silk_stream_gpu import stream_state_from_capture, zero_fields
+        if not silk_corpus.available():
+            raise SystemExit("silk_streams needs oracle/_ref/libopus_ref_silkcap.so (streams are captured from the reference encoder)")
+        rec = {k: np.array(v) for k, v in silk_corpus.corpus(F, "chain_dd", seed=20260401 + 1000003 * rank, variant="wb20cbr", seg_frames=T).items()}
+        names = {"pitch_in": "c_pitch_in", "shape_in": "c_shape_in", "fpc_in": "c_fpc_in", "gains_in": "c_gains_in",
+                 "prefilter_in": "c_prefilter_in", "q_in": "c_q_in", "bits_in": "c_bits_in"}
+        rows0 = np.arange(NS) * T
+        chain = SilkAnalysisChain(16, 4)
+        frames_dev = []
+        for t in range(T):
+            rows = rows0 + t
+            host = {k: rec[v][rows].copy() for k, v in names.items()}
+            SI = host["shape_in"].view(np.dtype(S.NoiseShapeIn))[:, 0]
+            finp = np.ascontiguousarray(SI["x"][:, 160:160 + 320]).astype(np.int16)        # the frame's own samples (behind 2 x la_shape of history)
+            zero_fields(host, CHAIN_FED_FIELDS)
+            zero_fields(host, CARRIED_FIELDS)                                              # nothing inherited comes from the host
+            ctl = np.zeros(NS, dtype=np.dtype(S.RateCtl))
+            fargs = rec["c_frame_args"][rows].view(np.int32)
+            ctl["condCoding"], ctl["maxBits"], ctl["useCBR"], ctl["nb_subfr"], ctl["frame_length"] = fargs[:, 0], fargs[:, 1], fargs[:, 2], 4, 320
+            frames_dev.append({"in": {k: torch.from_numpy(v).to(dev) for k, v in host.items()}, "input": torch.from_numpy(finp).to(dev),
+                               "ctl0": torch.from_numpy(ctl.view(np.uint8).reshape(NS, -1).copy()).to(dev),
+                               "ec0": torch.from_numpy(rec["c_ec_in"][rows].copy()).to(dev)})
+            frames_dev[-1]["ctl"], frames_dev[-1]["ec"] = frames_dev[-1]["ctl0"].clone(), frames_dev[-1]["ec0"].clone()
+        st0 = torch.from_numpy(stream_state_from_capture(rec, rows0, S, True).view(np.uint8).reshape(NS, -1).copy()).to(dev)
+        pf0, nsq0 = (torch.from_numpy(rec[k][rows0].copy()).to(dev) for k in ("c_prefilter_state_in", "c_q_state_in"))
+        st, pf_st, nsq_st = st0.clone(), pf0.clone(), nsq0.clone()
+
+        def one_step():
+            st.copy_(st0); pf_st.copy_(pf0); nsq_st.copy_(nsq0)          # every step starts the streams again at their captured t = 0
+            res = None
+            for fd in frames_dev:
+                fd["ctl"].copy_(fd["ctl0"]); fd["ec"].copy_(fd["ec0"])
+                i = fd["in"]
+                res = chain.run(i["pitch_in"], i["shape_in"], i["fpc_in"], i["gains_in"], i["prefilter_in"], pf_st, i["q_in"], nsq_st, True,
+                                bits_in=i["bits_in"], ec_state=fd["ec"], rate_ctl=fd["ctl"], streams=st, frame_input=fd["input"])
+            return res
+        for _ in range(warm):
+            one_step()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            res = one_step()
+            ev[k][1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        kname = "silk_nsq_del_dec_kernel"
+        kbytes = F * (640 + 324 + 1328)            # per frame: the samples in, pulses + Seed and the packet's coder out (the states stay on the device)
+        limiter = "latency / VALU issue (lane-per-frame kernels of serial fixed-point recurrences; whole two-frame step timed)"
+        metric = "SILK 16kHz mono 20ms frames/sec, streams mode (silk_encode_frame_FIX incl. its bitrate loop, inter-frame state carried on the device)"
+        workload = ("%d streams per GPU x %d consecutive frames per step (16 kHz mono synthetic speech, 32 kb/s VOIP CBR, complexity 5/7/10 in turn): the state "
+                    "a frame inherits is carried on the device from frame to frame, the capture of the reference supplies it only before the "
+                    "first frame, and per frame what silk_encode_frame_FIX does not compute (samples, VAD results, maxBits, the packet's "
+                    "coder); bit-exact vs FIXED_POINT" % (NS, T))
+        dtype = "int16/int32/int64 fixed-point"
+        extra = {"note": "avg_launch_ms is the whole step: %d frames of every stream, each the chain + bitrate loop + carry kernels" % T,
+                 "streams": NS, "frames_per_stream_and_step": T}
+        cpu = cpu_baseline_silk_encoder
+        if not a.no_parity and rank == 0:
+            rows = rows0 + (T - 1)
+            misc = rec["c_frame_misc"][rows]
+            got_ctl = frames_dev[-1]["ctl"].cpu().numpy().view(np.dtype(S.RateCtl))[:, 0]
+            ok = (np.array_equal(res["pulses"].cpu().numpy().view(np.uint8), misc[:, :320])
+                  and np.array_equal(nsq_st.cpu().numpy(), rec["c_frame_nsq"][rows]) and np.array_equal(pf_st.cpu().numpy(), rec["c_prefilter_state_out"][rows])
+                  and np.array_equal(frames_dev[-1]["ec"].cpu().numpy(), rec["c_frame_ec"][rows])
+                  and np.array_equal(frames_dev[0]["ec"].cpu().numpy(), rec["c_frame_ec"][rows0])
+                  and np.array_equal(got_ctl["passes"], rec["c_frame_args"][rows].view(np.int32)[:, 3]))
+            if not ok:
+                raise SystemExit("PARITY FAILURE (silk_streams: the last frame of the streams, whose inherited state only the device supplied)")
+            parity = {"checked": F, "note": "both frames of every stream: the range coder after the frame (every field, every payload byte); the "
+                                           "second frame also pulses, all of silk_nsq_state / silk_prefilter_state_FIX and the number of passes -- "
+                                           "its inherited state came from the device only"}
     elif a.workload == "silk_analysis":
         F = a.frames or 65536
         steps = a.steps or 5

@@ -910,6 +910,26 @@ CA_DEVFN void compute_mdcts_wave(L &F, const FrameCtx &fc, int shortBlocks)
 }
 
 // ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
+// Reductions over the eight lanes of an aligned octet, every lane receiving the result: DPP lane permutations on the vector ALU
+// (quad_perm [1,0,3,2] and [2,3,0,1], then row_half_mirror, which swaps the two quads of an octet) -- no LDS crossbar traffic
+// (ds_bpermute shuffles cost an LDS operation each: measured, 1.79 -> 2.16 ms on the whole kernel).
+#if !defined(CA_SINGLE_LANE)
+#define CA_OCT_REDUCE(v, OP)                                                                 \
+    do {                                                                                     \
+        i32 _t;                                                                              \
+        _t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = OP(v, _t);        \
+        _t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = OP(v, _t);        \
+        _t = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = OP(v, _t);       \
+    } while (0)
+CA_DEV i32 oct_max(i32 v) { CA_OCT_REDUCE(v, CA_OP_MAX); return v; }
+CA_DEV i32 oct_min(i32 v) { CA_OCT_REDUCE(v, CA_OP_MIN); return v; }
+CA_DEV i32 oct_add(i32 v) { CA_OCT_REDUCE(v, CA_OP_ADD); return v; }
+#else
+CA_DEV i32 oct_max(i32 v) { return v; }
+CA_DEV i32 oct_min(i32 v) { return v; }
+CA_DEV i32 oct_add(i32 v) { return v; }
+#endif
+
 // Channel c alone, over all 64 lanes: a band's two reductions (largest magnitude, then the sum of squares at the shift that
 // magnitude fixes) are split into chunks of eight bins -- 100 chunks per channel, one lane each -- and combined per band by
 // the band's own lane: 8 + 22 dependent steps per reduction instead of the 176 of the widest band (maxima compose exactly,
@@ -926,8 +946,8 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
         for (int j = lane(); j < 8 * NCH; j += LANES) {
             const i32 v = X[j];
             i32 mx = imax(0, v), mn = imin(0, v);
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) { mx = imax(mx, shfl_xor(mx, m)); mn = imin(mn, shfl_xor(mn, m)); }
+            mx = oct_max(mx);
+            mn = oct_min(mn);
             if ((j & 7) == 0) { red[j >> 3] = mx; red[NCH + (j >> 3)] = mn; }
         }
     } else {
@@ -957,8 +977,7 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
                 const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
                 sum = mul16_16(v, v);
             }
-#pragma unroll
-            for (int m = 1; m < 8; m <<= 1) sum = add32(sum, shfl_xor(sum, m));
+            sum = oct_add(sum);
             if ((j & 7) == 0) red[2 * NCH + (j >> 3)] = sum;
         }
     } else {

@@ -52,6 +52,8 @@ SYMBOLS = [
     ("opusgpu_silk_vad_batch", _i, [_vp, _vp, _vp, _i, _vp]),
     ("opusgpu_silk_rate_control_batch", _i, [_vp, _vp, _i, _vp]),
     ("opusgpu_silk_encode_frames_batch", _i, [_vp, _i, _i, _i, _i, _vp]),
+    ("opusgpu_silk_stream_carry_in", _i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    ("opusgpu_silk_stream_carry_out", _i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     ("opusgpu_silk_encode_frames_cbr_workspace_bytes", C.c_size_t, [_i]),
     ("opusgpu_silk_encode_frames_cbr_batch", _i, [_vp, _vp, _i, _i, _i, _i, _vp, C.c_size_t, _vp, _vp]),
     ("opusgpu_silk_VAD_GetSA_Q8_c", _i, [_vp, _vp]),

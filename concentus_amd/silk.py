@@ -405,6 +405,16 @@ class RateCtl(C.Structure):
 SIZES["silk_rate_ctl"] = C.sizeof(RateCtl)
 
 
+class SilkStream(C.Structure):
+    """opusgpu_silk_stream: what silk_encode_frame_FIX carries from one frame of a stream to the next (include/opusgpu_silk.h)."""
+    _fields_ = [("x_buf", C.c_int16 * 400), ("prev_NLSFq_Q15", C.c_int16 * 16)] + [(k, C.c_int32) for k in (
+        "prevLag", "prevSignalType", "first_frame_after_reset", "LTPCorr_Q15", "sum_log_gain_Q7", "LastGainIndex", "HarmBoost_smth_Q16",
+        "HarmShapeGain_smth_Q16", "Tilt_smth_Q16", "ec_prevSignalType", "ec_prevLagIndex", "frameCounter")] + [("reserved", C.c_int32 * 4)]
+
+
+SIZES["silk_stream"] = C.sizeof(SilkStream)
+
+
 def silk_rate_control(rate_ctl, ec_state):
     """One step of silk_encode_frame_FIX's bitrate loop over a batch: rate_ctl uint8 [N][160] (opusgpu_silk_rate_ctl, updated in place),
     ec_state uint8 [N][1328] (the coder after the pass just coded; read only). Sets done / recode / save2 / restore2 per frame."""

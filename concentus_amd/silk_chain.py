@@ -56,7 +56,7 @@ class SilkAnalysisChain:
         dst[:, do:do + 4] = v.view(torch.uint8)
 
     def run(self, pitch_in, shape_in, fpc_in, gains_in, prefilter_in, prefilter_state, q_in, nsq_state, del_dec, bits_in=None, ec_state=None,
-            rate_ctl=None):
+            rate_ctl=None, streams=None, frame_input=None):
         """All arguments are uint8 CUDA tensors [N][record bytes]. shape_in / fpc_in / gains_in / prefilter_in / q_in are
         completed in place from the outputs of the earlier stages; prefilter_state and nsq_state are updated in place.
         q_in is opusgpu_nsq_dd_in when del_dec else opusgpu_nsq_in. With bits_in / ec_state (opusgpu_silk_bits_in with which = 3, the
@@ -65,7 +65,10 @@ class SilkAnalysisChain:
         nb_subfr, frame_length set, the rest zero) the bitrate loop of silk_encode_frame_FIX (encode_frame_FIX.c:263-423) runs as well:
         frames over / under their bit budget are quantised and coded again with adjusted gains, up to six more times, each time from
         the coder and quantiser state they entered with; nsq_state / ec_state / "pulses" / "Seed" / bits_in end as the reference
-        leaves them, rate_ctl holds LastGainIndex, GainsIndices and the number of passes. Returns a dict of the stage outputs;
+        leaves them, rate_ctl holds LastGainIndex, GainsIndices and the number of passes. STREAMS MODE: with streams (uint8 [N][sizeof
+        opusgpu_silk_stream], one record per stream, updated in place) and frame_input (int16 [N][320]: the frame's samples) the fields a
+        frame inherits from the previous one (CARRIED_FIELDS) are filled on the device before the frame and the stream records updated
+        after it (opusgpu_silk_stream_carry_in / _out); prefilter_state / nsq_state are then the streams' own. Returns a dict of the stage outputs;
         "pulses" is int8 [N][320] (and "Seed" int32 [N] for the delayed-decision quantiser)."""
         import torch
         from . import lib as _lib
@@ -96,6 +99,14 @@ class SilkAnalysisChain:
         bufs = ChainBufs(*[C.c_void_p(t.data_ptr() if t is not None else None) for t in (
             pitch_in, pitch_out, shape_in, shape_out, fpc_in, fpc_out, gains_in, gains_out, prefilter_in, prefilter_state, prefilter_out,
             q_in, nsq_state, q_out, bits_in, ec_state if bits_in is not None else None, bits_out, ws)], C.c_size_t(ws.numel()))
+        if streams is not None:
+            S._check(streams, S.SIZES["silk_stream"], "streams")
+            if not (frame_input is not None and frame_input.is_cuda and frame_input.dtype == torch.int16 and frame_input.is_contiguous()
+                    and tuple(frame_input.shape) == (n, 320) and streams.shape[0] == n):
+                raise ValueError("frame_input must be a contiguous int16 CUDA tensor [streams][320], one row per stream record")
+            _lib.check(L.opusgpu_silk_stream_carry_in(C.c_void_p(streams.data_ptr()), C.c_void_p(frame_input.data_ptr()), C.byref(bufs),
+                                                      self.fs_kHz, self.nb_subfr, 1 if del_dec else 0, n, _lib.current_stream_handle()),
+                       "opusgpu_silk_stream_carry_in")
         if rate_ctl is None:
             rc = L.opusgpu_silk_encode_frames_batch(C.byref(bufs), self.fs_kHz, self.nb_subfr, 1 if del_dec else 0, n, _lib.current_stream_handle())
             _lib.check(rc, "opusgpu_silk_encode_frames_batch")
@@ -109,6 +120,11 @@ class SilkAnalysisChain:
                                                         C.byref(passes), _lib.current_stream_handle())
             _lib.check(rc, "opusgpu_silk_encode_frames_cbr_batch")
             self.last_loop_iterations = passes.value
+        if streams is not None:
+            _lib.check(L.opusgpu_silk_stream_carry_out(C.c_void_p(streams.data_ptr()), C.byref(bufs),
+                                                       C.c_void_p(rate_ctl.data_ptr()) if rate_ctl is not None else None,
+                                                       self.fs_kHz, self.nb_subfr, n, _lib.current_stream_handle()),
+                       "opusgpu_silk_stream_carry_out")
         out = {"pitch_out": pitch_out, "shape_out": shape_out, "fpc_out": fpc_out, "gains_out": gains_out, "prefilter_out": prefilter_out,
                "pulses": q_out[:, :320].view(torch.int8)}
         if del_dec:
@@ -124,6 +140,16 @@ class SilkAnalysisChain:
             raise _lib.OpusGpuError(-1, "SilkAnalysisChain.run: %d record(s) failed the device-side checks (status fields of the *_out records)" % bad)
         return out
 
+
+CARRIED_FIELDS = {         # streams mode: the record fields opusgpu_silk_stream_carry_in fills from the stream record + the frame's samples
+    "pitch_in": (S.FindPitchLagsIn, ("x_buf", "prevLag", "prevSignalType", "first_frame_after_reset", "LTPCorr_Q15")),
+    "shape_in": (S.NoiseShapeIn, ("x", "HarmBoost_smth_Q16", "HarmShapeGain_smth_Q16", "Tilt_smth_Q16")),
+    "fpc_in": (S.FindPredCoefsIn, ("x", "prev_NLSFq_Q15", "first_frame_after_reset", "sum_log_gain_Q7")),
+    "gains_in": (S.ProcessGainsIn, ("LastGainIndex",)),
+    "prefilter_in": (S.PrefilterIn, ("x",)),
+    "q_in": (S.NsqIn, ("Seed",)),
+    "bits_in": (S.SilkBitsIn, ("Seed", "ec_prevSignalType", "ec_prevLagIndex")),
+}
 
 CHAIN_FED_FIELDS = {       # the record fields run() fills: a caller (and the test) may leave them zero
     "shape_in": (S.NoiseShapeIn, ("pitch_res", "signalType", "LTPCorr_Q15", "predGain_Q16", "pitchL")),

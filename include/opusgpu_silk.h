@@ -467,6 +467,37 @@ int opusgpu_silk_encode_frames_cbr_batch(const opusgpu_silk_chain_bufs *bufs, op
                                          int del_dec, int n, void *d_loop_workspace, size_t loop_workspace_bytes, int *passes,
                                          void *hip_stream);
 
+/* ---- streams mode: the state silk_encode_frame_FIX carries from frame to frame, on the device -----------------
+ * One record per stream holds what the frame function reads from the previous frame through psEnc (opus-fix/silk/fixed/
+ * encode_frame_FIX.c:128, :145, :427, :437-441 and the fields its analysis calls update): the tail of x_buf, prevLag / prevSignalType /
+ * first_frame_after_reset, LTPCorr_Q15, the noise-shaping smoothers and LastGainIndex of sShape, prev_NLSFq_Q15, sum_log_gain_Q7, the
+ * entropy coder's conditional-coding memory and frameCounter. The two big states (silk_prefilter_state_FIX, silk_nsq_state) are the
+ * opusgpu_prefilter_state / opusgpu_nsq_state arrays the chain already updates in place: keep one per stream.
+ * Per frame:  opusgpu_silk_stream_carry_in   (stream record + the frame's samples d_input[n][OPUSGPU_SILK_MAX_FRAME] -> the carried
+ *                                              fields of the frame's *_in records: x_buf and its slices, the scalars above, Seed)
+ *             opusgpu_silk_encode_frames_batch or ..._cbr_batch
+ *             opusgpu_silk_stream_carry_out  (the frame's outputs -> stream record; d_ctl = the bitrate loop's records or NULL)
+ * all asynchronous on one stream, nothing returning to the host between frames. What the caller still fills per frame is the INPUT
+ * of silk_encode_frame_FIX that is computed outside it: the samples (inputBuf after the encoder's own filters), the VAD results,
+ * SNR_dB_Q7, condCoding / maxBits / useCBR, the packet's range coder, and the configuration fields (constant per encoder setting).
+ * The field list is pinned on the reference by tests/test_silk_stream_cpu.py; tests/test_silk_stream_gpu.py runs streams of consecutive
+ * frames with captures at t = 0 only for the state and compares every frame's payload. A fresh stream: all zero except
+ * first_frame_after_reset = 1, prevLag = 100, LastGainIndex = 10 (silk_init_encoder / silk_control_encoder defaults). */
+typedef struct opusgpu_silk_stream {
+    int16_t x_buf[OPUSGPU_SILK_MAX_LTP_MEM + OPUSGPU_SILK_MAX_LA_SHAPE];   /* the ltp_mem_length + la_shape samples the next frame starts with */
+    int16_t prev_NLSFq_Q15[OPUSGPU_SILK_MAX_ORDER];
+    int32_t prevLag, prevSignalType, first_frame_after_reset, LTPCorr_Q15;
+    int32_t sum_log_gain_Q7, LastGainIndex;
+    int32_t HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16;
+    int32_t ec_prevSignalType, ec_prevLagIndex, frameCounter;
+    int32_t reserved[4];
+} opusgpu_silk_stream;
+
+int opusgpu_silk_stream_carry_in(const opusgpu_silk_stream *d_streams, const int16_t *d_input, const opusgpu_silk_chain_bufs *bufs,
+                                 int fs_kHz, int nb_subfr, int del_dec, int n, void *hip_stream);
+int opusgpu_silk_stream_carry_out(opusgpu_silk_stream *d_streams, const opusgpu_silk_chain_bufs *bufs, const opusgpu_silk_rate_ctl *d_ctl,
+                                  int fs_kHz, int nb_subfr, int n, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,48 @@ void refdrv_decode_frames(const unsigned char *packets, int stride, const int *l
     free(th);
     free(jobs);
 }
+
+/* ---- SILK: opus_encode() as a mono VOIP encoder (the SILK path), `threads` encoders in parallel, each coding the same `nframes`
+ * frames of `frame` samples `loops` times over; returns the bytes produced (so that nothing is optimised away). Used by bench.py
+ * as the CPU baseline of the SILK streams workload: the reference's whole encoder, timed by the caller. ---- */
+typedef struct { const int16_t *pcm; long nframes; int frame, fs, bitrate, vbr, complexity, loops; long bytes; } silk_job;
+
+static void *silk_worker(void *arg)
+{
+    silk_job *j = (silk_job *)arg;
+    int err = 0;
+    unsigned char out[1500];
+    OpusEncoder *enc = opus_encoder_create(j->fs, 1, 2048, &err);         /* OPUS_APPLICATION_VOIP */
+    if (!enc) return NULL;
+    opus_encoder_ctl(enc, 4002, j->bitrate);
+    opus_encoder_ctl(enc, 4006, j->vbr);
+    opus_encoder_ctl(enc, 4020, 0);
+    opus_encoder_ctl(enc, 4010, j->complexity);
+    opus_encoder_ctl(enc, 4012, 0);
+    opus_encoder_ctl(enc, 4016, 0);
+    opus_encoder_ctl(enc, 4014, 0);
+    opus_encoder_ctl(enc, 4036, 16);
+    for (int l = 0; l < j->loops; l++)
+        for (long f = 0; f < j->nframes; f++) {
+            int n = opus_encode(enc, j->pcm + f * j->frame, j->frame, out, 1500);
+            if (n > 0) j->bytes += n;
+        }
+    opus_encoder_destroy(enc);
+    return NULL;
+}
+
+long refdrv_silk_encode_loop(const int16_t *pcm, long nframes, int frame, int fs, int bitrate, int vbr, int complexity, int loops, int threads)
+{
+    if (threads < 1) threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
+    silk_job *jobs = (silk_job *)malloc(sizeof(silk_job) * threads);
+    long total = 0;
+    for (int i = 0; i < threads; i++) {
+        jobs[i] = (silk_job){pcm, nframes, frame, fs, bitrate, vbr, complexity, loops, 0};
+        pthread_create(&th[i], NULL, silk_worker, &jobs[i]);
+    }
+    for (int i = 0; i < threads; i++) { pthread_join(th[i], NULL); total += jobs[i].bytes; }
+    free(th);
+    free(jobs);
+    return total;
+}

@@ -398,7 +398,7 @@ def _files(cache, kind, n, mode):
     return out
 
 
-def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=20260401, variant="wb20"):
+def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=20260401, variant="wb20", seg_frames=None):
     """n distinct records: kind "nsq" -> burg_in/burg_out/nsq_in/nsq_state_in/nsq_state_out/nsq_out captured at
     complexity 3 (silk_NSQ_c, control_codec.c:333-343); kind "dd" -> dd_in/dd_state_in/dd_state_out/dd_out captured at
     complexities 5 / 7 / 10 in turn (2 / 3 / 4 delayed-decision states). Returns read-only memory maps."""
@@ -407,11 +407,14 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
     # kind "fpc": silk_find_pred_coefs_FIX whole (voiced and unvoiced frames), complexities as "lpc"
     # kind "pred": silk_process_NLSFs + silk_residual_energy_FIX (the tail of silk_find_pred_coefs_FIX), complexities as "lpc"
     # kind "lpc": silk_find_LPC_FIX at complexity 3 (no NLSF interpolation: Burg + A2NLSF) and 5 / 8 / 10 (interpolation search)
+    # seg_frames: frames per segment = consecutive frames of ONE encoder (rows [k * seg_frames, (k + 1) * seg_frames) are a stream, in
+    # order: the streams-mode tests and bench take S = n / seg_frames streams of T = seg_frames frames from this)
+    seg = seg_frames or SEG_FRAMES
     complexities = complexities or ((3,) if kind in ("nsq", "chain_nsq") else (5, 7, 10) if kind in ("dd", "chain_dd") else (3, 5, 8, 10))
     # one directory per (kind, size, complexities, seed): ranks of a multi-GPU job ask for different seeds at the same time
     cache = os.path.join(cache or os.environ.get("CONCENTUS_SILK_CACHE", "/tmp/concentus_silk_corpus"),
-                         "%s%s_%d_%s_%d%s" % (kind, "_v2" if kind.startswith("chain") else "", n, "-".join(map(str, complexities)), seed,
-                                              "" if variant == "wb20" else "_" + variant))
+                         "%s%s_%d_%s_%d%s%s" % (kind, "_v2" if kind.startswith("chain") else "", n, "-".join(map(str, complexities)), seed,
+                                                "" if variant == "wb20" else "_" + variant, "" if seg == SEG_FRAMES else "_seg%d" % seg))
     done = os.path.join(cache, "done")
     if not os.path.exists(done):
         if under_profiler():
@@ -428,7 +431,7 @@ def corpus(n, kind="nsq", complexities=None, workers=None, cache=None, seed=2026
             f.flush()
         jobs, row = [], 0
         while row < n:
-            take = min(SEG_FRAMES, n - row)
+            take = min(seg, n - row)
             k = len(jobs)
             jobs.append((cache, kind, seed + 7919 * k + {"nsq": 0, "dd": 104729, "lpc": 1299709, "pred": 15485863, "fpc": 32452843, "gains": 49979687, "shape": 67867967, "prefilter": 86028121, "pitch": 104395301, "bits": 160481183, "vad": 179424673, "chain_nsq": 122949823, "chain_dd": 141650939}[kind], complexities[k % len(complexities)],
                          row, take, n, variant))
