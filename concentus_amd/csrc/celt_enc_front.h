@@ -910,26 +910,6 @@ CA_DEVFN void compute_mdcts_wave(L &F, const FrameCtx &fc, int shortBlocks)
 }
 
 // ---- compute_band_energies + amp2Log2 (bands.c:97-142, quant_bands.c:551-575) -----------------------
-// Reductions over the eight lanes of an aligned octet, every lane receiving the result: DPP lane permutations on the vector ALU
-// (quad_perm [1,0,3,2] and [2,3,0,1], then row_half_mirror, which swaps the two quads of an octet) -- no LDS crossbar traffic
-// (ds_bpermute shuffles cost an LDS operation each: measured, 1.79 -> 2.16 ms on the whole kernel).
-#if !defined(CA_SINGLE_LANE)
-#define CA_OCT_REDUCE(v, OP)                                                                 \
-    do {                                                                                     \
-        i32 _t;                                                                              \
-        _t = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = OP(v, _t);        \
-        _t = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = OP(v, _t);        \
-        _t = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = OP(v, _t);       \
-    } while (0)
-CA_DEV i32 oct_max(i32 v) { CA_OCT_REDUCE(v, CA_OP_MAX); return v; }
-CA_DEV i32 oct_min(i32 v) { CA_OCT_REDUCE(v, CA_OP_MIN); return v; }
-CA_DEV i32 oct_add(i32 v) { CA_OCT_REDUCE(v, CA_OP_ADD); return v; }
-#else
-CA_DEV i32 oct_max(i32 v) { return v; }
-CA_DEV i32 oct_min(i32 v) { return v; }
-CA_DEV i32 oct_add(i32 v) { return v; }
-#endif
-
 // Channel c alone, over all 64 lanes: a band's two reductions (largest magnitude, then the sum of squares at the shift that
 // magnitude fixes) are split into chunks of eight bins -- 100 chunks per channel, one lane each -- and combined per band by
 // the band's own lane: 8 + 22 dependent steps per reduction instead of the 176 of the widest band (maxima compose exactly,
@@ -940,24 +920,15 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
     const i32 *X = xf_row(F, c);
     i32 *red = reinterpret_cast<i32 *>(F.s.f2);                 // [0,100) chunk max, [100,200) chunk min, [200,300) chunk sums, [300,321) band shift
     constexpr int NCH = 100;                                    // CLT_eband5ms[NB] chunks of eight bins (LM 3)
-    if constexpr (LANES == 64) {
-        // one BIN per lane (consecutive lanes read consecutive words: no bank conflicts), a chunk = eight neighbouring lanes,
-        // combined with three xor-shuffles
-        for (int j = lane(); j < 8 * NCH; j += LANES) {
-            const i32 v = X[j];
-            i32 mx = imax(0, v), mn = imin(0, v);
-            mx = oct_max(mx);
-            mn = oct_min(mn);
-            if ((j & 7) == 0) { red[j >> 3] = mx; red[NCH + (j >> 3)] = mn; }
-        }
-    } else {
-        for (int ch = lane(); ch < NCH; ch += LANES) {
-            i32 mx = 0, mn = 0;
+    // (a lane reads its chunk's eight consecutive words -- 32-byte stride across lanes, some bank conflicts. The conflict-free
+    // alternative, one bin per lane and a cross-lane reduction per octet, was measured SLOWER, 1.79 -> 2.07 ms on the whole kernel
+    // with DPP reductions, 2.16 with ds_bpermute ones: this kernel is bound by vector-ALU issue, not by the LDS.)
+    for (int ch = lane(); ch < NCH; ch += LANES) {
+        i32 mx = 0, mn = 0;
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const i32 v = X[8 * ch + u]; mx = imax(mx, v); mn = imin(mn, v); }
-            red[ch] = mx;
-            red[NCH + ch] = mn;
-        }
+        for (int u = 0; u < 8; u++) { const i32 v = X[8 * ch + u]; mx = imax(mx, v); mn = imin(mn, v); }
+        red[ch] = mx;
+        red[NCH + ch] = mn;
     }
     wave_sync();
     for (int b = lane(); b < NB; b += LANES) {
@@ -968,32 +939,18 @@ CA_DEVFN void band_energies_channel(L &F, int c, i16 *bandLogE)
         red[3 * NCH + b] = maxval > 0 ? celt_ilog2(maxval) - 14 + (((CLT_logN400[b] >> 3) + LM3 + 1) >> 1) : 0x7fff;
     }
     wave_sync();
-    if constexpr (LANES == 64) {
-        for (int j = lane(); j < 8 * NCH; j += LANES) {
-            const int shift = red[3 * NCH + CLT_bin2band[j >> 3]];
-            i32 sum = 0;
-            if (shift != 0x7fff) {
-                const i32 x = X[j];
-                const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
-                sum = mul16_16(v, v);
-            }
-            sum = oct_add(sum);
-            if ((j & 7) == 0) red[2 * NCH + (j >> 3)] = sum;
-        }
-    } else {
-        for (int ch = lane(); ch < NCH; ch += LANES) {
-            const int shift = red[3 * NCH + CLT_bin2band[ch]];
-            i32 sum = 0;
-            if (shift != 0x7fff) {
+    for (int ch = lane(); ch < NCH; ch += LANES) {
+        const int shift = red[3 * NCH + CLT_bin2band[ch]];
+        i32 sum = 0;
+        if (shift != 0x7fff) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const i32 x = X[8 * ch + u];
-                    const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
-                    sum = mac16_16(sum, v, v);
-                }
+            for (int u = 0; u < 8; u++) {
+                const i32 x = X[8 * ch + u];
+                const i32 v = shift > 0 ? (i16)(x >> shift) : (i16)shl32(x, -shift);
+                sum = mac16_16(sum, v, v);
             }
-            red[2 * NCH + ch] = sum;
         }
+        red[2 * NCH + ch] = sum;
     }
     wave_sync();
     for (int b = lane(); b < NB; b += LANES) {

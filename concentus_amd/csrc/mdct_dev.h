@@ -23,6 +23,7 @@ struct MdctTab {
     const u32 *trig;
     const i16 *bitrev;
     const i16 *window;
+    const i16 *bitrev_sw;          // shift 0: fsw<0>(bitrev[i]), where the pre-rotation of the long transform stores input i
 };
 
 template <int SHIFT>
@@ -35,6 +36,7 @@ CA_DEV MdctTab mdct_global_tab()
     t.bitrev = SHIFT == 0 ? CLT_fft_bitrev480 : SHIFT == 1 ? CLT_fft_bitrev240
              : SHIFT == 2 ? CLT_fft_bitrev120 : CLT_fft_bitrev60;
     t.window = CLT_window120;
+    t.bitrev_sw = CLT_fft_bitrev480_sw;
     return t;
 }
 
@@ -56,6 +58,7 @@ CA_DEV MdctTab mdct_stage_tables(MdctLds &L, int tid, int nthreads)
     for (int i = tid; i < 120; i += nthreads) L.window[i] = g.window[i];
     MdctTab t;
     t.tw = L.tw; t.trig = L.trig; t.bitrev = L.bitrev; t.window = L.window;
+    t.bitrev_sw = g.bitrev_sw;
     return t;
 }
 
@@ -109,14 +112,36 @@ template <int SHIFT>
 CA_DEV int fsw(int e)
 {
     if constexpr (SHIFT == 0) {
-        // LUT[t], t = e >> 5 = 0..14: 9 4 2 15 3 14 8 5 11 14 1 4 2 7 8, four bits each, pre-shifted left by one
-        constexpr unsigned long long LUT = (9ull << 1) | (4ull << 5) | (2ull << 9) | (15ull << 13) | (3ull << 17) | (14ull << 21)
-            | (8ull << 25) | (5ull << 29) | (11ull << 33) | (14ull << 37) | (1ull << 41) | (4ull << 45) | (2ull << 49) | (7ull << 53)
-            | (8ull << 57);
+        // LUT[t], t = e >> 5 = 0..14, four bits each, pre-shifted left by one: CLT_FSW_LUT (celt_tables.h, tools/gen_tables.py)
+        constexpr unsigned long long LUT = CLT_FSW_LUT;
         const int s = (int)(LUT >> ((e >> 3) & 60)) & 30;
         return e ^ s ^ ((e >> 2) & 4);
     } else {
         return e;
+    }
+}
+
+// The P members e, e + M, ..., e + (P - 1) M of a butterfly. The transforms are issue-bound on the vector ALU (1 850 wave
+// instructions each, PMC), so the swizzle is not evaluated member by member: the members of a butterfly share the 64-bit LUT
+// shifted to the first one's block, differ in which 32-point block they fall in by a compile-time amount, and bit 4 of the index
+// is the same for all of them (M = 32, 96) or a compile-time function of the member (M = 8).
+template <int SW, int P, int M>
+CA_DEV void fft_members(int e, int (&a)[P])
+{
+    if constexpr (SW != 0) {
+#pragma unroll
+        for (int c = 0; c < P; c++) a[c] = e + c * M;
+    } else if constexpr (M == 8) {
+        // e = 32 g + j, j < 8: one block, s the same for the four; e + 8 c = e ^ 8 c, and bit 4 of it is c >> 1
+        const int A = e ^ ((int)(CLT_FSW_LUT >> ((e >> 3) & 60)) & 30);
+#pragma unroll
+        for (int c = 0; c < P; c++) a[c] = A ^ ((8 * c) ^ (4 * (c >> 1)));
+    } else {
+        static_assert(M % 32 == 0, "members whole blocks apart");
+        const unsigned long long W = CLT_FSW_LUT >> ((e >> 3) & 60);
+        const int E = e ^ ((e >> 2) & 4);
+#pragma unroll
+        for (int c = 0; c < P; c++) a[c] = (E + c * M) ^ ((int)(W >> (4 * ((c * M) >> 5))) & 30);
     }
 }
 
@@ -193,9 +218,10 @@ CA_DEV void fft_first8(int2 *x, int lane)
     lane = fft_lane(lane);
     for (int g = lane; g < NFFT / 8; g += LANES) {
         cpx v[8];
+        const int A = fsw<SHIFT>(8 * g);                                // the four pairs of a lane: fsw(8 g + 2 q) = fsw(8 g) ^ 2 q
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const cpx2 t = ld2(x + fsw<SHIFT>(8 * g + 2 * q));
+            const cpx2 t = ld2(x + (A ^ (2 * q)));
             v[2 * q] = t.a;
             v[2 * q + 1] = t.b;
         }
@@ -225,7 +251,7 @@ CA_DEV void fft_first8(int2 *x, int lane)
             v[7] = c_sub(v[3], t); v[3] = c_add(v[3], t);
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) st2(x + fsw<SHIFT>(8 * g + 2 * q), v[2 * q], v[2 * q + 1]);
+        for (int q = 0; q < 4; q++) st2(x + (A ^ (2 * q)), v[2 * q], v[2 * q + 1]);
     }
 }
 
@@ -242,7 +268,9 @@ CA_DEV void fft_radix4(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:146-176
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
         const int e = blk * NFFT + g * 4 * M + j;
-        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M), *f3p = x + fsw<SW>(e + 3 * M);
+        int m[4];
+        fft_members<SW, 4, M>(e, m);
+        int2 *f0p = x + m[0], *f1p = x + m[1], *f2p = x + m[2], *f3p = x + m[3];
         cpx f0 = ld(f0p);
         cpx a = c_mul(ld(f1p), tw[j * TWS]);
         cpx b = c_mul(ld(f2p), tw[2 * j * TWS]);
@@ -272,7 +300,9 @@ CA_DEV void fft_radix3(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:185-241
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, j = r % M;
         const int e = blk * NFFT + g * 3 * M + j;
-        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M);
+        int m[3];
+        fft_members<SW, 3, M>(e, m);
+        int2 *f0p = x + m[0], *f1p = x + m[1], *f2p = x + m[2];
         cpx f0 = ld(f0p);
         cpx a = c_mul(ld(f1p), tw[j * TWS]);
         cpx b = c_mul(ld(f2p), tw[2 * j * TWS]);
@@ -301,8 +331,9 @@ CA_DEV void fft_radix5(int2 *x, const u32 *tw, int lane)   // kiss_fft.c:245-322
         int blk = idx / (G * M), r = idx % (G * M);
         int g = r / M, u = r % M;
         const int e = blk * NFFT + g * 5 * M + u;
-        int2 *f0p = x + fsw<SW>(e), *f1p = x + fsw<SW>(e + M), *f2p = x + fsw<SW>(e + 2 * M), *f3p = x + fsw<SW>(e + 3 * M),
-             *f4p = x + fsw<SW>(e + 4 * M);
+        int m[5];
+        fft_members<SW, 5, M>(e, m);
+        int2 *f0p = x + m[0], *f1p = x + m[1], *f2p = x + m[2], *f3p = x + m[3], *f4p = x + m[4];
         cpx s0 = ld(f0p);
         cpx s1 = c_mul(ld(f1p), tw[u * TWS]);
         cpx s2 = c_mul(ld(f2p), tw[2 * u * TWS]);
@@ -443,13 +474,13 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
                     vb[k] = k == 3 ? mdct_fwd_pre<SHIFT>(sin, ia[k] + 120, T) : mdct_fwd_pre_mid<SHIFT>(sin, ia[k] + 120, T);
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) st2(f2 + fsw<0>(bitrev[ia[k]]), va[k], vb[k]);
+                for (int k = 0; k < 4; k++) st2(f2 + T.bitrev_sw[ia[k]], va[k], vb[k]);
             } else {
                 CA_FFT_ROLLED
                 for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
                     const int i = fft_pair_input(n0 + lane);
                     const cpx a = mdct_fwd_pre<SHIFT>(sin, i, T), b = mdct_fwd_pre<SHIFT>(sin, i + 120, T);
-                    st2(f2 + fsw<0>(bitrev[i]), a, b);
+                    st2(f2 + T.bitrev_sw[i], a, b);
                 }
             }
         }
@@ -496,7 +527,7 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
             CA_FFT_UNROLL(PRE)
             for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
                 const int i = fft_pair_input(n0 + lane);
-                st2(f2 + fsw<0>(bitrev[i]), pre(0, i), pre(0, i + 120));
+                st2(f2 + T.bitrev_sw[i], pre(0, i), pre(0, i + 120));
             }
         }
     } else {

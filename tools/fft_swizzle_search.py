@@ -31,7 +31,7 @@ G_R128 = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6
 G_R128 += [[x + 32 for x in g] for g in G_R128]
 G_W128 = [list(range(i, i + 8)) for i in range(0, 64, 8)]
 KINDS = {"r64": (8, G_R64, 64), "w64": (8, G_W64, 32), "r128": (16, G_R128, 64), "w128": (16, G_W128, 32)}
-LUT = [9, 4, 2, 15, 3, 14, 8, 5, 11, 14, 1, 4, 2, 7, 8, 0]          # fsw<0>
+LUT = list(gt.FSW_LUT) + [0]                                        # fsw<0> (tools/gen_tables.py is the one place that states it)
 
 
 def fsw(e, lut=LUT):

@@ -418,6 +418,15 @@ LITERAL_TABLES = [
 ]
 
 
+# Bank swizzle of the 480-point FFT scratch (concentus_amd/csrc/mdct_dev.h fsw<0>, searched by tools/fft_swizzle_search.py):
+# point e lives at e ^ (FSW_LUT[e >> 5] << 1) ^ (((e >> 4) & 1) << 2)
+FSW_LUT = [9, 4, 2, 15, 3, 14, 8, 5, 11, 14, 1, 4, 2, 7, 8]
+
+
+def fsw(e):
+    return e ^ (FSW_LUT[e >> 5] << 1) ^ (((e >> 4) & 1) << 2)
+
+
 def all_tables():
     idx, bits, caps = pulse_cache()
     tw = fft_twiddles(480)
@@ -454,6 +463,8 @@ def all_tables():
         b2b += [i] * (EBAND5MS[i + 1] - EBAND5MS[i])
     b2b += [NB_EBANDS] * (120 - len(b2b))
     t["bin2band"] = ("uint8_t", b2b)
+    # where the pre-rotation of the long transform puts input i: the bit-reversed position, bank-swizzled
+    t["fft_bitrev480_sw"] = ("int16_t", [fsw(v) for v in t["fft_bitrev480"][1]])
     return t
 
 
@@ -471,6 +482,9 @@ def emit(path, prefix="CLT_"):
         "#endif",
         "",
     ]
+    lines.append("/* fsw<0> of mdct_dev.h: LUT[t] << (4 t + 1), t = 0..14 */")
+    lines.append("#define %sFSW_LUT 0x%xull" % (prefix, sum(v << (4 * k + 1) for k, v in enumerate(FSW_LUT))))
+    lines.append("")
     for name, (ctype, vals) in t.items():
         lines.append("CLT_TABLE_QUAL %s %s%s[%d] = {" % (ctype, prefix, name, len(vals)))
         row = []
