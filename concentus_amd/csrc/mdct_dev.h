@@ -86,12 +86,9 @@ CA_DEV cpx c_sub(cpx a, cpx b) { return cpx{sub32(a.r, b.r), sub32(a.i, b.i)}; }
 // wavefronts of the SIMD, not the next trip of the same one, that cover a trip's LDS round trip.
 #if defined(CA_HOST_EMU)
 #define CA_FFT_ROLLED
-#define CA_FFT_UNROLL(n)
 CA_DEV int fft_lane(int lane) { return lane; }
 #else
 #define CA_FFT_ROLLED _Pragma("clang loop unroll(disable)")
-#define CA_FFT_PRAGMA(x) _Pragma(#x)
-#define CA_FFT_UNROLL(n) CA_FFT_PRAGMA(clang loop unroll_count(n))
 // the lane index as a value the compiler cannot see through: every stage derives its addresses from it afresh, so the
 // address arithmetic of a later stage is not hoisted above the earlier ones (where it would only hold registers)
 CA_DEV int fft_lane(int lane) { asm volatile("" : "+v"(lane)); return lane; }
@@ -432,28 +429,13 @@ CA_DEV cpx mdct_fwd_pre(const i32 *in, int i, const MdctTab &T)
     return cpx{pshr32(mul16_32_q16(17476, yr), SCALE_SHIFT), pshr32(mul16_32_q16(17476, yi), SCALE_SHIFT)};
 }
 
-// ... of an input point known to lie between the two window regions (Q <= i < N4 - Q)
-template <int SHIFT>
-CA_DEV cpx mdct_fwd_pre_mid(const i32 *in, int i, const MdctTab &T)
-{
-    constexpr int N2 = 960 >> SHIFT, OV2 = 60;
-    constexpr int SCALE_SHIFT = (8 - SHIFT) - 1;
-    const i32 re = in[N2 - 1 + OV2 - 2 * i], im = in[OV2 + 2 * i];
-    const u32 t = T.trig[i];
-    const i32 t0 = lo16(t), t1 = hi16(t);
-    const i32 yr = sub32(CA_SMUL(re, t0), CA_SMUL(im, t1));
-    const i32 yi = add32(CA_SMUL(im, t0), CA_SMUL(re, t1));
-    return cpx{pshr32(mul16_32_q16(17476, yr), SCALE_SHIFT), pshr32(mul16_32_q16(17476, yi), SCALE_SHIFT)};
-}
-
 // Lane schedule of the pre-rotation of the long transform: inputs i and i + 120 land on neighbouring points (bitrev[i + 120]
 // == bitrev[i] + 1 for i in [0, 120) and [240, 360)), so one lane produces both and stores them as ONE 16-byte unit; 240
 // such pairs, 60 per trip (the lanes of a trip read consecutive inputs: same coalescing as a plain sweep).
 enum { FFT_PAIRS = 240, FFT_PAIR_STEP = LANES >= 60 ? 60 : LANES };
 CA_DEV int fft_pair_input(int n) { return n < 120 ? n : n + 120; }
 
-// PRE: trips of the pre-rotation loop the compiler may keep in flight together (1 = rolled: least registers)
-template <int SHIFT, int B, int PRE = 1>
+template <int SHIFT, int B>
 CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, const MdctTab &T, int lane)
 {
     const u32 *trig = T.trig;
@@ -461,27 +443,12 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
     constexpr int N2 = 960 >> SHIFT, N4 = N2 / 2, NFFT = N4;
     if constexpr (SHIFT == 0 && B == 1) {
         static_assert(FFT_PAIRS % FFT_PAIR_STEP == 0, "whole trips");
-        if (lane < FFT_PAIR_STEP) {                                    // the guard outside the loop: trips can overlap their loads
-            if constexpr (LANES == 64 && PRE > 1) {
-                // the four trips written out: of their eight inputs per lane only the first (i = lane < 30) and the last
-                // (i = 420 + lane >= 450) touch the window; the other six are the plain middle case (mdct.c:178-189), whose two
-                // loads have no condition in front of them and are issued together
-                const int ia[4] = {lane, 60 + lane, 240 + lane, 300 + lane};
-                cpx va[4], vb[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    va[k] = k == 0 ? mdct_fwd_pre<SHIFT>(sin, ia[k], T) : mdct_fwd_pre_mid<SHIFT>(sin, ia[k], T);
-                    vb[k] = k == 3 ? mdct_fwd_pre<SHIFT>(sin, ia[k] + 120, T) : mdct_fwd_pre_mid<SHIFT>(sin, ia[k] + 120, T);
-                }
-#pragma unroll
-                for (int k = 0; k < 4; k++) st2(f2 + T.bitrev_sw[ia[k]], va[k], vb[k]);
-            } else {
-                CA_FFT_ROLLED
-                for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
-                    const int i = fft_pair_input(n0 + lane);
-                    const cpx a = mdct_fwd_pre<SHIFT>(sin, i, T), b = mdct_fwd_pre<SHIFT>(sin, i + 120, T);
-                    st2(f2 + T.bitrev_sw[i], a, b);
-                }
+        if (lane < FFT_PAIR_STEP) {
+            CA_FFT_ROLLED
+            for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
+                const int i = fft_pair_input(n0 + lane);
+                const cpx a = mdct_fwd_pre<SHIFT>(sin, i, T), b = mdct_fwd_pre<SHIFT>(sin, i + 120, T);
+                st2(f2 + T.bitrev_sw[i], a, b);
             }
         }
     } else {
@@ -506,7 +473,7 @@ CA_DEV void mdct_forward_wave(const i32 *sin, int2 *f2, i32 *dst, int dstride, c
 // Inverse MDCT of B blocks. Coefficient k of block b is src[(k*B + b) * sstride]; block b produces
 // out[b*N2 + 60 .. b*N2 + 60 + N2) and TDAC-mixes out[b*N2 .. b*N2+120) (the first 60 samples of
 // block 0 are the previous frame's tail). src must not alias out.    Reference: mdct.c:263-363.
-template <int SHIFT, int B, int PRE = 1>
+template <int SHIFT, int B>
 CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, const MdctTab &T, int lane)
 {
     const u32 *trig = T.trig;
@@ -524,7 +491,7 @@ CA_DEV void mdct_backward_wave(const i32 *src, int sstride, int2 *f2, i32 *out, 
     };
     if constexpr (SHIFT == 0 && B == 1) {
         if (lane < FFT_PAIR_STEP) {                                    // pairs (i, i + 120): see mdct_forward_wave
-            CA_FFT_UNROLL(PRE)
+            CA_FFT_ROLLED
             for (int n0 = 0; n0 < FFT_PAIRS; n0 += FFT_PAIR_STEP) {
                 const int i = fft_pair_input(n0 + lane);
                 st2(f2 + T.bitrev_sw[i], pre(0, i), pre(0, i + 120));

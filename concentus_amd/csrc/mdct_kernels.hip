@@ -10,9 +10,6 @@
 #include "mdct_dev.h"
 #include "opusgpu_internal.h"
 #include <stdlib.h>
-#ifndef OPUSGPU_MDCT_PRE_DEFAULT
-#define OPUSGPU_MDCT_PRE_DEFAULT 1
-#endif
 
 namespace ca {
 
@@ -26,10 +23,13 @@ struct __align__(16) MdctFftLds {
     __align__(16) int2 f2[480];
 };
 
-// OCC = wavefronts per SIMD the register budget must admit (second __launch_bounds__ argument): 8 = all 32 wavefront slots of a
-// CU, so that the 8 192 transforms of config #2 (32 per CU) are resident in ONE round instead of 24 + 8 (opusgpu_mdct_occupancy()).
-template <int SHIFT, int OCC, int PRE = 1>
-__global__ __launch_bounds__(64, OCC) void mdct_forward_kernel(const i32 *__restrict__ sig, i32 *__restrict__ freq,
+// __launch_bounds__(64, 8): the register budget of eight wavefronts per SIMD = all 32 wavefront slots of a CU, so that the 8 192
+// transforms of config #2 (32 per CU) are resident in ONE round; the kernels need 53 / 57 VGPRs (mdct_dev.h: every stage derives its
+// addresses from an opaque copy of the lane index, which keeps the compiler from hoisting them across stages). Tried on top of this
+// and dropped, all measured at 4 096 and 65 536 frames (gpurun_out/r03_c, r03_f): keeping 2 or 4 trips of the pre-rotation's loads in
+// flight (no change), a start-up stagger of the wavefront layers of a one-round launch (monotonically slower).
+template <int SHIFT>
+__global__ __launch_bounds__(64, 8) void mdct_forward_kernel(const i32 *__restrict__ sig, i32 *__restrict__ freq,
                                                                int ntransforms)
 {
     constexpr int B = 1 << SHIFT;
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(64, OCC) void mdct_forward_kernel(const i32 *__rest
     const int lane = threadIdx.x;
     const MdctTab T = mdct_global_tab<SHIFT>();   // 5 KB of tables: L1-resident
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
-        mdct_forward_wave<SHIFT, B, PRE>(sig + (size_t)t * 1080, S.f2, freq + (size_t)t * 960, 1, T, lane);
+        mdct_forward_wave<SHIFT, B>(sig + (size_t)t * 1080, S.f2, freq + (size_t)t * 960, 1, T, lane);
         wave_sync();
     }
 }
 
-template <int SHIFT, int OCC, int PRE = 1>
-__global__ __launch_bounds__(64, OCC) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *sig, int ntransforms)
+template <int SHIFT>
+__global__ __launch_bounds__(64, 8) void mdct_backward_kernel(const i32 *__restrict__ freq, i32 *sig, int ntransforms)
 {
     constexpr int B = 1 << SHIFT;
     __shared__ MdctFftLds S;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64, OCC) void mdct_backward_kernel(const i32 *__res
     const MdctTab T = mdct_global_tab<SHIFT>();
     for (int t = blockIdx.x; t < ntransforms; t += gridDim.x) {
         // out[0, 60) (the previous frame's tail) is live on entry, [60, 1020) is produced, [1020, 1080) untouched (mdct.c:345-361)
-        mdct_backward_wave<SHIFT, B, PRE>(freq + (size_t)t * 960, 1, S.f2, sig + (size_t)t * 1080, T, lane);
+        mdct_backward_wave<SHIFT, B>(freq + (size_t)t * 960, 1, S.f2, sig + (size_t)t * 1080, T, lane);
         wave_sync();
     }
 }
@@ -131,14 +131,6 @@ static int grid_for(int ntransforms, int waves_per_cu)
 
 using namespace ca;
 
-// trips of the pre-rotation loop kept in flight by the long-transform batch kernels (OPUSGPU_MDCT_PRE = 1 | 2 | 4; all builds hold
-// the <= 64-VGPR budget of eight wavefronts per SIMD). Read per call so that a bench can compare them.
-static int opusgpu_mdct_pre(void)
-{
-    const char *e = getenv("OPUSGPU_MDCT_PRE");
-    return e ? atoi(e) : OPUSGPU_MDCT_PRE_DEFAULT;
-}
-
 extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq, int n_frames, int channels,
                                           int shift, void *stream)
 {
@@ -150,11 +142,8 @@ extern "C" int opusgpu_mdct_forward_batch(const int32_t *d_sig, int32_t *d_freq,
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = nt;        // one transform per one-wave workgroup: nothing is staged per workgroup, the dispatcher balances
-    const int pre = opusgpu_mdct_pre();
-    if (shift == 0 && pre == 2) hipLaunchKernelGGL((mdct_forward_kernel<0, 8, 2>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
-    else if (shift == 0 && pre == 4) hipLaunchKernelGGL((mdct_forward_kernel<0, 8, 4>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
-    else if (shift == 0) hipLaunchKernelGGL((mdct_forward_kernel<0, 8, 1>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
-    else                 hipLaunchKernelGGL((mdct_forward_kernel<3, 1>), dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    if (shift == 0) hipLaunchKernelGGL(mdct_forward_kernel<0>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
+    else            hipLaunchKernelGGL(mdct_forward_kernel<3>, dim3(grid), dim3(64), 0, s, d_sig, d_freq, nt);
     return opusgpu_check_launch();
 }
 
@@ -169,11 +158,8 @@ extern "C" int opusgpu_mdct_backward_batch(const int32_t *d_freq, int32_t *d_sig
     if (!d_sig || !d_freq) return OPUSGPU_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int grid = nt;
-    const int pre = opusgpu_mdct_pre();
-    if (shift == 0 && pre == 2) hipLaunchKernelGGL((mdct_backward_kernel<0, 8, 2>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
-    else if (shift == 0 && pre == 4) hipLaunchKernelGGL((mdct_backward_kernel<0, 8, 4>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
-    else if (shift == 0) hipLaunchKernelGGL((mdct_backward_kernel<0, 8, 1>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
-    else                 hipLaunchKernelGGL((mdct_backward_kernel<3, 1>), dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    if (shift == 0) hipLaunchKernelGGL(mdct_backward_kernel<0>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
+    else            hipLaunchKernelGGL(mdct_backward_kernel<3>, dim3(grid), dim3(64), 0, s, d_freq, d_sig, nt);
     return opusgpu_check_launch();
 }
 
