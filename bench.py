@@ -1375,6 +1375,12 @@ def main(argv=None):
             scale = (extra.get("frames_per_launch") or pm.get("units_per_launch") or 1) / float(pm.get("units_per_launch") or 1)
             roof["valu_issue_frac"] = round(pm["SQ_INSTS_VALU"] * scale * 4.0 / (SIMDS * CLOCK_HZ * kms * 1e-3), 4)
             roof["valu_wave_insts_per_launch"] = int(pm["SQ_INSTS_VALU"] * scale)
+            if pm.get("SQ_THREAD_CYCLES_VALU") and pm.get("SQ_ACTIVE_INST_VALU"):
+                # lanes doing work per issued vector instruction / 64: thread-cycles over instruction-cycles of the same
+                # PMC pass (tools/prof_celt.sh pmc3), both in quad-cycles. valu_issue_frac counts a wave-instruction as issued whatever
+                # its EXEC mask holds; the product of the two is the share of the machine's vector lane-slots doing useful work.
+                roof["valu_lane_util"] = round(pm["SQ_THREAD_CYCLES_VALU"] / (64.0 * pm["SQ_ACTIVE_INST_VALU"]), 4)
+                roof["valu_useful_lane_frac"] = round(roof["valu_issue_frac"] * roof["valu_lane_util"], 4)
         out_line = {
             "metric": metric,
             "value": round(value, 1),

@@ -23,11 +23,13 @@ def cp(a, b):
 
 cp(os.path.join(src, "pytest_gpu.log"), "pytest_gpu.log")
 cp(os.path.join(src, "bench.json"), "bench.json")
+cp(os.path.join(src, "bench_mdct_4096.json"), "bench_mdct_4096.json")
+cp(os.path.join(src, "bench_mdct_65536.json"), "bench_mdct_65536.json")
 cp(os.path.join(src, "celt", "summary.txt"), "summary.txt")
 cp(os.path.join(src, "celt", "bench_prof.json"), "bench_under_rocprof.json")
 for f in glob.glob(os.path.join(src, "celt", "stats", "**", "*_kernel_stats.csv"), recursive=True):
     cp(f, "kernel_stats.csv")
-for w in ("mdct", "decode", "silk", "silk_deldec", "silk_lpc", "mixed", "celt_streams", "silk_frames", "silk_frames_cbr", "silk_analysis", "silk_pred", "silk_nlsf"):
+for w in ("mdct", "decode", "silk", "silk_deldec", "silk_lpc", "mixed", "celt_streams", "silk_frames", "silk_frames_cbr", "silk_streams", "silk_analysis", "silk_pred", "silk_nlsf"):
     cp(os.path.join(src, "bench_prof_%s.json" % w), "bench_under_rocprof_%s.json" % w)
     for f in glob.glob(os.path.join(src, "stats_%s" % w, "**", "*_kernel_stats.csv"), recursive=True):
         cp(f, "kernel_stats_%s.csv" % w)

@@ -21,7 +21,7 @@ def short(name):
 
 def main(d, units, out=None):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for sub in ("pmc1", "pmc2"):
+    for sub in ("pmc1", "pmc2", "pmc3"):
         for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])

@@ -24,7 +24,7 @@ def main(d):
                 print("%-28s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
                     k, r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]))
     print("# PMC, average per launch")
-    for sub in ("pmc1", "pmc2", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc1", "pmc2", "pmc3", "pmc_fetch", "pmc_write"):
         agg = collections.defaultdict(list)
         for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity "$@" > $O/bench_prof.json 2> $O/prof.err &&
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --output-format csv -d $O/pmc1 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity "$@" > /dev/null 2>> $O/prof.err &&
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $O/pmc2 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity "$@" > /dev/null 2>> $O/prof.err &&
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES --output-format csv -d $O/pmc3 -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity "$@" > /dev/null 2>> $O/prof.err &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity "$@" > /dev/null 2>> $O/prof.err &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-parity "$@" > /dev/null 2>> $O/prof.err &&
 python3 $R/tools/pmc_summary.py $O > $O/summary.txt && cat $O/summary.txt

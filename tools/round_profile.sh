@@ -9,6 +9,9 @@ mkdir -p $O
 cd $R
 timeout -k 10 900 python3 -m pytest tests -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 timeout -k 10 300 python3 bench.py > $O/bench.json 2> $O/bench.err && cut -c1-160 $O/bench.json
+# config #2 at its own size and at 65 536 frames (one round vs steady state: DESIGN section 4), CPU baseline included
+timeout -k 10 200 python3 bench.py --workload mdct > $O/bench_mdct_4096.json 2>> $O/bench.err && cut -c1-160 $O/bench_mdct_4096.json
+timeout -k 10 200 python3 bench.py --workload mdct --frames 65536 --no-cpu-baseline > $O/bench_mdct_65536.json 2>> $O/bench.err && cut -c1-160 $O/bench_mdct_65536.json
 bash tools/prof_celt.sh $TAG/celt > $O/celt_summary_stdout.txt 2>&1; tail -3 $O/celt_summary_stdout.txt
 python3 tools/pmc_traffic.py $O/celt/pmc_fetch $O/celt/pmc_write $O/traffic_celt.json > /dev/null
 python3 tools/pmc_db.py $O/celt 65536 $O/pmc_celt.json

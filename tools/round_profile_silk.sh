@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for w in silk_frames silk_frames_cbr silk_analysis silk_pred silk_nlsf; do
+for w in silk_frames silk_frames_cbr silk_streams silk_analysis silk_pred silk_nlsf; do
   # corpus capture (worker interpreters) and any stale checker library are built by a PLAIN python3 run first: nothing
   # under the profiler may start child processes (bench.py refuses to, tests/silk_corpus.py under_profiler)
   python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_prepare_$w.json 2> $O/prepare_$w.err || { echo "$w prepare failed"; continue; }
