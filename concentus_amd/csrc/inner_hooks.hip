@@ -301,12 +301,14 @@ static void nsq_hook(int del_dec, const void *psEncC, void *NSQ, void *psIndices
     DevBuf din(in_bytes), dst(sizeof(opusgpu_nsq_state)), dout(out_bytes), dws(ws_bytes);
     if (!din.p || !dst.p || !dout.p || !dws.p) { fail(OPUSGPU_ALLOC_FAIL); return; }
     if (!h2d(din.p, &rec, in_bytes) || !h2d(dst.p, NSQ, sizeof(opusgpu_nsq_state))) { fail(OPUSGPU_INTERNAL_ERROR); return; }
-    (void)opusgpu_silk_bad_records(nullptr);
+    OpusgpuHookBadScope bad;                 // the out records carry no status word: count rejections privately to this thread
+    if (bad.rc != OPUSGPU_OK) { fail(bad.rc); return; }
     rc = del_dec ? opusgpu_silk_nsq_del_dec_batch((const opusgpu_nsq_dd_in *)din.p, (opusgpu_nsq_state *)dst.p, (opusgpu_nsq_dd_out *)dout.p,
                                                   1, dws.p, ws_bytes, nullptr)
                  : opusgpu_silk_nsq_batch((const opusgpu_nsq_in *)din.p, (opusgpu_nsq_state *)dst.p, (opusgpu_nsq_out *)dout.p, 1, dws.p,
                                           ws_bytes, nullptr);
-    if (rc == OPUSGPU_OK && opusgpu_silk_bad_records(nullptr) != 0) rc = OPUSGPU_BAD_ARG;      // header outside the kernels' bounds
+    const int n_bad = bad.take();
+    if (rc == OPUSGPU_OK && n_bad != 0) rc = n_bad < 0 ? n_bad : OPUSGPU_BAD_ARG;      // header outside the kernels' bounds
     opusgpu_nsq_dd_out h_out;
     if (rc == OPUSGPU_OK && (!d2h(&h_out, dout.p, out_bytes) || !d2h(NSQ, dst.p, sizeof(opusgpu_nsq_state)))) rc = OPUSGPU_INTERNAL_ERROR;
     fail(rc);

@@ -13,6 +13,17 @@ extern "C" void opusgpu_timing_end(int slot, hipStream_t s);
 extern "C" int opusgpu_lane_frames(void);
 // device counter of SILK records whose header failed the bounds checks (silk_validate.h); nullptr = allocation failed
 extern "C" int *opusgpu_bad_record_counter(void);
+extern "C" int opusgpu_private_bad_counter_begin(void);
+extern "C" int opusgpu_private_bad_counter_end(void);
+// Scope of a one-record hook: the record kernels it launches count rejected records into a counter of the calling thread
+// (runtime.hip), never into the device's shared one that concurrent batch callers read through opusgpu_silk_bad_records().
+struct OpusgpuHookBadScope {
+    int rc;
+    bool open;
+    OpusgpuHookBadScope() : rc(opusgpu_private_bad_counter_begin()), open(true) {}
+    int take() { open = false; return opusgpu_private_bad_counter_end(); }
+    ~OpusgpuHookBadScope() { if (open) (void)opusgpu_private_bad_counter_end(); }
+};
 // records per wavefront of the lane-per-record SILK analysis kernels that keep no per-lane LDS: 64, 32, 16 or 8 (OPUSGPU_SILK_LANES)
 extern "C" int opusgpu_silk_lanes_per_block(void);
 // hipMemcpy of a per-call hook with its status mapped: OPUSGPU_OK or OPUSGPU_INTERNAL_ERROR

@@ -95,13 +95,18 @@ extern "C" int opusgpu_kernel_timing_read(double *ms_sum, int *launches, int n_k
 
 // ---- bad-record counter of the SILK record kernels (silk_validate.h) ----
 // One counter per device, allocated on first use and never freed (4 bytes for the life of the process).
+// The one-record hooks count into a counter of their own thread instead (opusgpu_private_bad_counter_begin/_end below),
+// so a hook call never reads or clears what a batch running on another thread has counted.
 namespace {
 std::mutex g_bad_m;
 int *g_bad[64] = {};
+thread_local int *t_bad_private[64] = {};
+thread_local int *t_bad_active = nullptr;
 }
 
 extern "C" int *opusgpu_bad_record_counter(void)
 {
+    if (t_bad_active) return t_bad_active;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lk(g_bad_m);
@@ -112,6 +117,29 @@ extern "C" int *opusgpu_bad_record_counter(void)
         g_bad[dev] = p;
     }
     return g_bad[dev];
+}
+
+// From here to opusgpu_private_bad_counter_end() the record kernels launched by THIS thread count into a counter only this
+// thread reads (4 bytes per thread and device, allocated on first use, never freed). Returns OPUSGPU_OK or an error code.
+extern "C" int opusgpu_private_bad_counter_begin(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return OPUSGPU_INTERNAL_ERROR;
+    if (!t_bad_private[dev] && hipMalloc((void **)&t_bad_private[dev], sizeof(int)) != hipSuccess) { t_bad_private[dev] = nullptr; return OPUSGPU_ALLOC_FAIL; }
+    if (hipMemset(t_bad_private[dev], 0, sizeof(int)) != hipSuccess) return OPUSGPU_INTERNAL_ERROR;
+    t_bad_active = t_bad_private[dev];
+    return OPUSGPU_OK;
+}
+
+// Ends the scope; returns the records rejected inside it (after the null stream has drained), or a negative error code.
+extern "C" int opusgpu_private_bad_counter_end(void)
+{
+    int *p = t_bad_active;
+    t_bad_active = nullptr;
+    if (!p) return 0;
+    int n = 0;
+    if (hipMemcpy(&n, p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return OPUSGPU_INTERNAL_ERROR;
+    return n;
 }
 
 // Records rejected by the SILK batch kernels of the current device since the last call (waits for `stream`).

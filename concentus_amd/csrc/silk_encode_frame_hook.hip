@@ -61,7 +61,8 @@ int run_bits(const opusgpu_silk_bits_in &in, ref_ec_ctx *e, opusgpu_silk_bits_ou
 {
     opusgpu_ec_state *h_ec = (opusgpu_ec_state *)malloc(sizeof(*h_ec));
     if (!h_ec) return OPUSGPU_ALLOC_FAIL;
-    int rc = ec_to_record(h_ec, e) ? OPUSGPU_OK : OPUSGPU_BAD_ARG;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    int rc = ec_to_record(h_ec, e) ? bad.rc : OPUSGPU_BAD_ARG;
     DevMem din(sizeof(in)), dec(sizeof(*h_ec)), dout(sizeof(*out));
     if (rc == OPUSGPU_OK && (!din.p || !dec.p || !dout.p)) rc = OPUSGPU_ALLOC_FAIL;
     if (rc == OPUSGPU_OK && (hipMemcpy(din.p, &in, sizeof(in), hipMemcpyHostToDevice) != hipSuccess ||
@@ -72,7 +73,7 @@ int run_bits(const opusgpu_silk_bits_in &in, ref_ec_ctx *e, opusgpu_silk_bits_ou
     if (rc == OPUSGPU_OK && (hipMemcpy(out, dout.p, sizeof(*out), hipMemcpyDeviceToHost) != hipSuccess ||
                              hipMemcpy(h_ec, dec.p, sizeof(*h_ec), hipMemcpyDeviceToHost) != hipSuccess))
         rc = OPUSGPU_INTERNAL_ERROR;
-    if (rc == OPUSGPU_OK && out->status != OPUSGPU_OK) { rc = out->status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && out->status != OPUSGPU_OK) rc = out->status;
     if (rc == OPUSGPU_OK) ec_from_record(e, h_ec);
     free(h_ec);
     return rc;
@@ -85,13 +86,14 @@ int run_rate_step(opusgpu_silk_rate_ctl *ctl, const ref_ec_ctx *e)
     if (!h_ec) return OPUSGPU_ALLOC_FAIL;
     h_ec->storage = e->storage; h_ec->nbits_total = e->nbits_total; h_ec->rng = e->rng; h_ec->offs = e->offs;
     DevMem dctl(sizeof(*ctl)), dec(sizeof(*h_ec));
-    int rc = (dctl.p && dec.p) ? OPUSGPU_OK : OPUSGPU_ALLOC_FAIL;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    int rc = (dctl.p && dec.p) ? bad.rc : OPUSGPU_ALLOC_FAIL;
     if (rc == OPUSGPU_OK && (hipMemcpy(dctl.p, ctl, sizeof(*ctl), hipMemcpyHostToDevice) != hipSuccess ||
                              hipMemcpy(dec.p, h_ec, sizeof(*h_ec), hipMemcpyHostToDevice) != hipSuccess))
         rc = OPUSGPU_INTERNAL_ERROR;
     if (rc == OPUSGPU_OK) rc = opusgpu_silk_rate_control_batch((opusgpu_silk_rate_ctl *)dctl.p, (const opusgpu_ec_state *)dec.p, 1, nullptr);
     if (rc == OPUSGPU_OK && hipMemcpy(ctl, dctl.p, sizeof(*ctl), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
-    if (rc == OPUSGPU_OK && ctl->status != OPUSGPU_OK) { rc = ctl->status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && ctl->status != OPUSGPU_OK) rc = ctl->status;
     free(h_ec);
     return rc;
 }

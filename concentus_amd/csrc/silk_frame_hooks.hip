@@ -20,7 +20,9 @@ static int run_record(const In *h_in, Out *h_out, State *h_state, Launch launch)
     In *d_in = nullptr;
     Out *d_out = nullptr;
     State *d_state = nullptr;
-    int rc = OPUSGPU_OK;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    int rc = bad.rc;
+    if (rc != OPUSGPU_OK) return rc;
     if (hipMalloc(&d_in, sizeof(In)) != hipSuccess || hipMalloc(&d_out, sizeof(Out)) != hipSuccess ||
         (h_state && hipMalloc(&d_state, sizeof(State)) != hipSuccess))
         rc = OPUSGPU_ALLOC_FAIL;
@@ -28,7 +30,7 @@ static int run_record(const In *h_in, Out *h_out, State *h_state, Launch launch)
     if (rc == OPUSGPU_OK && h_state && hipMemcpy(d_state, h_state, sizeof(State), hipMemcpyHostToDevice) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     if (rc == OPUSGPU_OK) rc = launch(d_in, d_state, d_out);
     if (rc == OPUSGPU_OK && hipMemcpy(h_out, d_out, sizeof(Out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
-    if (rc == OPUSGPU_OK && h_out->status != OPUSGPU_OK) { rc = h_out->status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && h_out->status != OPUSGPU_OK) rc = h_out->status;
     if (rc == OPUSGPU_OK && h_state && hipMemcpy(h_state, d_state, sizeof(State), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);

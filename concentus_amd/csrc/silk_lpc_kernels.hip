@@ -104,11 +104,13 @@ extern "C" void opusgpu_silk_find_LPC_FIX(void *psEncC, int16_t NLSF_Q15[], cons
         return;
     }
     int rc = hipMemcpy(d_in, &h_in, sizeof(h_in), hipMemcpyHostToDevice) == hipSuccess ? OPUSGPU_OK : OPUSGPU_INTERNAL_ERROR;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    if (rc == OPUSGPU_OK) rc = bad.rc;
     if (rc == OPUSGPU_OK) rc = opusgpu_silk_find_lpc_batch(d_in, d_out, 1, nullptr);
     if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     (void)hipFree(d_in);
     (void)hipFree(d_out);
-    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) { rc = h_out.status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) rc = h_out.status;
     opusgpu_set_last_error(rc);
     if (rc != OPUSGPU_OK) return;
     memcpy(NLSF_Q15, h_out.NLSF_Q15, sizeof(int16_t) * (size_t)h_in.predictLPCOrder);

@@ -21,6 +21,21 @@ CA_DEV i32 s_lshift_sat32(i32 a, int s) { return shl32(s_limit(a, (i32)0x8000000
 CA_DEV i32 s_addw(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 CA_DEV i32 s_subw(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 
+// a / b for 0 <= a < 2^22, 0 < b < 2^22, exact: the quotient estimated through a single-precision reciprocal is at most one
+// off, one comparison of the remainder settles it (a generic 32-bit signed division is ~40 instructions on the device)
+CA_DEV i32 s_div_small(i32 a, i32 b)
+{
+#if defined(CA_HOST_EMU)
+    const float rb = 1.0f / (float)b;
+#else
+    const float rb = __builtin_amdgcn_rcpf((float)b);
+#endif
+    i32 q = (i32)((float)a * rb);
+    const i32 r = a - __mul24(q, b);
+    q += r < 0 ? -1 : r >= b ? 1 : 0;
+    return q;
+}
+
 CA_DEV i32 s_div32_varq(i32 a32, i32 b32, int Qres)                 // Inlines.h:96-139
 {
     int a_headrm = s_clz32(s_abs(a32)) - 1;

@@ -139,17 +139,17 @@ CA_DEV void silk_NLSF_stabilize_dev(i16 *NLSF_Q15, const i16 *NDeltaMin_Q15, int
 CA_DEV void silk_NLSF_VQ_weights_laroia_dev(i16 *W, const i16 *NLSF_Q15, int D)             // NLSF_VQ_weights_laroia.c:41-80
 {
     const i32 one = (i32)1 << (15 + NLSF_W_Q);
-    i32 tmp1 = one / imax(NLSF_Q15[0], 1);
-    i32 tmp2 = one / imax(NLSF_Q15[1] - NLSF_Q15[0], 1);
+    i32 tmp1 = s_div_small(one, imax(NLSF_Q15[0], 1));
+    i32 tmp2 = s_div_small(one, imax(NLSF_Q15[1] - NLSF_Q15[0], 1));
     W[0] = (i16)imin(tmp1 + tmp2, 32767);
 #pragma unroll
     for (int k = 1; k < D - 1; k += 2) {
-        tmp1 = one / imax(NLSF_Q15[k + 1] - NLSF_Q15[k], 1);
+        tmp1 = s_div_small(one, imax(NLSF_Q15[k + 1] - NLSF_Q15[k], 1));
         W[k] = (i16)imin(tmp1 + tmp2, 32767);
-        tmp2 = one / imax(NLSF_Q15[k + 2] - NLSF_Q15[k + 1], 1);
+        tmp2 = s_div_small(one, imax(NLSF_Q15[k + 2] - NLSF_Q15[k + 1], 1));
         W[k + 1] = (i16)imin(tmp1 + tmp2, 32767);
     }
-    tmp1 = one / imax((1 << 15) - NLSF_Q15[D - 1], 1);
+    tmp1 = s_div_small(one, imax((1 << 15) - NLSF_Q15[D - 1], 1));
     W[D - 1] = (i16)imin(tmp1 + tmp2, 32767);
 }
 
@@ -193,97 +193,102 @@ CA_DEV void silk_NLSF_unpack_dev(i16 *ec_ix, u8 *pred_Q8, const NlsfCB &cb, int 
     }
 }
 
-// NLSF_del_dec_quant.c:35-217. ind[][] rows are written for every coefficient the moment it is visited, so the
-// whole-row copy of the reference (:183, which also moves not-yet-written bytes) moves the same live bytes as the
-// copy of the visited suffix done here.
-#if defined(CA_HOST_EMU)
-#define CA_NLSF_MEMBER inline
-#else
-#define CA_NLSF_MEMBER __device__ __forceinline__
-#endif
-// The trellis' survivor state: index paths, previous outputs, rate-distortion values. Every access is a dependent step of the search
-// (indexed by state and coefficient at run time), so where it lives sets the pace: local arrays (private memory on the device) by
-// default, a lane's column of an LDS block [slot][64 lanes] in the kernels (NlsfTrellisCol).
-struct NlsfTrellisLocal {
-    i32 v[28];
-    i16 path[NLSF_DD_STATES * SILK_MAX_LPC];
-    CA_NLSF_MEMBER i16 &ind(int j, int i) { return path[j * SILK_MAX_LPC + i]; }
-    CA_NLSF_MEMBER i32 &prev_out(int j) { return v[j]; }
-    CA_NLSF_MEMBER i32 &RD(int j) { return v[8 + j]; }
-    CA_NLSF_MEMBER i32 &RD_min(int j) { return v[16 + j]; }
-    CA_NLSF_MEMBER i32 &RD_max(int j) { return v[20 + j]; }
-    CA_NLSF_MEMBER i32 &sort(int j) { return v[24 + j]; }
+// ---- the delayed-decision trellis (NLSF_del_dec_quant.c:35-217) --------------------------------------------------------------
+// R(v): what coding the index v costs with one entropy table, in Q5 bits -- the table's entry inside +-3, 280 at +-4, 43 more per
+// step beyond. The reference's four-way branch (:100-128) evaluates exactly R(ind) and R(ind + 1); tabulated here for v = -10 .. 10
+// per table, the trellis reads two entries and branches on nothing.
+enum { NLSF_RATE_EXT = 2 * NLSF_MAX_AMP_EXT + 1, NLSF_EC_TABLES = 8 };
+CA_DEV int nlsf_rate_ext(const u8 *rates_Q5 /* the nine entries of one table */, int v)
+{
+    const int a = v < 0 ? -v : v;
+    return a < NLSF_MAX_AMP ? (int)rates_Q5[v + NLSF_MAX_AMP] : (280 - 43 * NLSF_MAX_AMP) + 43 * a;
+}
+
+// What silk_NLSF_encode recomputes for every survivor although it depends on the survivor's first-stage vector alone
+// (NLSF_encode.c:93-103: the Laroia weights of the codebook vector and their square roots), and the extended rate tables.
+// Same functions, evaluated once per workgroup (device: LDS) or once per process (host build).
+struct NlsfEncTables {
+    i16 wb_W_QW[32 * 16], nb_W_QW[32 * 10];
+    u16 wb_W_Q9[32 * 16], nb_W_Q9[32 * 10];
+    u16 wb_rate[NLSF_EC_TABLES * NLSF_RATE_EXT], nb_rate[NLSF_EC_TABLES * NLSF_RATE_EXT];
 };
-enum { NLSF_TRELLIS_SLOTS16 = NLSF_DD_STATES * SILK_MAX_LPC + 2 * 28 };     // 64 16-bit slots + 28 32-bit slots per lane
-struct NlsfTrellisCol {
-    i16 *p16;                                            // -> this lane's 16-bit column (slot stride 64)
-    i32 *p32;                                            // -> this lane's 32-bit column behind it
-    CA_NLSF_MEMBER i16 &ind(int j, int i) { return p16[(j * SILK_MAX_LPC + i) * 64]; }
-    CA_NLSF_MEMBER i32 &prev_out(int j) { return p32[j * 64]; }
-    CA_NLSF_MEMBER i32 &RD(int j) { return p32[(8 + j) * 64]; }
-    CA_NLSF_MEMBER i32 &RD_min(int j) { return p32[(16 + j) * 64]; }
-    CA_NLSF_MEMBER i32 &RD_max(int j) { return p32[(20 + j) * 64]; }
-    CA_NLSF_MEMBER i32 &sort(int j) { return p32[(24 + j) * 64]; }
-    // block: NLSF_TRELLIS_SLOTS16 * 64 16-bit words of LDS, 4-byte aligned; lane: 0 .. 63
-    static CA_NLSF_MEMBER NlsfTrellisCol at(i16 *block, int lane)
-    {
-        NlsfTrellisCol t;
-        t.p16 = block + lane;
-        t.p32 = reinterpret_cast<i32 *>(block + NLSF_DD_STATES * SILK_MAX_LPC * 64) + lane;
-        return t;
+
+CA_DEV void nlsf_stage_enc_tables(NlsfEncTables &E, int tid, int nthreads)      // reads the constant tables: no ordering against nlsf_stage_tables
+{
+    for (int v = tid; v < 64; v += nthreads) {                                  // first-stage vectors: 0 .. 31 WB, 32 .. 63 NB / MB
+        const bool wb = v < 32;
+        const int vec = v & 31, order = wb ? 16 : 10;
+        const u8 *cbv = wb ? &SILK_NLSF_WB_CB1_Q8[vec * 16] : &SILK_NLSF_NB_MB_CB1_Q8[vec * 10];
+        i16 nlsf[SILK_MAX_LPC], W[SILK_MAX_LPC];
+        for (int i = 0; i < order; i++) nlsf[i] = (i16)((i32)cbv[i] << 7);
+        silk_NLSF_VQ_weights_laroia_dev(W, nlsf, order);
+        for (int i = 0; i < order; i++) {
+            (wb ? E.wb_W_QW : E.nb_W_QW)[vec * order + i] = W[i];
+            (wb ? E.wb_W_Q9 : E.nb_W_Q9)[vec * order + i] = (u16)s_sqrt_approx((i32)W[i] << (18 - NLSF_W_Q));
+        }
     }
-};
+    for (int e = tid; e < 2 * NLSF_EC_TABLES * NLSF_RATE_EXT; e += nthreads) {
+        const bool wb = e < NLSF_EC_TABLES * NLSF_RATE_EXT;
+        const int k = wb ? e : e - NLSF_EC_TABLES * NLSF_RATE_EXT, t = k / NLSF_RATE_EXT, v = k % NLSF_RATE_EXT - NLSF_MAX_AMP_EXT;
+        (wb ? E.wb_rate : E.nb_rate)[k] = (u16)nlsf_rate_ext((wb ? SILK_NLSF_WB_ec_Rates_Q5 : SILK_NLSF_NB_MB_ec_Rates_Q5) + t * (2 * NLSF_MAX_AMP + 1), v);
+    }
+}
+#if defined(CA_HOST_EMU)
+inline const NlsfEncTables *nlsf_enc_tables_host()
+{
+    static const NlsfEncTables E = [] { NlsfEncTables e; nlsf_stage_enc_tables(e, 0, 1); return e; }();
+    return &E;
+}
+#endif
+
+// silk_NLSF_unpack for the trellis: the predictor taps and, instead of ec_ix (table * 9), the offset of the coefficient's
+// extended rate table (table * 21)
+template <int ORDER>
+CA_DEV void nlsf_unpack_rates(i16 *rate_ix, u8 *pred_Q8, const NlsfCB &cb, int CB1_index)
+{
+    const u8 *ec_sel_ptr = &cb.ec_sel[CB1_index * ORDER / 2];
+#pragma unroll
+    for (int i = 0; i < ORDER; i += 2) {
+        const int entry = *ec_sel_ptr++;
+        rate_ix[i] = (i16)(((entry >> 1) & 7) * NLSF_RATE_EXT);
+        pred_Q8[i] = cb.pred_Q8[i + (entry & 1) * (ORDER - 1)];
+        rate_ix[i + 1] = (i16)(((entry >> 5) & 7) * NLSF_RATE_EXT);
+        pred_Q8[i + 1] = cb.pred_Q8[i + ((entry >> 4) & 1) * (ORDER - 1) + 1];
+    }
+}
 
 // element idx (run-time, 0 .. 3) of a four-entry register array: compare chains instead of memory
 CA_DEV i32 nlsf_get4(const i32 *a, int idx) { return idx == 0 ? a[0] : idx == 1 ? a[1] : idx == 2 ? a[2] : a[3]; }
 CA_DEV void nlsf_set4(i32 *a, int idx, i32 v) { a[0] = idx == 0 ? v : a[0]; a[1] = idx == 1 ? v : a[1]; a[2] = idx == 2 ? v : a[2]; a[3] = idx == 3 ? v : a[3]; }
 
-// One coefficient of the trellis with NS (1, 2 or 4: a compile-time constant) live states: every index into the rate-distortion
-// values / previous outputs is then a constant and the two arrays are registers; only the index paths (T.ind: addressed by
-// coefficient and, in the survivor exchange, by run-time state) stay in the trellis memory.
-template <int NS, class TM>
-CA_DEV void nlsf_trellis_step(TM &T, i32 *RD /*[8]*/, i32 *po /*[8]*/, const int i, const int order, const bool last, const int in_Q10, const i32 w_Q5i,
-                              const i32 pred_coef_Q16, const u8 *rates_Q5, const int quant_step_size_Q16, const i32 inv_quant_step_size_Q6,
-                              const i32 mu_Q20)
+// One coefficient of the trellis with NS (1, 2 or 4: a compile-time constant) live states. The reference keeps a row of indices
+// per state and copies whole rows when a state is replaced (:183); here a state is, per coefficient, its index value and the
+// state of the previous coefficient it continues (a trace-back pointer) -- a row copy moves exactly that pair --, four pairs
+// packed into one word per coefficient (value + 16 in bits 0-4, pointer in bits 5-6 of each byte), the words in registers. The
+// winner's row is read back through the pointers once the search is over (nlsf_traceback).
+template <int NS>
+CA_DEV u32 nlsf_trellis_step(i32 *RD /*[8]*/, i32 *po /*[8]*/, const bool last, const int in_Q10, const i32 w_Q5i, const i32 pred_coef_Q16,
+                             const u16 *rext /* -> R(0) of the coefficient's table */, const int quant_step_size_Q16,
+                             const i32 inv_quant_step_size_Q6, const i32 mu_Q20)
 {
+    i32 val[NLSF_DD_STATES], ptr[NLSF_DD_STATES];
 #pragma unroll
     for (int j = 0; j < NS; j++) {
         const int pred_Q10 = s_smulwb(pred_coef_Q16, po[j]);
         const int res_Q10 = in_Q10 - pred_Q10;
         int ind_tmp = s_smulwb(inv_quant_step_size_Q6, res_Q10);
         ind_tmp = s_limit(ind_tmp, -NLSF_MAX_AMP_EXT, NLSF_MAX_AMP_EXT - 1);
-        T.ind(j, i) = (i8)ind_tmp;
+        val[j] = ind_tmp;
+        ptr[j] = j;
         // out0 / out1: the two reconstruction levels around the residual (the reference tabulates them per call, :61-79)
         int out0_Q10 = shl32(ind_tmp, 10), out1_Q10 = out0_Q10 + 1024;
-        if (ind_tmp > 0) { out0_Q10 -= NLSF_LEVEL_ADJ_Q10; out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
-        else if (ind_tmp == 0) { out1_Q10 -= NLSF_LEVEL_ADJ_Q10; }
-        else if (ind_tmp == -1) { out0_Q10 += NLSF_LEVEL_ADJ_Q10; }
-        else { out0_Q10 += NLSF_LEVEL_ADJ_Q10; out1_Q10 += NLSF_LEVEL_ADJ_Q10; }
+        out0_Q10 += ind_tmp > 0 ? -NLSF_LEVEL_ADJ_Q10 : ind_tmp < 0 ? NLSF_LEVEL_ADJ_Q10 : 0;
+        out1_Q10 += ind_tmp >= 0 ? -NLSF_LEVEL_ADJ_Q10 : ind_tmp < -1 ? NLSF_LEVEL_ADJ_Q10 : 0;
         out0_Q10 = s_smulwb(out0_Q10, quant_step_size_Q16) + pred_Q10;
         out1_Q10 = s_smulwb(out1_Q10, quant_step_size_Q16) + pred_Q10;
         po[j] = (i16)out0_Q10;
         po[j + NS] = (i16)out1_Q10;
-        int rate0_Q5, rate1_Q5;
-        if (ind_tmp + 1 >= NLSF_MAX_AMP) {
-            if (ind_tmp + 1 == NLSF_MAX_AMP) {
-                rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
-                rate1_Q5 = 280;
-            } else {
-                rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(43, ind_tmp);
-                rate1_Q5 = rate0_Q5 + 43;
-            }
-        } else if (ind_tmp <= -NLSF_MAX_AMP) {
-            if (ind_tmp == -NLSF_MAX_AMP) {
-                rate0_Q5 = 280;
-                rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
-            } else {
-                rate0_Q5 = (280 - 43 * NLSF_MAX_AMP) + s_smulbb(-43, ind_tmp);
-                rate1_Q5 = rate0_Q5 - 43;
-            }
-        } else {
-            rate0_Q5 = rates_Q5[ind_tmp + NLSF_MAX_AMP];
-            rate1_Q5 = rates_Q5[ind_tmp + 1 + NLSF_MAX_AMP];
-        }
+        const int rate0_Q5 = rext[ind_tmp], rate1_Q5 = rext[ind_tmp + 1];
         const i32 RD_tmp = RD[j];
         int diff_Q10 = in_Q10 - out0_Q10;
         RD[j] = s_addw(s_addw(RD_tmp, (i32)((u32)s_smulbb(diff_Q10, diff_Q10) * (u32)w_Q5i)), s_smulbb(mu_Q20, rate0_Q5));
@@ -292,27 +297,20 @@ CA_DEV void nlsf_trellis_step(TM &T, i32 *RD /*[8]*/, i32 *po /*[8]*/, const int
     }
     if (NS <= (NLSF_DD_STATES >> 1)) {                                                      // the states double (:136-145)
 #pragma unroll
-        for (int j = 0; j < NS; j++) T.ind(j + NS, i) = (i8)(T.ind(j, i) + 1);
+        for (int j = 0; j < NS; j++) { val[j + NS] = val[j] + 1; ptr[j + NS] = j; }
 #pragma unroll
-        for (int j = 2 * NS; j < NLSF_DD_STATES; j++) T.ind(j, i) = T.ind(j - 2 * NS, i);
+        for (int j = 2 * NS; j < NLSF_DD_STATES; j++) { val[j] = val[j - 2 * NS]; ptr[j] = ptr[j - 2 * NS]; }
     } else if (!last) {                                                                     // keep the best four of the eight (:146-199)
         i32 RD_min[NLSF_DD_STATES], RD_max[NLSF_DD_STATES], srt[NLSF_DD_STATES];
 #pragma unroll
         for (int j = 0; j < NLSF_DD_STATES; j++) {
-            if (RD[j] > RD[j + NLSF_DD_STATES]) {
-                RD_max[j] = RD[j];
-                RD_min[j] = RD[j + NLSF_DD_STATES];
-                RD[j] = RD_min[j];
-                RD[j + NLSF_DD_STATES] = RD_max[j];
-                const i32 t = po[j];
-                po[j] = po[j + NLSF_DD_STATES];
-                po[j + NLSF_DD_STATES] = t;
-                srt[j] = j + NLSF_DD_STATES;
-            } else {
-                RD_min[j] = RD[j];
-                RD_max[j] = RD[j + NLSF_DD_STATES];
-                srt[j] = j;
-            }
+            const bool up = RD[j] > RD[j + NLSF_DD_STATES];
+            const i32 lo = up ? RD[j + NLSF_DD_STATES] : RD[j], hi = up ? RD[j] : RD[j + NLSF_DD_STATES];
+            const i32 pl = up ? po[j + NLSF_DD_STATES] : po[j], ph = up ? po[j] : po[j + NLSF_DD_STATES];
+            RD_min[j] = lo; RD_max[j] = hi;
+            RD[j] = lo; RD[j + NLSF_DD_STATES] = hi;
+            po[j] = pl; po[j + NLSF_DD_STATES] = ph;
+            srt[j] = up ? j + NLSF_DD_STATES : j;
         }
         while (1) {
             i32 min_max = 0x7FFFFFFF, max_min = 0;
@@ -328,29 +326,37 @@ CA_DEV void nlsf_trellis_step(TM &T, i32 *RD /*[8]*/, i32 *po /*[8]*/, const int
             nlsf_set4(po, ind_max_min, nlsf_get4(po + NLSF_DD_STATES, ind_min_max));
             nlsf_set4(RD_min, ind_max_min, 0);
             nlsf_set4(RD_max, ind_min_max, 0x7FFFFFFF);
-            for (int k = i; k < order; k++) T.ind(ind_max_min, k) = T.ind(ind_min_max, k);
+            nlsf_set4(val, ind_max_min, nlsf_get4(val, ind_min_max));                        // the row copy (:183)
+            nlsf_set4(ptr, ind_max_min, nlsf_get4(ptr, ind_min_max));
         }
 #pragma unroll
-        for (int j = 0; j < NLSF_DD_STATES; j++) T.ind(j, i) = (i8)(T.ind(j, i) + (srt[j] >> NLSF_DD_STATES_LOG2));
+        for (int j = 0; j < NLSF_DD_STATES; j++) val[j] += srt[j] >> NLSF_DD_STATES_LOG2;
     }
+    u32 w = 0;
+#pragma unroll
+    for (int j = 0; j < NLSF_DD_STATES; j++) w |= (u32)((val[j] + 16) | (ptr[j] << 5)) << (8 * j);
+    return w;
 }
 
-template <class TM>
-CA_DEV i32 silk_NLSF_del_dec_quant_dev(TM &T, i8 *indices, const i16 *x_Q10, const i16 *w_Q5, const u8 *pred_coef_Q8, const i16 *ec_ix,
-                                       const u8 *ec_rates_Q5, int quant_step_size_Q16, i32 inv_quant_step_size_Q6, i32 mu_Q20, int order)
+// The search over one survivor's residual: returns the best rate-distortion value, the trace-back words in tb[ORDER] and the
+// winning candidate (0 .. 7: state | upper-candidate bit) in `win`.
+template <int ORDER>
+CA_DEV i32 nlsf_del_dec_quant(u32 *tb, int &win, const i16 *x_Q10, const i16 *w_Q5, const u8 *pred_coef_Q8, const i16 *rate_ix,
+                              const u16 *rates_ext, const int quant_step_size_Q16, const i32 inv_quant_step_size_Q6, const i32 mu_Q20)
 {
     i32 RD[2 * NLSF_DD_STATES], po[2 * NLSF_DD_STATES];
 #pragma unroll
     for (int j = 0; j < 2 * NLSF_DD_STATES; j++) { RD[j] = 0; po[j] = 0; }
-    for (int i = order - 1; i >= 0; i--) {
-        const u8 *rates_Q5 = &ec_rates_Q5[ec_ix[i]];
+#pragma unroll
+    for (int i = ORDER - 1; i >= 0; i--) {
+        const u16 *rext = rates_ext + rate_ix[i] + NLSF_MAX_AMP_EXT;
         const i32 pred_coef_Q16 = (i32)pred_coef_Q8[i] << 8;
         const int in_Q10 = x_Q10[i];
         const i32 w = (i32)w_Q5[i];
-        // one state at the last coefficient, two at the one before, four from there on (NLSF_DD_STATES = 4; order >= 3)
-        if (i == order - 1) nlsf_trellis_step<1>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
-        else if (i == order - 2) nlsf_trellis_step<2>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
-        else nlsf_trellis_step<4>(T, RD, po, i, order, i == 0, in_Q10, w, pred_coef_Q16, rates_Q5, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
+        // one state at the last coefficient, two at the one before, four from there on (NLSF_DD_STATES = 4; ORDER >= 3)
+        if (i == ORDER - 1) tb[i] = nlsf_trellis_step<1>(RD, po, i == 0, in_Q10, w, pred_coef_Q16, rext, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
+        else if (i == ORDER - 2) tb[i] = nlsf_trellis_step<2>(RD, po, i == 0, in_Q10, w, pred_coef_Q16, rext, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
+        else tb[i] = nlsf_trellis_step<4>(RD, po, i == 0, in_Q10, w, pred_coef_Q16, rext, quant_step_size_Q16, inv_quant_step_size_Q6, mu_Q20);
     }
     int ind_tmp = 0;
     i32 min_Q25 = 0x7FFFFFFF;
@@ -358,9 +364,21 @@ CA_DEV i32 silk_NLSF_del_dec_quant_dev(TM &T, i8 *indices, const i16 *x_Q10, con
     for (int j = 0; j < 2 * NLSF_DD_STATES; j++) {
         if (min_Q25 > RD[j]) { min_Q25 = RD[j]; ind_tmp = j; }
     }
-    for (int j = 0; j < order; j++) indices[j] = (i8)T.ind(ind_tmp & (NLSF_DD_STATES - 1), j);
-    indices[0] = (i8)(indices[0] + (ind_tmp >> NLSF_DD_STATES_LOG2));
+    win = ind_tmp;
     return min_Q25;
+}
+
+template <int ORDER>
+CA_DEV void nlsf_traceback(i8 *indices, const u32 *tb, int win)                             // :207-213
+{
+    int s = win & (NLSF_DD_STATES - 1);
+#pragma unroll
+    for (int i = 0; i < ORDER; i++) {
+        const u32 e = (tb[i] >> (8 * s)) & 0xff;
+        indices[i] = (i8)((int)(e & 31) - 16);
+        s = (int)(e >> 5);
+    }
+    indices[0] = (i8)(indices[0] + (win >> NLSF_DD_STATES_LOG2));
 }
 
 CA_DEV void silk_NLSF_decode_dev(i16 *pNLSF_Q15, const i8 *NLSFIndices, const NlsfCB &cb)    // NLSF_decode.c:63-101
@@ -390,19 +408,20 @@ CA_DEV void silk_NLSF_decode_dev(i16 *pNLSF_Q15, const i8 *NLSFIndices, const Nl
     silk_NLSF_stabilize_dev(pNLSF_Q15, cb.deltaMin_Q15, cb.order);
 }
 
-// silk_NLSF_encode (NLSF_encode.c:38-157): quantises pNLSF_Q15 in place, writes NLSFIndices[order + 1], returns the RD value
-template <class TM>
-CA_DEV i32 silk_NLSF_encode_dev(TM &T, i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &cb, const i16 *pW_QW, int NLSF_mu_Q20, int nSurvivors,
-                                int signalType)
+// silk_NLSF_encode (NLSF_encode.c:38-157): quantises pNLSF_Q15 in place, writes NLSFIndices[ORDER + 1], returns the RD value
+template <int ORDER>
+CA_DEV i32 silk_NLSF_encode_dev(i8 *NLSFIndices, i16 *pNLSF_Q15, const NlsfCB &cb, const NlsfEncTables &E, const i16 *pW_QW, int NLSF_mu_Q20,
+                                int nSurvivors, int signalType)
 {
     i32 err_Q26[NLSF_MAX_SURVIVORS];                     // nVectors <= 32
     int tempIndices1[NLSF_MAX_SURVIVORS];
-    silk_NLSF_stabilize_dev(pNLSF_Q15, cb.deltaMin_Q15, cb.order);
+    silk_NLSF_stabilize_dev(pNLSF_Q15, cb.deltaMin_Q15, ORDER);
     {                                                                                       // silk_NLSF_VQ, NLSF_VQ.c:35-68
         const u8 *p = cb.CB1_Q8;
         for (int i = 0; i < cb.nVectors; i++) {
             i32 sum_error_Q26 = 0;
-            for (int m = 0; m < cb.order; m += 2) {
+#pragma unroll
+            for (int m = 0; m < ORDER; m += 2) {
                 i32 diff_Q15 = (i32)pNLSF_Q15[m] - ((i32)*p++ << 7);
                 i32 sum_error_Q30 = s_smulbb(diff_Q15, diff_Q15);
                 diff_Q15 = (i32)pNLSF_Q15[m + 1] - ((i32)*p++ << 7);
@@ -413,99 +432,98 @@ CA_DEV i32 silk_NLSF_encode_dev(TM &T, i8 *NLSFIndices, i16 *pNLSF_Q15, const Nl
         }
     }
     silk_insertion_sort_increasing_dev(err_Q26, tempIndices1, cb.nVectors, nSurvivors);
-    // survivors one after the other; only the best one's path is kept (the reference keeps all and picks the first minimum)
+    const i16 *W_QW_tab = ORDER == 16 ? E.wb_W_QW : E.nb_W_QW;
+    const u16 *W_Q9_tab = ORDER == 16 ? E.wb_W_Q9 : E.nb_W_Q9;
+    const u16 *rates_ext = ORDER == 16 ? E.wb_rate : E.nb_rate;
+    // survivors one after the other; only the best one's trace-back is kept (the reference keeps all paths and picks the first minimum)
     i32 best_RD = 0;
-    int best_s = -1;
-    i8 best_path[SILK_MAX_LPC];
+    int best_s = -1, best_win = 0;
+    u32 best_tb[ORDER];
+#pragma unroll
+    for (int i = 0; i < ORDER; i++) best_tb[i] = 0;
     for (int s = 0; s < nSurvivors; s++) {
         const int ind1 = tempIndices1[s];
-        i16 res_Q10[SILK_MAX_LPC], NLSF_tmp_Q15[SILK_MAX_LPC], W_tmp_QW[SILK_MAX_LPC], W_adj_Q5[SILK_MAX_LPC], ec_ix[SILK_MAX_LPC];
-        u8 pred_Q8[SILK_MAX_LPC];
-        i8 path[SILK_MAX_LPC];
-        const u8 *pCB_element = &cb.CB1_Q8[ind1 * cb.order];
+        i16 res_Q10[ORDER], W_adj_Q5[ORDER], rate_ix[ORDER];
+        u8 pred_Q8[ORDER];
+        const u8 *pCB_element = &cb.CB1_Q8[ind1 * ORDER];
+        const i16 *W_tmp_QW = &W_QW_tab[ind1 * ORDER];
+        const u16 *W_tmp_Q9 = &W_Q9_tab[ind1 * ORDER];
 #pragma unroll
-        for (int i = 0; i < cb.order; i++) NLSF_tmp_Q15[i] = (i16)((i32)pCB_element[i] << 7);
-        silk_NLSF_VQ_weights_laroia_dev(W_tmp_QW, NLSF_tmp_Q15, cb.order);
-#pragma unroll
-        for (int i = 0; i < cb.order; i++) {
-            const i32 res_Q15 = (i16)(pNLSF_Q15[i] - NLSF_tmp_Q15[i]);
-            const i32 W_tmp_Q9 = s_sqrt_approx((i32)W_tmp_QW[i] << (18 - NLSF_W_Q));
-            res_Q10[i] = (i16)(s_smulbb(res_Q15, W_tmp_Q9) >> 14);
-            W_adj_Q5[i] = (i16)(((i32)pW_QW[i] << 5) / (i32)W_tmp_QW[i]);
+        for (int i = 0; i < ORDER; i++) {
+            const i32 res_Q15 = (i16)(pNLSF_Q15[i] - (i16)((i32)pCB_element[i] << 7));
+            res_Q10[i] = (i16)(s_smulbb(res_Q15, (i32)W_tmp_Q9[i]) >> 14);
+            W_adj_Q5[i] = (i16)s_div_small((i32)pW_QW[i] << 5, (i32)W_tmp_QW[i]);
         }
-        silk_NLSF_unpack_dev(ec_ix, pred_Q8, cb, ind1);
-        i32 RD = silk_NLSF_del_dec_quant_dev(T, path, res_Q10, W_adj_Q5, pred_Q8, ec_ix, cb.ec_Rates_Q5, cb.quantStepSize_Q16,
-                                             cb.invQuantStepSize_Q6, NLSF_mu_Q20, cb.order);
+        nlsf_unpack_rates<ORDER>(rate_ix, pred_Q8, cb, ind1);
+        u32 tb[ORDER];
+        int win;
+        i32 RD = nlsf_del_dec_quant<ORDER>(tb, win, res_Q10, W_adj_Q5, pred_Q8, rate_ix, rates_ext, cb.quantStepSize_Q16, cb.invQuantStepSize_Q6,
+                                           NLSF_mu_Q20);
         const u8 *iCDF_ptr = &cb.CB1_iCDF[(signalType >> 1) * cb.nVectors];
         const int prob_Q8 = ind1 == 0 ? 256 - iCDF_ptr[ind1] : iCDF_ptr[ind1 - 1] - iCDF_ptr[ind1];
         const int bits_q7 = (8 << 7) - s_lin2log(prob_Q8);
         RD = s_addw(RD, s_smulbb(bits_q7, NLSF_mu_Q20 >> 2));
-        if (best_s < 0 || RD < best_RD) {
-            best_RD = RD;
-            best_s = s;
-            for (int i = 0; i < cb.order; i++) best_path[i] = path[i];
-        }
+        const bool better = best_s < 0 || RD < best_RD;
+        best_RD = better ? RD : best_RD;
+        best_s = better ? s : best_s;
+        best_win = better ? win : best_win;
+#pragma unroll
+        for (int i = 0; i < ORDER; i++) best_tb[i] = better ? tb[i] : best_tb[i];
     }
     NLSFIndices[0] = (i8)tempIndices1[best_s];
-    for (int i = 0; i < cb.order; i++) NLSFIndices[1 + i] = best_path[i];
+    nlsf_traceback<ORDER>(NLSFIndices + 1, best_tb, best_win);
     silk_NLSF_decode_dev(pNLSF_Q15, NLSFIndices, cb);
     return best_RD;
 }
 
-// silk_process_NLSFs (process_NLSFs.c:35-106). pNLSF_Q15: in = silk_find_LPC_FIX's NLSFs, out = the quantised ones.
-// T: the trellis' survivor state (NlsfTrellisLocal / NlsfTrellisCol above).
-template <class TM>
-CA_DEV void silk_process_NLSFs_order_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
-                                         int speech_activity_Q8, int nb_subfr, const int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
-                                         int nSurvivors, int signalType, const NlsfTablesLds *tables)
+// silk_process_NLSFs (process_NLSFs.c:35-106). pNLSF_Q15: in = silk_find_LPC_FIX's NLSFs, out = the quantised ones. The two LPC
+// orders of the format (16 wideband, 10 narrow / medium band) are two instances of the body: with the order a constant the
+// per-coefficient loops unroll and the small per-survivor arrays they fill (residuals, weights, rate-table offsets, predictor
+// taps, the trace-back words) are registers instead of run-time-indexed private memory.
+template <int ORDER>
+CA_DEV void silk_process_NLSFs_order_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
+                                         int speech_activity_Q8, int nb_subfr, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
+                                         int nSurvivors, int signalType, const NlsfTablesLds *tables, const NlsfEncTables &E)
 {
-    const NlsfCB cb = nlsf_codebook(order, tables);
+    const NlsfCB cb = nlsf_codebook(ORDER, tables);
     i16 pNLSF0_temp_Q15[SILK_MAX_LPC], pNLSFW_QW[SILK_MAX_LPC], pNLSFW0_temp_QW[SILK_MAX_LPC];
     // NLSF_mu = 0.003 - 0.001 * speech_activity  (SILK_FIX_CONST(0.003, 20) = 3146, SILK_FIX_CONST(-0.001, 28) = -268434)
     i32 NLSF_mu_Q20 = s_smlawb(3146, -268434, speech_activity_Q8);
     if (nb_subfr == 2) NLSF_mu_Q20 = NLSF_mu_Q20 + (NLSF_mu_Q20 >> 1);
-    silk_NLSF_VQ_weights_laroia_dev(pNLSFW_QW, pNLSF_Q15, order);
+    silk_NLSF_VQ_weights_laroia_dev(pNLSFW_QW, pNLSF_Q15, ORDER);
     const bool doInterpolate = useInterpolatedNLSFs == 1 && NLSFInterpCoef_Q2 < 4;
     if (doInterpolate) {
-        silk_interpolate_dev(pNLSF0_temp_Q15, prev_NLSFq_Q15, pNLSF_Q15, NLSFInterpCoef_Q2, order);
-        silk_NLSF_VQ_weights_laroia_dev(pNLSFW0_temp_QW, pNLSF0_temp_Q15, order);
+        silk_interpolate_dev(pNLSF0_temp_Q15, prev_NLSFq_Q15, pNLSF_Q15, NLSFInterpCoef_Q2, ORDER);
+        silk_NLSF_VQ_weights_laroia_dev(pNLSFW0_temp_QW, pNLSF0_temp_Q15, ORDER);
         const i32 i_sqr_Q15 = s_smulbb(NLSFInterpCoef_Q2, NLSFInterpCoef_Q2) << 11;
-        for (int i = 0; i < order; i++)
+        for (int i = 0; i < ORDER; i++)
             pNLSFW_QW[i] = (i16)s_smlawb(pNLSFW_QW[i] >> 1, (i32)pNLSFW0_temp_QW[i], i_sqr_Q15);
     }
-    silk_NLSF_encode_dev(T, NLSFIndices, pNLSF_Q15, cb, pNLSFW_QW, NLSF_mu_Q20, nSurvivors, signalType);
-    silk_NLSF2A_dev(PredCoef_Q12[1], pNLSF_Q15, order);
+    silk_NLSF_encode_dev<ORDER>(NLSFIndices, pNLSF_Q15, cb, E, pNLSFW_QW, NLSF_mu_Q20, nSurvivors, signalType);
+    silk_NLSF2A_dev(PredCoef_Q12[1], pNLSF_Q15, ORDER);
     if (doInterpolate) {
-        silk_interpolate_dev(pNLSF0_temp_Q15, prev_NLSFq_Q15, pNLSF_Q15, NLSFInterpCoef_Q2, order);
-        silk_NLSF2A_dev(PredCoef_Q12[0], pNLSF0_temp_Q15, order);
+        silk_interpolate_dev(pNLSF0_temp_Q15, prev_NLSFq_Q15, pNLSF_Q15, NLSFInterpCoef_Q2, ORDER);
+        silk_NLSF2A_dev(PredCoef_Q12[0], pNLSF0_temp_Q15, ORDER);
     } else {
-        for (int i = 0; i < order; i++) PredCoef_Q12[0][i] = PredCoef_Q12[1][i];
+        for (int i = 0; i < ORDER; i++) PredCoef_Q12[0][i] = PredCoef_Q12[1][i];
     }
 }
 
-// The two LPC orders of the format (16 wideband, 10 narrow / medium band) as two instances of the inlined body: with the order a
-// constant the per-coefficient loops unroll and the small per-survivor arrays they fill (residuals, weights, entropy-table
-// offsets, predictor taps) are registers instead of run-time-indexed private memory.
-template <class TM>
-CA_DEV void silk_process_NLSFs_dev(TM &T, i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
-                                   int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
-                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
-{
-    if (order == 16)
-        silk_process_NLSFs_order_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, 16, useInterpolatedNLSFs,
-                                     NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
-    else
-        silk_process_NLSFs_order_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, 10, useInterpolatedNLSFs,
-                                     NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
-}
-
+// tables / enc: the workgroup's LDS copies in the kernels (nlsf_stage_tables, nlsf_stage_enc_tables); the host build may pass
+// neither (constant tables; the derived ones built on first use)
 CA_DEV void silk_process_NLSFs_dev(i16 PredCoef_Q12[2][SILK_MAX_LPC], i8 *NLSFIndices, i16 *pNLSF_Q15, const i16 *prev_NLSFq_Q15,
                                    int speech_activity_Q8, int nb_subfr, int order, int useInterpolatedNLSFs, int NLSFInterpCoef_Q2,
-                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr)
+                                   int nSurvivors, int signalType, const NlsfTablesLds *tables = nullptr, const NlsfEncTables *enc = nullptr)
 {
-    NlsfTrellisLocal T;
-    silk_process_NLSFs_dev(T, PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, order, useInterpolatedNLSFs,
-                           NLSFInterpCoef_Q2, nSurvivors, signalType, tables);
+#if defined(CA_HOST_EMU)
+    if (!enc) enc = nlsf_enc_tables_host();
+#endif
+    if (order == 16)
+        silk_process_NLSFs_order_dev<16>(PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, useInterpolatedNLSFs,
+                                         NLSFInterpCoef_Q2, nSurvivors, signalType, tables, *enc);
+    else
+        silk_process_NLSFs_order_dev<10>(PredCoef_Q12, NLSFIndices, pNLSF_Q15, prev_NLSFq_Q15, speech_activity_Q8, nb_subfr, useInterpolatedNLSFs,
+                                         NLSFInterpCoef_Q2, nSurvivors, signalType, tables, *enc);
 }
 
 // silk_residual_energy_FIX (residual_energy_FIX.c:37-98): x = LPC_in_pre, nb_subfr * (subfr_length + LPC_order) samples

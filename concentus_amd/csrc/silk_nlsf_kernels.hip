@@ -15,8 +15,9 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
                                                                 int *__restrict__ bad_records)
 {
     __shared__ NlsfTablesLds tables;
-    __shared__ __attribute__((aligned(16))) i16 trellis_s[NLSF_TRELLIS_SLOTS16 * 64];     // the trellis' survivor state, [slot][lane]
+    __shared__ NlsfEncTables enc;
     nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
+    nlsf_stage_enc_tables(enc, threadIdx.x, blockDim.x);
     __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
@@ -33,9 +34,8 @@ __global__ __launch_bounds__(64) void silk_process_nlsfs_kernel(const opusgpu_pr
     i8 idx[SILK_MAX_LPC + 1];
     for (int k = 0; k < SILK_MAX_LPC; k++) { nlsf[k] = in.NLSF_Q15[k]; prev[k] = in.prev_NLSFq_Q15[k]; pc[0][k] = pc[1][k] = 0; }
     for (int k = 0; k <= SILK_MAX_LPC; k++) idx[k] = 0;
-    NlsfTrellisCol T = NlsfTrellisCol::at(trellis_s, threadIdx.x);
-    silk_process_NLSFs_dev(T, pc, idx, nlsf, prev, in.speech_activity_Q8, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
-                           in.NLSFInterpCoef_Q2, in.NLSF_MSVQ_Survivors, in.signalType, &tables);
+    silk_process_NLSFs_dev(pc, idx, nlsf, prev, in.speech_activity_Q8, in.nb_subfr, in.predictLPCOrder, in.useInterpolatedNLSFs,
+                           in.NLSFInterpCoef_Q2, in.NLSF_MSVQ_Survivors, in.signalType, &tables, &enc);
     for (int k = 0; k < in.predictLPCOrder; k++) { o.PredCoef_Q12[0][k] = pc[0][k]; o.PredCoef_Q12[1][k] = pc[1][k]; o.NLSF_Q15[k] = nlsf[k]; }
     for (int k = 0; k <= in.predictLPCOrder; k++) o.NLSFIndices[k] = idx[k];
     o.status = OPUSGPU_OK;
@@ -124,11 +124,13 @@ static int run_one(const In &h_in, Out &h_out, Launch launch)
         return OPUSGPU_ALLOC_FAIL;
     }
     int rc = hipMemcpy(d_in, &h_in, sizeof(In), hipMemcpyHostToDevice) == hipSuccess ? OPUSGPU_OK : OPUSGPU_INTERNAL_ERROR;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    if (rc == OPUSGPU_OK) rc = bad.rc;
     if (rc == OPUSGPU_OK) rc = launch(d_in, d_out);
     if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(Out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     (void)hipFree(d_in);
     (void)hipFree(d_out);
-    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) { rc = h_out.status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) rc = h_out.status;
     return rc;
 }
 

@@ -30,10 +30,11 @@ struct PredCoefsCfg {                                   // the psEnc / psEncCtrl
 
 // res_pitch: index 0 = res_pitch[0]; x: index 0 = the reference's x[0] (the frame), negative indices reach into x_buf.
 // pre: storage of LPC_in_pre (nb * (subfr_length + order) samples, each read a handful of times, in order); e: the Burg recursion's
-// edge accessor over it (silk_burg_dev.h), staged here once LPC_in_pre exists; T: the NLSF trellis' survivor state (silk_nlsf_dev.h;
-// it may share its storage with e, whose contents are dead once silk_find_LPC_FIX has returned).
-template <class XG, class PRE, class XE, class TM>
-CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, XE e, TM &T, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr)
+// edge accessor over it (silk_burg_dev.h), staged here once LPC_in_pre exists; tables / enc: the workgroup's NLSF codebook copies and
+// derived tables (silk_nlsf_dev.h).
+template <class XG, class PRE, class XE>
+CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, PRE pre, XE e, PredCoefsOut &o, const NlsfTablesLds *tables = nullptr,
+                                     const NlsfEncTables *enc = nullptr)
 {
     const int order = c.predictLPCOrder, nb = c.nb_subfr, L = c.subfr_length;
     i32 invGains_Q16[4], local_gains[4], Wght_Q15[4];
@@ -84,8 +85,8 @@ CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, 
     e.stage(pre, L + order, nb);
     o.NLSFInterpCoef_Q2 = silk_find_LPC_dev(pre, e, minInvGain_Q30, L, nb, order, c.useInterpolatedNLSFs, c.first_frame_after_reset,
                                             c.prev_NLSFq_Q15, o.NLSF_Q15);
-    silk_process_NLSFs_dev(T, o.PredCoef_Q12, o.NLSFIndices, o.NLSF_Q15, c.prev_NLSFq_Q15, c.speech_activity_Q8, nb, order,
-                           c.useInterpolatedNLSFs, o.NLSFInterpCoef_Q2, c.NLSF_MSVQ_Survivors, c.signalType, tables);
+    silk_process_NLSFs_dev(o.PredCoef_Q12, o.NLSFIndices, o.NLSF_Q15, c.prev_NLSFq_Q15, c.speech_activity_Q8, nb, order,
+                           c.useInterpolatedNLSFs, o.NLSFInterpCoef_Q2, c.NLSF_MSVQ_Survivors, c.signalType, tables, enc);
     silk_residual_energy_dev(o.ResNrg, o.ResNrgQ, pre, o.PredCoef_Q12, local_gains, L, nb, order);
 }
 
@@ -94,8 +95,7 @@ CA_DEV void silk_find_pred_coefs_dev(const PredCoefsCfg &c, XG res_pitch, XG x, 
 {
     BurgEdgesOf<PRE> e;
     e.x = pre; e.L = c.subfr_length + c.predictLPCOrder;
-    NlsfTrellisLocal T;
-    silk_find_pred_coefs_dev(c, res_pitch, x, pre, e, T, o, tables);
+    silk_find_pred_coefs_dev(c, res_pitch, x, pre, e, o, tables);
 }
 
 }  // namespace ca

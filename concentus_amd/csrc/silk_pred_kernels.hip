@@ -19,7 +19,9 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
 {
     __shared__ __attribute__((aligned(16))) i16 edge_s[BURG_EDGE_SLOTS * 64];
     __shared__ NlsfTablesLds tables;
+    __shared__ NlsfEncTables enc;
     nlsf_stage_tables(tables, threadIdx.x, 64);
+    nlsf_stage_enc_tables(enc, threadIdx.x, 64);
     __syncthreads();
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
@@ -45,10 +47,7 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     i16 pre[OPUSGPU_SILK_BURG_MAX_X];
     BurgEdgesCol e;
     e.p = edge_s + threadIdx.x;
-    // the NLSF trellis takes over the edge block once the Burg analyses are done
-    static_assert(NLSF_TRELLIS_SLOTS16 <= BURG_EDGE_SLOTS, "the trellis state fits the edge block");
-    NlsfTrellisCol T = NlsfTrellisCol::at(edge_s, threadIdx.x);
-    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, T, o, &tables);
+    silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, o, &tables, &enc);
     const int order = in.predictLPCOrder, nb = in.nb_subfr;
     memset(&out, 0, sizeof(out));
     for (int k = 0; k < order; k++) { out.PredCoef_Q12[0][k] = o.PredCoef_Q12[0][k]; out.PredCoef_Q12[1][k] = o.PredCoef_Q12[1][k]; out.NLSF_Q15[k] = o.NLSF_Q15[k]; }
@@ -162,13 +161,15 @@ extern "C" void opusgpu_silk_find_pred_coefs_FIX(void *psEnc, void *psEncCtrl, c
     int rc = OPUSGPU_OK;
     if (hipMalloc(&d_in, sizeof(*h_in)) != hipSuccess || hipMalloc(&d_out, sizeof(h_out)) != hipSuccess) rc = OPUSGPU_ALLOC_FAIL;
     if (rc == OPUSGPU_OK && hipMemcpy(d_in, h_in, sizeof(*h_in), hipMemcpyHostToDevice) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
+    OpusgpuHookBadScope bad;                 // rejected records count into this thread's counter, not the device's shared one
+    if (rc == OPUSGPU_OK) rc = bad.rc;
     if (rc == OPUSGPU_OK) rc = opusgpu_silk_find_pred_coefs_batch(d_in, d_out, 1, nullptr);
     if (rc == OPUSGPU_OK && hipMemcpy(&h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost) != hipSuccess) rc = OPUSGPU_INTERNAL_ERROR;
     if (d_in) (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     const int voiced = h_in->signalType == 2;
     free(h_in);
-    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) { rc = h_out.status; (void)opusgpu_silk_bad_records(nullptr); }
+    if (rc == OPUSGPU_OK && h_out.status != OPUSGPU_OK) rc = h_out.status;
     opusgpu_set_last_error(rc);
     if (rc != OPUSGPU_OK) return;
     char *ctl = (char *)psEncCtrl;

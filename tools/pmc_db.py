@@ -4,7 +4,8 @@ averages of the instruction / cycle counters bench.py's VALU-issue roofline need
 per launch, SQ_WAVES, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_ANY, SQ_ACTIVE_INST_VALU ...) plus the batch size they were
 collected at (units_per_launch), so the count can be scaled to the batch bench.py runs.
 
-usage: pmc_db.py <prof dir> <units_per_launch> [out.json]    (merges into an existing out.json)"""
+usage: pmc_db.py <prof dir> <units_per_launch> [out.json] [prefix]   (merges into an existing out.json; the passes are read
+from <prof dir>/<prefix>pmc1 ... pmc4)"""
 import collections
 import csv
 import glob
@@ -19,10 +20,10 @@ def short(name):
     return m.group(1) if m else None
 
 
-def main(d, units, out=None):
+def main(d, units, out=None, prefix=""):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for sub in ("pmc1", "pmc2", "pmc3"):
-        for f in glob.glob(os.path.join(d, sub, "**", "*_counter_collection.csv"), recursive=True):
+    for sub in ("pmc1", "pmc2", "pmc3", "pmc4"):
+        for f in glob.glob(os.path.join(d, prefix + sub, "**", "*_counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 k = short(r["Kernel_Name"])
                 if k:
@@ -41,4 +42,4 @@ def main(d, units, out=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else None)
+    main(sys.argv[1], int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else None, sys.argv[4] if len(sys.argv) > 4 else "")
