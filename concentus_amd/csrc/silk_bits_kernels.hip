@@ -2,6 +2,7 @@
 // information and excitation of one SILK frame onto the Opus range coder, one lane per frame; the arithmetic lives in
 // silk_bits_dev.h, the coder in rangecoder.h (lane build: every lane writes its own buffer).
 #define CA_LANE_FRAME 1
+#include <stdlib.h>
 #include <string.h>
 #include "silk_bits_dev.h"
 #include "opusgpu_internal.h"
@@ -54,6 +55,15 @@ __global__ __launch_bounds__(64) void silk_encode_bits_kernel(const opusgpu_silk
 
 using namespace ca;
 
+// Records per wavefront: the coder is a chain of dependent loads (the pulses, the tables) with few instructions in between, so
+// partially filled wavefronts -- more of them per SIMD -- hide each other's latency (OPUSGPU_SILK_BITS_LANES=16/32/64).
+static int bits_lanes()
+{
+    const char *e = getenv("OPUSGPU_SILK_BITS_LANES");
+    const int v = e ? atoi(e) : 64;
+    return (v == 16 || v == 32 || v == 64) ? v : 64;
+}
+
 extern "C" int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, opusgpu_ec_state *d_ec, opusgpu_silk_bits_out *d_out, int n, void *stream)
 {
     if (n < 0) return OPUSGPU_BAD_ARG;
@@ -61,7 +71,8 @@ extern "C" int opusgpu_silk_encode_bits_batch(const opusgpu_silk_bits_in *d_in, 
     if (!d_in || !d_ec || !d_out) return OPUSGPU_BAD_ARG;
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
-    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_in, d_ec, d_out, n, bad, (const int *)nullptr);
+    const int lpb = bits_lanes();
+    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((n + lpb - 1) / lpb), dim3(lpb), 0, (hipStream_t)stream, d_in, d_ec, d_out, n, bad, (const int *)nullptr);
     return opusgpu_check_launch();
 }
 
@@ -72,6 +83,7 @@ extern "C" int opusgpu_silk_encode_bits_rows(const opusgpu_silk_bits_in *d_in, o
     if (m <= 0) return m < 0 ? OPUSGPU_BAD_ARG : OPUSGPU_OK;
     int *bad = opusgpu_bad_record_counter();
     if (!bad) return OPUSGPU_ALLOC_FAIL;
-    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((m + 63) / 64), dim3(64), 0, stream, d_in, d_ec, d_out, m, bad, d_rows);
+    const int lpb = bits_lanes();
+    hipLaunchKernelGGL(silk_encode_bits_kernel, dim3((m + lpb - 1) / lpb), dim3(lpb), 0, stream, d_in, d_ec, d_out, m, bad, d_rows);
     return opusgpu_check_launch();
 }

@@ -21,6 +21,27 @@ CA_DEV i32 s_lshift_sat32(i32 a, int s) { return shl32(s_limit(a, (i32)0x8000000
 CA_DEV i32 s_addw(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 CA_DEV i32 s_subw(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 
+// Eight consecutive 16-bit samples as ONE 16-byte access (no alignment assumed). A lane that streams through its own record
+// touches a cache line of its own per instruction, so what a signal in a record costs is the number of memory instructions, not
+// the bytes: the loops over the signals of a record (silk_pitch_dev.h, silk_pred_kernels.hip) move eight samples per instruction.
+struct Pack8 { i16 s[8]; };
+template <class P>
+CA_DEV void pe_load8(i32 *v, P p)
+{
+    Pack8 t;
+    __builtin_memcpy(&t, &p[0], sizeof(t));
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = t.s[u];
+}
+template <class P>
+CA_DEV void pe_store8(P p, const i32 *v)
+{
+    Pack8 t;
+#pragma unroll
+    for (int u = 0; u < 8; u++) t.s[u] = (i16)v[u];
+    __builtin_memcpy(&p[0], &t, sizeof(t));
+}
+
 // a / b for 0 <= a < 2^22, 0 < b < 2^22, exact: the quotient estimated through a single-precision reciprocal is at most one
 // off, one comparison of the remainder settles it (a generic 32-bit signed division is ~40 instructions on the device)
 CA_DEV i32 s_div_small(i32 a, i32 b)

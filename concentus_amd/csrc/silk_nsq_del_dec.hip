@@ -12,11 +12,14 @@
 // replacement) is a handful of quad broadcasts (DPP quad_perm), and a wavefront advances 16 records.
 //   * per path, in registers: the 16 newest sLPC_Q14 samples (a shift register), sAR2_Q14[16], LF_AR, Seed, SeedInit, RD;
 //   * per path, in LDS ([row][lane], lanes rotated per row): the five 32-deep decision rings RandState / Q / Xq /
-//     Pred / Shape (40 KB per wavefront);
+//     Pred / Shape (40 KB per wavefront), with one level of indirection: a path's entry for ring slot t lies in the column of
+//     the path that WROTE it, and every path carries a 64-bit map (2 bits per slot) saying which column that is;
 //   * per record, in HBM: the NSQ state (xq, sLTP_shp_Q14: read at the pitch lag by all four lanes, written by the
 //     winner's lane) and the re-whitening scratch sLTP / sLTP_Q15 (workspace).
-// The reference's survivor copy (memcpy of the struct tail, :583-584) becomes: registers through ds_bpermute, the 160
-// ring rows by the four lanes of the quad together (40 read+write pairs).
+// The reference's survivor copy (memcpy of the struct tail, :583-584) becomes: registers through ds_bpermute -- the map among
+// them: copying it IS the copy of the 160 ring rows (a replaced path goes on reading its new parent's history where the
+// parent wrote it; all four paths write slot t in the same step, each into its own column, so no entry is overwritten while a
+// map still points at it).
 // sLPC_Q14[0..32) of the state output is rebuilt from the winner's Xq ring: after the last subframe (length >= 32)
 // both hold the last 32 xq_Q14 values (:307).
 #include "silk_math.h"
@@ -46,6 +49,14 @@ CA_DEV void quad_fence()
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// column (0 .. 3) of ring slot t in a path's map; the map's entry for slot t set to k
+CA_DEV int mget(u32 m0, u32 m1, int t) { return (int)(((t & 16) ? m1 : m0) >> ((t & 15) << 1)) & 3; }
+CA_DEV void mset(u32 &m0, u32 &m1, int t, int k)
+{
+    const u32 sh = (u32)(t & 15) << 1, keep = ~(3u << sh), v = (u32)k << sh;
+    const u32 a = (m0 & keep) | v, b = (m1 & keep) | v;
+    if (t & 16) m1 = b; else m0 = a;
 }
 CA_DEV i16 sat16(i32 v) { return (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v)); }
 }  // namespace dd
@@ -84,6 +95,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
 #pragma unroll
     for (int j = 0; j < 16; j++) { lp[j] = NSQ.sLPC_Q14[31 - j]; ar[j] = NSQ.sAR2_Q14[j]; }
     i32 seed = (k + in.Seed) & 3, seed0 = seed, rd = 0, lf_ar = NSQ.sLF_AR_shp_Q14;
+    u32 m0 = 0x55555555u * (u32)k, m1 = m0;        // every slot of the (zeroed) rings in the path's own column
     ring[ridx(R_SHAPE + 0, ln)] = NSQ.sLTP_shp_Q14[ltp_mem - 1];
     i32 prev_gain_Q16 = NSQ.prev_gain_Q16;
     int lag = NSQ.lagPrev;
@@ -121,11 +133,12 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                     { i32 v = qb<2>(rd); if (nst > 2 && v < best) { best = v; w = 2; } }
                     { i32 v = qb<3>(rd); if (nst > 3 && v < best) { best = v; w = 3; } }
                     if (k != w) rd = s_addw(rd, 0x7FFFFFFF >> 4);
+                    const u32 wm0 = (u32)qsel((i32)m0, quad, w), wm1 = (u32)qsel((i32)m1, quad, w);
                     for (int i = k; i < delay; i += 4) {
-                        const int last = (smpl + delay - 1 - i) & MASK;
-                        pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, quad + w)], 10);
-                        pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, quad + w)], in.Gains_Q16[1]), 14));
-                        NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, quad + w)];
+                        const int last = (smpl + delay - 1 - i) & MASK, wc = quad + mget(wm0, wm1, last);
+                        pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, wc)], 10);
+                        pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, wc)], in.Gains_Q16[1]), 14));
+                        NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, wc)];
                     }
                     subfr = 0;
                     quad_fence();
@@ -330,7 +343,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 { i32 v = qb<2>(c0.rd); if (nst > 2 && v < best) { best = v; w = 2; } }
                 { i32 v = qb<3>(c0.rd); if (nst > 3 && v < best) { best = v; w = 3; } }
             }
-            const i32 my_rand = ring[ridx(R_RND + last, ln)];
+            const i32 my_rand = ring[ridx(R_RND + last, quad + mget(m0, m1, last))];
             const i32 wrand = qsel(my_rand, quad, w);
             if (my_rand != wrand) {             // paths that disagree with the winner on the sample that expires now
                 c0.rd = s_addw(c0.rd, 0x7FFFFFFF >> 4);
@@ -355,27 +368,17 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                     const i32 a = __shfl(seed, src, 64), b = __shfl(seed0, src, 64);
                     const i32 q = __shfl(c1.q, src, 64), d = __shfl(c1.rd, src, 64), x = __shfl(c1.xq, src, 64);
                     const i32 f = __shfl(c1.lf_ar, src, 64), s = __shfl(c1.shp, src, 64), e = __shfl(c1.exc, src, 64);
-                    if (me) { seed = a; seed0 = b; c0.q = q; c0.rd = d; c0.xq = x; c0.lf_ar = f; c0.shp = s; c0.exc = e; }
+                    const u32 ma = (u32)__shfl((i32)m0, src, 64), mb = (u32)__shfl((i32)m1, src, 64);     // the five rings
+                    if (me) { seed = a; seed0 = b; c0.q = q; c0.rd = d; c0.xq = x; c0.lf_ar = f; c0.shp = s; c0.exc = e; m0 = ma; m1 = mb; }
                 }
-                if (replace && worst != best2) {
-                    // 40 rows per lane, read in two batches of 20 so the LDS latency is paid twice, not forty times
-#pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        i32 t[20];
-#pragma unroll
-                        for (int u = 0; u < 20; u++) t[u] = ring[ridx(h * 80 + 4 * u + k, quad + best2)];
-#pragma unroll
-                        for (int u = 0; u < 20; u++) ring[ridx(h * 80 + 4 * u + k, quad + worst)] = t[u];
-                    }
-                }
-                quad_fence();
             }
             // the winner's lane releases the sample that is `delay` old
             if (k == w && (subfr > 0 || i >= delay)) {
-                pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, ln)], 10);
-                pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, ln)], i >= delay ? Gain_Q10 : prev_Gain_Q10), 8));
-                NSQ.sLTP_shp_Q14[shp_idx - delay] = ring[ridx(R_SHAPE + last, ln)];
-                sLTP_Q15[ltp_idx - delay] = ring[ridx(R_PRED + last, ln)];
+                const int wc = quad + mget(m0, m1, last);
+                pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, wc)], 10);
+                pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, wc)], i >= delay ? Gain_Q10 : prev_Gain_Q10), 8));
+                NSQ.sLTP_shp_Q14[shp_idx - delay] = ring[ridx(R_SHAPE + last, wc)];
+                sLTP_Q15[ltp_idx - delay] = ring[ridx(R_PRED + last, wc)];
             }
             shp_idx++;
             ltp_idx++;
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
             ring[ridx(R_SHAPE + smpl, ln)] = c0.shp;
             seed = s_addw(seed, s_rshift_round(c0.q, 10));
             ring[ridx(R_RND + smpl, ln)] = seed;
+            mset(m0, m1, smpl, k);
             rd = c0.rd;
             quad_fence();
             if (voiced && !pred_ahead) pn = pred_lag[1];
@@ -412,13 +416,17 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
         const i32 Gain_Q10 = in.Gains_Q16[nb_subfr - 1] >> 6;
         i8 *pl = pulses + nb_subfr * L;
         i16 *pxq = &NSQ.xq[ltp_mem + nb_subfr * L];
+        const u32 wm0 = (u32)qsel((i32)m0, quad, w), wm1 = (u32)qsel((i32)m1, quad, w);
         for (int i = k; i < delay; i += 4) {
-            const int last = (smpl + delay - 1 - i) & MASK;
-            pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, quad + w)], 10);
-            pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, quad + w)], Gain_Q10), 8));
-            NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, quad + w)];
+            const int last = (smpl + delay - 1 - i) & MASK, wc = quad + mget(wm0, wm1, last);
+            pl[i - delay] = (i8)s_rshift_round(ring[ridx(R_Q + last, wc)], 10);
+            pxq[i - delay] = sat16(s_rshift_round(s_smulww(ring[ridx(R_XQ + last, wc)], Gain_Q10), 8));
+            NSQ.sLTP_shp_Q14[shp_idx - delay + i] = ring[ridx(R_SHAPE + last, wc)];
         }
-        for (int m = k; m < 32; m += 4) NSQ.sLPC_Q14[31 - m] = ring[ridx(R_XQ + ((smpl + m) & MASK), quad + w)];
+        for (int m = k; m < 32; m += 4) {
+            const int slot = (smpl + m) & MASK;
+            NSQ.sLPC_Q14[31 - m] = ring[ridx(R_XQ + slot, quad + mget(wm0, wm1, slot))];
+        }
         if (k == w) {
             outs[r].Seed = seed0;
 #pragma unroll

@@ -334,7 +334,7 @@ CA_DEV int silk_pitch_analysis_core_geom_dev(XA frame, SCR scr, int *pitch_out, 
         if (shifted) {
             shift >>= 1;
             for (int i = 0; i < frame_length; i++) scr[i] = (i16)((i32)frame[i] >> shift);
-        } else {
+        } else if ((const void *)&scr[0] != (const void *)&frame[0]) {                      // (the caller may hand over the frame in `scr` itself)
             for (int i = 0; i < frame_length; i++) scr[i] = (i16)(i32)frame[i];
         }
         const int CBimax_old = CBimax;
@@ -490,6 +490,47 @@ CA_DEV void silk_LPC_analysis_filter_dev(OUT out, XA in, const i16 *B, int len, 
     for (int j = 0; j < d; j++) out[j] = 0;
 }
 
+// silk_LPC_analysis_filter_dev with eight samples per memory access and a second copy of the first len2 output samples in out2 (the
+// pitch estimator reads the whitened frame many times: from the caller's fast storage instead of from the output record)
+template <class OUT, class OUT2, class XA>
+CA_DEV void silk_LPC_analysis_filter_dup_dev(OUT out, OUT2 out2, int len2, XA in, const i16 *B, int len, int d)
+{
+    i32 nB[SILK_MAX_LPC], w[SILK_MAX_LPC];
+    for (int j = 0; j < SILK_MAX_LPC; j++) { nB[j] = j < d ? (i32)(i16)(-(i32)B[j]) : 0; w[j] = 0; }
+    int ix = 0;
+    for (; ix + 8 <= len; ix += 8) {
+        i32 xi[8], y[8];
+        pe_load8(xi, in + ix);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            i32 sum = 0;
+#pragma unroll
+            for (int m = 0; m < SILK_MAX_LPC; m++) sum = s_addw(sum, __mul24(nB[m], w[m]));
+            const i32 v = xi[u] + pshr32(sum, 12);
+            y[u] = ix + u < d ? 0 : (v > 32767 ? 32767 : (v < -32768 ? -32768 : v));        // out[0 .. d) = 0; the window fills meanwhile
+#pragma unroll
+            for (int m = SILK_MAX_LPC - 1; m > 0; m--) w[m] = w[m - 1];
+            w[0] = xi[u];
+        }
+        pe_store8(out + ix, y);
+        if (ix + 8 <= len2) pe_store8(out2 + ix, y);
+        else for (int u = 0; u < 8; u++) if (ix + u < len2) out2[ix + u] = (i16)y[u];
+    }
+    for (; ix < len; ix++) {
+        i32 sum = 0;
+#pragma unroll
+        for (int m = 0; m < SILK_MAX_LPC; m++) sum = s_addw(sum, __mul24(nB[m], w[m]));
+        const i32 xi = (i32)in[ix];
+        const i32 v = xi + pshr32(sum, 12);
+        const i16 y = (i16)(ix < d ? 0 : (v > 32767 ? 32767 : (v < -32768 ? -32768 : v)));
+        out[ix] = y;
+        if (ix < len2) out2[ix] = y;
+#pragma unroll
+        for (int m = SILK_MAX_LPC - 1; m > 0; m--) w[m] = w[m - 1];
+        w[0] = xi;
+    }
+}
+
 struct PitchCfg {                                       // the psEnc fields the call reads
     int fs_kHz, nb_subfr, frame_length, ltp_mem_length, la_pitch, pitch_LPC_win_length, pitchEstimationLPCOrder, pitchEstimationComplexity,
         pitchEstimationThreshold_Q16, signalType, first_frame_after_reset, speech_activity_Q8, prevSignalType, input_tilt_Q15, prevLag,
@@ -516,7 +557,7 @@ CA_DEV i32 pitch_whitening_filter_dev(i16 *A_Q12, const i32 *auto_corr, const in
     return predGain_Q16;
 }
 
-// x_buf: index 0 = x - ltp_mem_length (buf_len samples); res: buf_len samples out (read back by the estimator); ws / xs / scr:
+// x_buf: index 0 = x - ltp_mem_length (buf_len samples); res: buf_len samples out; ws / xs / scr (may be one array):
 // scratch of pitch_LPC_win_length, pitch_LPC_win_length and (20 + 5 nb_subfr) fs_kHz samples in the caller's storage.
 template <class XG, class RES, class SCR>
 CA_DEV void silk_find_pitch_lags_dev(const PitchCfg &c, XG x_buf, RES res, SCR ws, SCR xs, SCR scr, PitchOut &o)
@@ -525,7 +566,11 @@ CA_DEV void silk_find_pitch_lags_dev(const PitchCfg &c, XG x_buf, RES res, SCR w
     const XG xw = x_buf + (buf_len - W);
     silk_apply_sine_window_dev(ws, xw, 1, c.la_pitch);
     const int mid = W - (c.la_pitch << 1);
-    for (int i = 0; i < mid; i++) ws[c.la_pitch + i] = (i16)(i32)xw[c.la_pitch + i];
+    {
+        int i = 0;
+        for (; i + 8 <= mid; i += 8) { i32 v[8]; pe_load8(v, xw + (c.la_pitch + i)); pe_store8(ws + (c.la_pitch + i), v); }
+        for (; i < mid; i++) ws[c.la_pitch + i] = (i16)(i32)xw[c.la_pitch + i];
+    }
     silk_apply_sine_window_dev(ws + (c.la_pitch + mid), xw + (c.la_pitch + mid), 2, c.la_pitch);
     i32 auto_corr[SILK_MAX_LPC + 1];
     i16 A_Q12[SILK_MAX_LPC];
@@ -537,7 +582,9 @@ CA_DEV void silk_find_pitch_lags_dev(const PitchCfg &c, XG x_buf, RES res, SCR w
     else if (order == 10) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 10);
     else if (order == 8) o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, 8);
     else o.predGain_Q16 = pitch_whitening_filter_dev(A_Q12, auto_corr, order);
-    silk_LPC_analysis_filter_dev(res, x_buf, A_Q12, buf_len, order);
+    // the estimator's frame ((20 + 5 nb_subfr) ms of the whitened buffer) also goes to scr, where the estimator reads it (ws / xs are dead)
+    const int core_len = (PE_LTP_MEM_LENGTH_MS + c.nb_subfr * PE_SUBFR_LENGTH_MS) * c.fs_kHz;
+    silk_LPC_analysis_filter_dup_dev(res, scr, core_len, x_buf, A_Q12, buf_len, order);
     o.signalType = c.signalType;
     o.LTPCorr_Q15 = c.LTPCorr_Q15;
     if (c.signalType != 0 && c.first_frame_after_reset == 0) {
@@ -547,7 +594,7 @@ CA_DEV void silk_find_pitch_lags_dev(const PitchCfg &c, XG x_buf, RES res, SCR w
         thrhld_Q13 = thrhld_Q13 + s_smulbb(-1228, c.prevSignalType >> 1);
         thrhld_Q13 = s_smlawb(thrhld_Q13, -1637, c.input_tilt_Q15);
         thrhld_Q13 = thrhld_Q13 > 32767 ? 32767 : (thrhld_Q13 < -32768 ? -32768 : thrhld_Q13);
-        const int unvoiced = silk_pitch_analysis_core_dev(res, scr, o.pitchL, &o.lagIndex, &o.contourIndex, &o.LTPCorr_Q15, c.prevLag,
+        const int unvoiced = silk_pitch_analysis_core_dev(scr, scr, o.pitchL, &o.lagIndex, &o.contourIndex, &o.LTPCorr_Q15, c.prevLag,
                                                           c.pitchEstimationThreshold_Q16, (int)thrhld_Q13, c.fs_kHz, c.pitchEstimationComplexity,
                                                           c.nb_subfr);
         o.signalType = unvoiced ? 1 : 2;

@@ -47,6 +47,8 @@ __global__ __launch_bounds__(64) void silk_find_pred_coefs_kernel(const opusgpu_
     i16 pre[OPUSGPU_SILK_BURG_MAX_X];
     BurgEdgesCol e;
     e.p = edge_s + threadIdx.x;
+    // (private copies of res_pitch / x, fetched eight samples per access, were measured: 2.20 -> 2.48 ms -- the LTP analysis' windows
+    // are served by the L1 as they lie in the record)
     silk_find_pred_coefs_dev(c, (const i16 *)in.res_pitch, (const i16 *)in.x + in.ltp_mem_length, (i16 *)pre, e, o, &tables, &enc);
     const int order = in.predictLPCOrder, nb = in.nb_subfr;
     memset(&out, 0, sizeof(out));

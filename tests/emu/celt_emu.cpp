@@ -333,8 +333,8 @@ extern "C" void emu_silk_find_pitch_lags(const opusgpu_find_pitch_lags_in *in, o
         ca::PitchOut o;
         memset(&o, 0, sizeof(o));
         memset(&out[r], 0, sizeof(out[r]));
-        int16_t ws[384], xs[384], scr[640];
-        ca::silk_find_pitch_lags_dev(c, (const int16_t *)i.x_buf, (int16_t *)out[r].res, (int16_t *)ws, (int16_t *)xs, (int16_t *)scr, o);
+        int16_t work[640];                 // one array for the window block, its down-shifted copy and the estimator's frame, as in the kernel
+        ca::silk_find_pitch_lags_dev(c, (const int16_t *)i.x_buf, (int16_t *)out[r].res, (int16_t *)work, (int16_t *)work, (int16_t *)work, o);
         for (int k = 0; k < i.nb_subfr; k++) out[r].pitchL[k] = o.pitchL[k];
         out[r].lagIndex = o.lagIndex; out[r].contourIndex = o.contourIndex; out[r].LTPCorr_Q15 = o.LTPCorr_Q15; out[r].signalType = o.signalType;
         out[r].predGain_Q16 = o.predGain_Q16;
