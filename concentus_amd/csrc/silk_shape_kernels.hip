@@ -56,6 +56,35 @@ __global__ __launch_bounds__(64) void silk_noise_shape_kernel(const opusgpu_nois
     out.status = OPUSGPU_OK;
 }
 
+// The harmonic-shaping ring of silk_prefilter_state_FIX (sLTP_shp[512]) as the kernel holds it: a frame reads at most
+// lag + 2 <= PF_RING - 1 samples back from its newest entry and appends one per sample, so a lane keeps the newest PF_RING
+// entries as a ring of its own in its LDS column (40 KB per workgroup instead of 64: four workgroups per CU, the whole batch in
+// one round) and translates the 512-ring positions silk_prefilter_dev computes: distance from the newest entry -> slot.
+enum { PF_RING = 320 };
+struct PrefiltRingPos { int cur, head; };                      // 512-ring position and slot of the newest entry
+struct PrefiltRing {
+    i16 *col;                                                  // this lane's column, slot stride 64
+    PrefiltRingPos *s;
+    struct Ref {
+        const PrefiltRing *r;
+        int p;
+        __device__ __forceinline__ operator i32() const
+        {
+            int t = r->s->head + ((p - r->s->cur) & LTP_MASK);
+            t = t >= PF_RING ? t - PF_RING : t;
+            return (i32)r->col[t * 64];
+        }
+        __device__ __forceinline__ void operator=(i16 v) const                              // the reference appends at (newest - 1) & 511
+        {
+            const int h = r->s->head == 0 ? PF_RING - 1 : r->s->head - 1;
+            r->s->head = h;
+            r->s->cur = p;
+            r->col[h * 64] = v;
+        }
+    };
+    __device__ __forceinline__ Ref operator[](int k) const { return Ref{this, k}; }
+};
+
 struct OutCol32 {                                              // xw_Q3 straight into the output record
     i32 *p;
     __device__ __forceinline__ i32 &operator[](int k) const { return p[k]; }
@@ -64,7 +93,7 @@ struct OutCol32 {                                              // xw_Q3 straight
 __global__ __launch_bounds__(64) void silk_prefilter_kernel(const opusgpu_prefilter_in *__restrict__ recs, opusgpu_prefilter_state *__restrict__ states,
                                                             opusgpu_prefilter_out *__restrict__ outs, int n_rec, int *__restrict__ bad_records)
 {
-    __shared__ i16 ltp_s[LTP_BUF_LENGTH * 64];                 // the 64 harmonic-shaping ring buffers, [slot][lane]
+    __shared__ i16 ltp_s[PF_RING * 64];                        // the newest PF_RING entries of the 64 harmonic-shaping rings, [slot][lane]
     const int r = blockIdx.x * 64 + threadIdx.x;
     if (r >= n_rec) return;
     const opusgpu_prefilter_in &in = recs[r];
@@ -76,12 +105,20 @@ __global__ __launch_bounds__(64) void silk_prefilter_kernel(const opusgpu_prefil
         atomicAdd(bad_records, 1);
         return;
     }
-    ShapeCol ltp;
-    ltp.p = ltp_s + threadIdx.x;
-    for (int k = 0; k < LTP_BUF_LENGTH; k += 2) {
-        const int w = *reinterpret_cast<const int *>(&st.sLTP_shp[k]);
-        ltp[k] = (i16)w;
-        ltp[k + 1] = (i16)(w >> 16);
+    PrefiltRingPos rp;
+    rp.cur = st.sLTP_shp_buf_idx;
+    rp.head = 0;
+    PrefiltRing ltp;
+    ltp.col = ltp_s + threadIdx.x;
+    ltp.s = &rp;
+    for (int a = 0; a < PF_RING; a += 8) {                     // slot a <- the entry a behind the newest, eight per access where the 512-ring does not wrap
+        const int p0 = (rp.cur + a) & LTP_MASK;
+        i32 v[8];
+        if (p0 <= LTP_BUF_LENGTH - 8) pe_load8(v, (const i16 *)st.sLTP_shp + p0);
+        else
+            for (int u = 0; u < 8; u++) v[u] = st.sLTP_shp[(p0 + u) & LTP_MASK];
+#pragma unroll
+        for (int u = 0; u < 8; u++) ltp.col[(a + u) * 64] = (i16)v[u];
     }
     PrefilterState P;
     for (int k = 0; k <= MAX_SHAPE_LPC_ORDER; k++) P.sAR_shp[k] = st.sAR_shp[k];
@@ -99,8 +136,22 @@ __global__ __launch_bounds__(64) void silk_prefilter_kernel(const opusgpu_prefil
     xw.p = out.xw_Q3;
     silk_prefilter_dev(P, c, (const i16 *)in.x, xw, ltp);
     for (int k = in.nb_subfr * in.subfr_length; k < OPUSGPU_SILK_MAX_FRAME; k++) out.xw_Q3[k] = 0;
-    for (int k = 0; k < LTP_BUF_LENGTH; k += 2)
-        *reinterpret_cast<int *>(&st.sLTP_shp[k]) = (int)((u32)(u16)ltp[k] | ((u32)(u16)ltp[k + 1] << 16));
+    {                                                          // the frame's new entries back into the 512-ring (the others have not changed)
+        const int N = in.nb_subfr * in.subfr_length;           // <= PF_RING: appended this call, newest at rp.cur / slot rp.head
+        for (int a = 0; a < N; a += 8) {
+            const int p0 = (rp.cur + a) & LTP_MASK;
+            i32 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                int t = rp.head + a + u;
+                t = t >= PF_RING ? t - PF_RING : t;
+                v[u] = ltp.col[t * 64];
+            }
+            if (p0 <= LTP_BUF_LENGTH - 8 && a + 8 <= N) pe_store8((i16 *)st.sLTP_shp + p0, v);
+            else
+                for (int u = 0; u < 8 && a + u < N; u++) st.sLTP_shp[(p0 + u) & LTP_MASK] = (i16)v[u];
+        }
+    }
     for (int k = 0; k <= MAX_SHAPE_LPC_ORDER; k++) st.sAR_shp[k] = P.sAR_shp[k];
     st.sLTP_shp_buf_idx = P.sLTP_shp_buf_idx; st.sLF_AR_shp_Q12 = P.sLF_AR_shp_Q12; st.sLF_MA_shp_Q12 = P.sLF_MA_shp_Q12;
     st.sHarmHP_Q2 = P.sHarmHP_Q2; st.lagPrev = P.lagPrev;

@@ -95,9 +95,11 @@ __device__ __forceinline__ bool prefilter_record_ok(const opusgpu_prefilter_in &
     const int n = in.nb_subfr, L = in.subfr_length, D = in.shapingLPCOrder;
     if (!((n == 2 || n == 4) && L >= 1 && L <= 80 && n * L <= OPUSGPU_SILK_MAX_FRAME && D >= 2 && D <= 16 && !(D & 1))) return false;
     if ((unsigned)in.signalType > 2u || in.warping_Q16 < 0 || in.warping_Q16 > 32767) return false;
-    if ((unsigned)st.sLTP_shp_buf_idx > 511u || st.lagPrev < 0 || st.lagPrev > 508) return false;      // ring-buffer taps stay distinct from the write slot
+    // the harmonic-shaping taps reach lag + 2 entries back: inside the part of the ring the kernel keeps (silk_shape_kernels.hip PF_RING = 320;
+    // the encoder's lags end at 18 ms = 288 samples, pitch_est_defines.h PE_MAX_LAG_MS)
+    if ((unsigned)st.sLTP_shp_buf_idx > 511u || st.lagPrev < 0 || st.lagPrev == 1 || st.lagPrev > 316) return false;
     for (int k = 0; k < n; k++)
-        if (in.pitchL[k] < 0 || in.pitchL[k] > 508) return false;
+        if (in.pitchL[k] < 0 || in.pitchL[k] == 1 || in.pitchL[k] > 316) return false;
     return true;
 }
 

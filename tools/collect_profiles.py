@@ -33,6 +33,10 @@ for w in ("mdct", "decode", "silk", "silk_deldec", "silk_lpc", "mixed", "celt_st
     cp(os.path.join(src, "bench_prof_%s.json" % w), "bench_under_rocprof_%s.json" % w)
     for f in glob.glob(os.path.join(src, "stats_%s" % w, "**", "*_kernel_stats.csv"), recursive=True):
         cp(f, "kernel_stats_%s.csv" % w)
+if glob.glob(os.path.join(src, "silk_frames_pmc1")):
+    import subprocess
+    js = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "pmc_silk_summary.py"), src])
+    open(os.path.join(dst, "pmc_silk.json"), "wb").write(js)
 traffic = {}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 if os.path.exists(tp):

@@ -25,6 +25,7 @@ pmc_passes() {
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA --output-format csv -d $O/${w}_pmc2 -- python3 $R/bench.py --workload $w --steps 1 --warmup 0 --no-cpu-baseline --no-parity > /dev/null 2>> $O/prof_pmc_$w.err
   echo "pmc $w rc=$?"
 }
+python3 $R/bench.py --workload silk_lpc --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_prepare_silk_lpc.json 2> $O/prepare_silk_lpc.err   # its corpus, outside the profiler
 pmc_passes silk_frames && pmc_passes silk_nlsf && pmc_passes silk_lpc
 # instruction-fetch stalls (the analysis kernels are long straight-line code); last, since the counter names may not exist
 w=silk_frames
