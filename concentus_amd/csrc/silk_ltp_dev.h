@@ -46,18 +46,9 @@ CA_DEV void silk_sum_sqr_shift_dev(i32 *energy, int *shift, XA x, int len)      
     i32 nrg = 0;
     int shft = 0, i;
     len--;
+    // one loop for the reference's two (before / after the first overflow): with shft = 0 the second form is the first
+#pragma unroll 4
     for (i = 0; i < len; i += 2) {
-        const i32 a = x[i], b = x[i + 1];
-        nrg = s_addw(nrg, __mul24(a, a));
-        nrg = s_addw(nrg, __mul24(b, b));
-        if (nrg < 0) {
-            nrg = (i32)((u32)nrg >> 2);
-            shft = 2;
-            i += 2;
-            break;
-        }
-    }
-    for (; i < len; i += 2) {
         const i32 a = x[i], b = x[i + 1];
         const i32 t = s_addw(__mul24(a, a), __mul24(b, b));
         nrg = (i32)((u32)nrg + ((u32)t >> shft));

@@ -56,6 +56,7 @@ template <class XA>
 CA_DEV void silk_resampler_down2_dev(i32 *S, i16 *out, XA in, int inLen)                    // resampler_down2.c:36-74
 {
     const int len2 = inLen >> 1;
+#pragma unroll 4
     for (int k = 0; k < len2; k++) {
         i32 in32 = shl32((i32)in[2 * k], 10);
         i32 Y = s_subw(in32, S[0]);
@@ -98,6 +99,7 @@ template <class XA, class YA>
 CA_DEV i32 pe_inner_prod(XA x, YA y, int len)                                               // silk_inner_prod_aligned = celt_inner_prod
 {
     i32 s = 0;
+#pragma unroll 8
     for (int i = 0; i < len; i++) s = s_addw(s, __mul24((i32)x[i], (i32)y[i]));
     return s;
 }
@@ -179,15 +181,21 @@ CA_DEV int silk_pitch_analysis_core_geom_dev(XA frame, SCR scr, int *pitch_out, 
     }
     filt_state[0] = filt_state[1] = 0;
     silk_resampler_down2_dev(filt_state, frame_4kHz, (const i16 *)frame_8kHz, frame_length_8kHz);
-    for (int i = frame_length_4kHz - 1; i > 0; i--) {
-        const i32 v = (i32)frame_4kHz[i] + frame_4kHz[i - 1];
-        frame_4kHz[i] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+    {
+        i32 hi = frame_4kHz[frame_length_4kHz - 1];                                        // every sample is read once, on its way down
+#pragma unroll 4
+        for (int i = frame_length_4kHz - 1; i > 0; i--) {
+            const i32 lo = frame_4kHz[i - 1], v = hi + lo;
+            frame_4kHz[i] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+            hi = lo;
+        }
     }
     i32 energy;
     int shift;
     silk_sum_sqr_shift_dev(&energy, &shift, (const i16 *)frame_4kHz, frame_length_4kHz);
     if (shift > 0) {
         shift >>= 1;
+#pragma unroll 8
         for (int i = 0; i < frame_length_4kHz; i++) frame_4kHz[i] = (i16)(frame_4kHz[i] >> shift);
     }
     // ---- first stage, 4 kHz (:170-289)
@@ -252,8 +260,10 @@ CA_DEV int silk_pitch_analysis_core_geom_dev(XA frame, SCR scr, int *pitch_out, 
     silk_sum_sqr_shift_dev(&energy, &shift, (const i16 *)frame_8kHz, frame_length_8kHz);
     if (shift > 0) {
         shift >>= 1;
+#pragma unroll 8
         for (int i = 0; i < frame_length_8kHz; i++) frame_8kHz[i] = (i16)(frame_8kHz[i] >> shift);
     }
+#pragma unroll 8
     for (int i = 0; i < nb_subfr * CSTRIDE_8KHZ; i++) C[i] = 0;
     for (int k = 0; k < nb_subfr; k++) {
         const i16 *target_ptr = &frame_8kHz[PE_LTP_MEM_LENGTH_MS * 8 + k * SF_LENGTH_8KHZ];
@@ -333,6 +343,7 @@ CA_DEV int silk_pitch_analysis_core_geom_dev(XA frame, SCR scr, int *pitch_out, 
         const bool shifted = shift > 0;
         if (shifted) {
             shift >>= 1;
+#pragma unroll 8
             for (int i = 0; i < frame_length; i++) scr[i] = (i16)((i32)frame[i] >> shift);
         } else if ((const void *)&scr[0] != (const void *)&frame[0]) {                      // (the caller may hand over the frame in `scr` itself)
             for (int i = 0; i < frame_length; i++) scr[i] = (i16)(i32)frame[i];
