@@ -137,7 +137,12 @@ CA_DEV void silk_encode_pulses_dev(RangeEnc &ec, int signalType, int quantOffset
 {
     const int iter = frame_length >> 4;
     int sum_pulses[MAX_SHELL_BLOCKS], nRshifts[MAX_SHELL_BLOCKS];
-    for (int i = 0; i < iter * SHELL_FRAME; i++) { const int q = (i8)pulses[i]; absq[i] = (u8)(q < 0 ? -q : q); }
+    for (int i = 0; i < iter; i++) {                                                         // a shell block per 16-byte access
+        struct B16 { i8 b[SHELL_FRAME]; } blk;
+        __builtin_memcpy(&blk, &pulses[i * SHELL_FRAME], sizeof(blk));
+#pragma unroll
+        for (int k = 0; k < SHELL_FRAME; k++) { const int q = blk.b[k]; absq[i * SHELL_FRAME + k] = (u8)(q < 0 ? -q : q); }
+    }
     for (int i = 0; i < iter; i++) {
         u8 *ap = absq + i * SHELL_FRAME;
         nRshifts[i] = 0;

@@ -4,6 +4,41 @@
 #define CA_LANE_FRAME 1
 #include <stdlib.h>
 #include <string.h>
+#include "fixmath.h"
+#include "silk_entropy_tables.h"
+// The excitation coder looks its tables up at data-dependent per-lane addresses, once or twice per coded symbol, in one long
+// dependent chain: from the constant tables in global memory every look-up is an L1 / L2 round trip of a wavefront that has
+// nothing else to do. The workgroup keeps LDS copies and the sources below see those under the tables' names.
+#define SILK_BITS_LDS_TABLES(X) \
+    X(SILK_shell_code_table0, 152) X(SILK_shell_code_table1, 152) X(SILK_shell_code_table2, 152) X(SILK_shell_code_table3, 152) \
+    X(SILK_shell_code_table_offsets, 17) X(SILK_pulses_per_block_iCDF, 180) X(SILK_pulses_per_block_BITS_Q5, 162) \
+    X(SILK_rate_levels_iCDF, 18) X(SILK_rate_levels_BITS_Q5, 18) X(SILK_sign_iCDF, 42) X(SILK_lsb_iCDF, 2) X(SILK_max_pulses_table, 4)
+namespace ca {
+struct SilkBitsTablesLds {
+#define X(NAME, N) u8 NAME##_[N];
+    SILK_BITS_LDS_TABLES(X)
+#undef X
+};
+__shared__ SilkBitsTablesLds g_bits_tables;
+__device__ __forceinline__ void fill_bits_tables()             // followed by the caller's __syncthreads()
+{
+#define X(NAME, N) for (int k = threadIdx.x; k < N; k += blockDim.x) g_bits_tables.NAME##_[k] = NAME[k];
+    SILK_BITS_LDS_TABLES(X)
+#undef X
+}
+}  // namespace ca
+#define SILK_shell_code_table0 g_bits_tables.SILK_shell_code_table0_
+#define SILK_shell_code_table1 g_bits_tables.SILK_shell_code_table1_
+#define SILK_shell_code_table2 g_bits_tables.SILK_shell_code_table2_
+#define SILK_shell_code_table3 g_bits_tables.SILK_shell_code_table3_
+#define SILK_shell_code_table_offsets g_bits_tables.SILK_shell_code_table_offsets_
+#define SILK_pulses_per_block_iCDF g_bits_tables.SILK_pulses_per_block_iCDF_
+#define SILK_pulses_per_block_BITS_Q5 g_bits_tables.SILK_pulses_per_block_BITS_Q5_
+#define SILK_rate_levels_iCDF g_bits_tables.SILK_rate_levels_iCDF_
+#define SILK_rate_levels_BITS_Q5 g_bits_tables.SILK_rate_levels_BITS_Q5_
+#define SILK_sign_iCDF g_bits_tables.SILK_sign_iCDF_
+#define SILK_lsb_iCDF g_bits_tables.SILK_lsb_iCDF_
+#define SILK_max_pulses_table g_bits_tables.SILK_max_pulses_table_
 #include "silk_bits_dev.h"
 #include "opusgpu_internal.h"
 #include "../../include/opusgpu_silk.h"
@@ -17,6 +52,7 @@ __global__ __launch_bounds__(64) void silk_encode_bits_kernel(const opusgpu_silk
 {
     __shared__ NlsfTablesLds tables;
     nlsf_stage_tables(tables, threadIdx.x, blockDim.x);
+    fill_bits_tables();
     __syncthreads();
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_rec) return;
