@@ -69,66 +69,80 @@ CA_DEV void silk_sum_sqr_shift_dev(i32 *energy, int *shift, XA x, int len)      
     *energy = nrg;
 }
 
-// X'*t (corrMatrix_FIX.c:39-72); x: L + order - 1 samples forming the data matrix, t: L samples
-template <class XA>
-CA_DEV void silk_corrVector_dev(XA x, XA t, int L, int order, i32 *Xt, int rshifts)
+// X'*t (corrMatrix_FIX.c:39-72); x: L + ORDER - 1 samples forming the data matrix, t: L samples. One pass: the ORDER samples of x that
+// meet t[i] (one per lag) travel in a register window, so x and t are each read once instead of once per lag.
+template <int ORDER, class XA>
+CA_DEV void silk_corrVector_dev(XA x, XA t, int L, i32 *Xt, int rshifts)
 {
-    for (int lag = 0; lag < order; lag++) {
-        const int o = order - 1 - lag;                      // ptr1 = &x[order - 1] - lag
-        i32 s = 0;
-        if (rshifts > 0) {
-            for (int i = 0; i < L; i++) s += __mul24((i32)x[o + i], (i32)t[i]) >> rshifts;
-        } else {
-            for (int i = 0; i < L; i++) s = s_addw(s, __mul24((i32)x[o + i], (i32)t[i]));       // celt_inner_prod: MAC16_16, wraps
-        }
-        Xt[lag] = s;
+    i32 w[ORDER], s[ORDER];
+#pragma unroll
+    for (int m = 0; m < ORDER; m++) { s[m] = 0; w[m] = m < ORDER - 1 ? (i32)x[m] : 0; }
+#pragma unroll 8
+    for (int i = 0; i < L; i++) {
+        w[ORDER - 1] = (i32)x[i + ORDER - 1];
+        const i32 ti = (i32)t[i];
+#pragma unroll
+        for (int lag = 0; lag < ORDER; lag++) s[lag] = s_addw(s[lag], __mul24(w[ORDER - 1 - lag], ti) >> rshifts);     // ptr1 = &x[ORDER - 1] - lag
+#pragma unroll
+        for (int m = 0; m < ORDER - 1; m++) w[m] = w[m + 1];
     }
+#pragma unroll
+    for (int lag = 0; lag < ORDER; lag++) Xt[lag] = s[lag];
 }
 
-// X'*X (corrMatrix_FIX.c:75-158)
-template <class XA>
-CA_DEV void silk_corrMatrix_dev(XA x, int L, int order, int head_room, i32 *XX, int *rshifts)
+// X'*X (corrMatrix_FIX.c:75-158). The lag products in one pass over x (the same register window); the diagonals' edge corrections
+// read the first and last ORDER - 1 samples, kept in registers.
+template <int ORDER, class XA>
+CA_DEV void silk_corrMatrix_dev(XA x, int L, int head_room, i32 *XX, int *rshifts)
 {
     i32 energy;
     int rshifts_local;
-    silk_sum_sqr_shift_dev(&energy, &rshifts_local, x, L + order - 1);
+    silk_sum_sqr_shift_dev(&energy, &rshifts_local, x, L + ORDER - 1);
     const int head_room_rshifts = imax(head_room - s_clz32(energy), 0);
     energy >>= head_room_rshifts;
     rshifts_local += head_room_rshifts;
-    for (int i = 0; i < order - 1; i++) { const i32 v = x[i]; energy -= __mul24(v, v) >> rshifts_local; }
+    i32 hd[ORDER - 1], tl[ORDER - 1];                       // x[0 .. ORDER - 1) and x[L .. L + ORDER - 1)
+#pragma unroll
+    for (int m = 0; m < ORDER - 1; m++) { hd[m] = x[m]; tl[m] = x[L + m]; }
+#pragma unroll
+    for (int i = 0; i < ORDER - 1; i++) energy -= __mul24(hd[i], hd[i]) >> rshifts_local;
     if (rshifts_local < *rshifts) {
         energy >>= *rshifts - rshifts_local;
         rshifts_local = *rshifts;
     }
     XX[0] = energy;
-    const int p1 = order - 1;                               // ptr1 = &x[order - 1]
-    for (int j = 1; j < order; j++) {
-        const i32 a = x[p1 + L - j], b = x[p1 - j];
+    // ptr1 = &x[ORDER - 1]: x[p1 + L - j] = tl[ORDER - 1 - j], x[p1 - j] = hd[ORDER - 1 - j]
+#pragma unroll
+    for (int j = 1; j < ORDER; j++) {
+        const i32 a = tl[ORDER - 1 - j], b = hd[ORDER - 1 - j];
         energy = s_subw(energy, __mul24(a, a) >> rshifts_local);
         energy = s_addw(energy, __mul24(b, b) >> rshifts_local);
-        XX[j * order + j] = energy;
+        XX[j * ORDER + j] = energy;
     }
-    int p2 = order - 2;                                     // ptr2 = &x[order - 2]
-    for (int lag = 1; lag < order; lag++, p2--) {
-        energy = 0;
-        if (rshifts_local > 0) {
-            for (int i = 0; i < L; i++) energy += __mul24((i32)x[p1 + i], (i32)x[p2 + i]) >> rshifts_local;
-        } else {
-            for (int i = 0; i < L; i++) energy = s_addw(energy, __mul24((i32)x[p1 + i], (i32)x[p2 + i]));
-        }
-        XX[lag * order] = energy;
+    i32 E[ORDER], w[ORDER];                                 // E[lag] = sum_i x[p1 + i] * x[p1 - lag + i]
+#pragma unroll
+    for (int m = 0; m < ORDER; m++) { E[m] = 0; w[m] = m < ORDER - 1 ? hd[m] : 0; }
+#pragma unroll 8
+    for (int i = 0; i < L; i++) {
+        w[ORDER - 1] = (i32)x[i + ORDER - 1];
+#pragma unroll
+        for (int lag = 1; lag < ORDER; lag++) E[lag] = s_addw(E[lag], __mul24(w[ORDER - 1], w[ORDER - 1 - lag]) >> rshifts_local);
+#pragma unroll
+        for (int m = 0; m < ORDER - 1; m++) w[m] = w[m + 1];
+    }
+#pragma unroll
+    for (int lag = 1; lag < ORDER; lag++) {
+        energy = E[lag];
+        XX[lag * ORDER] = energy;
         XX[lag] = energy;
-        for (int j = 1; j < order - lag; j++) {
-            const i32 a1 = x[p1 + L - j], a2 = x[p2 + L - j], b1 = x[p1 - j], b2 = x[p2 - j];
-            if (rshifts_local > 0) {
-                energy = s_subw(energy, __mul24(a1, a2) >> rshifts_local);
-                energy = s_addw(energy, __mul24(b1, b2) >> rshifts_local);
-            } else {
-                energy = s_subw(energy, __mul24(a1, a2));
-                energy = s_addw(energy, __mul24(b1, b2));
-            }
-            XX[(lag + j) * order + j] = energy;
-            XX[j * order + lag + j] = energy;
+        // ptr2 = &x[ORDER - 1 - lag]: x[p2 + L - j] = tl[ORDER - 1 - lag - j], x[p2 - j] = hd[ORDER - 1 - lag - j]
+#pragma unroll
+        for (int j = 1; j < ORDER - lag; j++) {
+            const i32 a1 = tl[ORDER - 1 - j], a2 = tl[ORDER - 1 - lag - j], b1 = hd[ORDER - 1 - j], b2 = hd[ORDER - 1 - lag - j];
+            energy = s_subw(energy, __mul24(a1, a2) >> rshifts_local);
+            energy = s_addw(energy, __mul24(b1, b2) >> rshifts_local);
+            XX[(lag + j) * ORDER + j] = energy;
+            XX[j * ORDER + lag + j] = energy;
         }
     }
     *rshifts = rshifts_local;
@@ -246,8 +260,8 @@ CA_DEV void silk_find_LTP_dev(i16 *b_Q14, i32 *WLTP, int *LTPredCodGain_Q7, XA r
             rr_shifts += LTP_CORRS_HEAD_ROOM - LZs;
         }
         corr_rshifts[k] = rr_shifts;
-        silk_corrMatrix_dev(lag_ptr, subfr_length, LTP_ORDER, LTP_CORRS_HEAD_ROOM, WLTP_ptr, &corr_rshifts[k]);
-        silk_corrVector_dev(lag_ptr, r_ptr, subfr_length, LTP_ORDER, Rr, corr_rshifts[k]);
+        silk_corrMatrix_dev<LTP_ORDER>(lag_ptr, subfr_length, LTP_CORRS_HEAD_ROOM, WLTP_ptr, &corr_rshifts[k]);
+        silk_corrVector_dev<LTP_ORDER>(lag_ptr, r_ptr, subfr_length, Rr, corr_rshifts[k]);
         if (corr_rshifts[k] > rr_shifts) rr[k] >>= corr_rshifts[k] - rr_shifts;
         // SILK_FIX_CONST(LTP_DAMPING / 3 = 0.05 / 3, 16) = 1092
         i32 regu = 1;
