@@ -159,13 +159,31 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             const int lg = in.pitchL[k];
             if (rewhite_flag) {
                 if (k == 0) inv_gain_Q31 = shl32(s_smulwb(inv_gain_Q31, in.LTP_scale_Q14), 2);
+#pragma unroll 4
                 for (int i = sLTP_buf_idx - lg - 5 / 2; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
             }
             if (gain_adj_Q16 != (i32)1 << 16) {
-                for (int i = sLTP_shp_buf_idx - ltp_mem_length; i < sLTP_shp_buf_idx; i++)
-                    NSQ.sLTP_shp_Q14[i] = s_smulww(gain_adj_Q16, NSQ.sLTP_shp_Q14[i]);
-                if (voiced && rewhite_flag == 0)
-                    for (int i = sLTP_buf_idx - lg - 5 / 2; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulww(gain_adj_Q16, sLTP_Q15[i]);
+                // four values per access (the record is 4-byte aligned): a lane's access to its own record costs a cache line per
+                // instruction whatever its width
+                struct __attribute__((packed, aligned(4))) Q4 { i32 v[4]; };
+                int i = sLTP_shp_buf_idx - ltp_mem_length;
+                for (; i + 4 <= sLTP_shp_buf_idx; i += 4) {
+                    Q4 q = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[i]);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) q.v[u] = s_smulww(gain_adj_Q16, q.v[u]);
+                    *reinterpret_cast<Q4 *>(&NSQ.sLTP_shp_Q14[i]) = q;
+                }
+                for (; i < sLTP_shp_buf_idx; i++) NSQ.sLTP_shp_Q14[i] = s_smulww(gain_adj_Q16, NSQ.sLTP_shp_Q14[i]);
+                if (voiced && rewhite_flag == 0) {
+                    i = sLTP_buf_idx - lg - 5 / 2;
+                    for (; i + 4 <= sLTP_buf_idx; i += 4) {
+                        Q4 q = *reinterpret_cast<const Q4 *>(&sLTP_Q15[i]);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) q.v[u] = s_smulww(gain_adj_Q16, q.v[u]);
+                        *reinterpret_cast<Q4 *>(&sLTP_Q15[i]) = q;
+                    }
+                    for (; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulww(gain_adj_Q16, sLTP_Q15[i]);
+                }
                 sLF_AR_shp_Q14 = s_smulww(gain_adj_Q16, sLF_AR_shp_Q14);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
@@ -200,6 +218,160 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
         if (lag > 0) {
 #pragma unroll
             for (int j = 0; j < 3; j++) st[j] = NSQ.sLTP_shp_Q14[shp_lag - j];
+        }
+        struct __attribute__((packed, aligned(4))) Q4 { i32 v[4]; };
+        // ---- the usual case (no pitch lag, or one of >= 12 samples; subframes of 4n samples), four samples per group ----
+        // What limits the kernel is the memory pipeline, not arithmetic: a lane's load or store of its own record occupies it for a
+        // cache line whatever its width, and loads queue behind earlier stores (one counter orders both). So a group's three inputs
+        // (x_Q3, the prediction tap, the shaping tap: four values each) are ONE 16-byte load each, issued BEFORE the previous group's
+        // five 16-byte stores, whose completion then overlaps the next group's arithmetic. Inside a group the two 16-deep
+        // histories (sLPC_Q14's newest samples, the sAR2 delay line) are not shifted per sample: sample u reads them through
+        // compile-time indices into [the group's new values | the registers as they were at the group's start].
+        const bool fast = (lag <= 0 || lag >= 12) && (subfr_length & 3) == 0;
+        if (fast) {
+            i32 ar13z[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) ar13z[j] = j < shapingLPCOrder ? ar13[j] : 0;       // the delay line beyond the order adds nothing
+            Q4 xg, pg, sg;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { pg.v[u] = 0; sg.v[u] = 0; }
+            xg = *reinterpret_cast<const Q4 *>(&x_Q3[0]);
+            if (voiced) pg = *reinterpret_cast<const Q4 *>(&sLTP_Q15[pred_lag + 1]);
+            if (lag > 0) sg = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[shp_lag + 1]);
+            for (int i0 = 0; i0 < subfr_length; i0 += 4) {
+                i32 nw[4] = {0, 0, 0, 0}, sv[4] = {0, 0, 0, 0}, o_shp[4], o_ltp[4];
+                u32 o_xq[4], o_pl[4];
+                const int shp_idx0 = sLTP_shp_buf_idx, ltp_idx0 = sLTP_buf_idx;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    rand_seed = (i32)(907633515u + (u32)rand_seed * 196314165u);
+                    sv[u] = u == 0 ? lp[0] : nw[u - 1];                                    // the newest sLPC_Q14 sample enters the delay line
+                    i32 LPC_pred_Q10 = predictLPCOrder >> 1;
+#pragma unroll
+                    for (int j = 0; j < 10; j++) LPC_pred_Q10 = s_smlawb(LPC_pred_Q10, j < u ? nw[u - 1 - j] : lp[j - u], a12[j]);
+                    if (predictLPCOrder == 16) {
+#pragma unroll
+                        for (int j = 10; j < 16; j++) LPC_pred_Q10 = s_smlawb(LPC_pred_Q10, j < u ? nw[u - 1 - j] : lp[j - u], a12[j]);
+                    }
+                    i32 LTP_pred_Q13 = 0;
+                    if (voiced) {
+                        LTP_pred_Q13 = 2;
+                        LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[0], b0);
+                        LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[1], b1);
+                        LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[2], b2);
+                        LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[3], b3);
+                        LTP_pred_Q13 = s_smlawb(LTP_pred_Q13, pt[4], b4);
+                    }
+                    // noise shape feedback (NSQ.c:262-279): after the shift the delay line holds [sv[u], sv[u-1], .., ar[0], ar[1], ..]
+                    i32 n_AR_Q12 = shapingLPCOrder >> 1;
+#pragma unroll
+                    for (int j = 0; j < 16; j++) n_AR_Q12 = s_smlawb(n_AR_Q12, j <= u ? sv[u - j] : ar[j - u - 1], ar13z[j]);
+                    n_AR_Q12 = shl32(n_AR_Q12, 1);
+                    n_AR_Q12 = s_smlawb(n_AR_Q12, sLF_AR_shp_Q14, Tilt_Q14);
+                    i32 n_LF_Q12 = s_smulwb(shp_prev, LF_shp_Q14);
+                    n_LF_Q12 = s_smlawt(n_LF_Q12, sLF_AR_shp_Q14, LF_shp_Q14);
+                    i32 tmp1 = s_subw(shl32(LPC_pred_Q10, 2), n_AR_Q12);
+                    tmp1 = s_subw(tmp1, n_LF_Q12);
+                    if (lag > 0) {
+                        i32 n_LTP_Q13 = s_smulwb(s_addw(st[0], st[2]), HarmShapeFIRPacked_Q14);
+                        n_LTP_Q13 = s_smlawt(n_LTP_Q13, st[1], HarmShapeFIRPacked_Q14);
+                        n_LTP_Q13 = shl32(n_LTP_Q13, 1);
+                        const i32 tmp2 = s_subw(LTP_pred_Q13, n_LTP_Q13);
+                        tmp1 = s_addw(tmp2, shl32(tmp1, 1));
+                        tmp1 = s_rshift_round(tmp1, 3);
+                    } else {
+                        tmp1 = s_rshift_round(tmp1, 2);
+                    }
+                    i32 r_Q10 = s_subw(s_smulww(xg.v[u], inv_gain_Q23), tmp1);
+                    if (rand_seed < 0) r_Q10 = (i32)(0u - (u32)r_Q10);
+                    r_Q10 = s_limit(r_Q10, -(31 << 10), 30 << 10);
+                    i32 q1_Q10 = r_Q10 - offset_Q10, q2_Q10, rd1_Q20, rd2_Q20;
+                    const i32 q1_Q0 = q1_Q10 >> 10;
+                    if (q1_Q0 > 0) {
+                        q1_Q10 = shl32(q1_Q0, 10) - 80 + offset_Q10;
+                        q2_Q10 = q1_Q10 + 1024;
+                        rd1_Q20 = s_smulbb(q1_Q10, Lambda_Q10);
+                        rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else if (q1_Q0 == 0) {
+                        q1_Q10 = offset_Q10;
+                        q2_Q10 = q1_Q10 + (1024 - 80);
+                        rd1_Q20 = s_smulbb(q1_Q10, Lambda_Q10);
+                        rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else if (q1_Q0 == -1) {
+                        q2_Q10 = offset_Q10;
+                        q1_Q10 = q2_Q10 - (1024 - 80);
+                        rd1_Q20 = s_smulbb(-q1_Q10, Lambda_Q10);
+                        rd2_Q20 = s_smulbb(q2_Q10, Lambda_Q10);
+                    } else {
+                        q1_Q10 = shl32(q1_Q0, 10) + 80 + offset_Q10;
+                        q2_Q10 = q1_Q10 + 1024;
+                        rd1_Q20 = s_smulbb(-q1_Q10, Lambda_Q10);
+                        rd2_Q20 = s_smulbb(-q2_Q10, Lambda_Q10);
+                    }
+                    i32 rr_Q10 = r_Q10 - q1_Q10;
+                    rd1_Q20 = s_addw(rd1_Q20, s_smulbb(rr_Q10, rr_Q10));
+                    rr_Q10 = r_Q10 - q2_Q10;
+                    rd2_Q20 = s_addw(rd2_Q20, s_smulbb(rr_Q10, rr_Q10));
+                    if (rd2_Q20 < rd1_Q20) q1_Q10 = q2_Q10;
+                    const i32 pulse = (i8)s_rshift_round(q1_Q10, 10);
+                    o_pl[u] = (u32)pulse & 0xffu;
+                    i32 exc_Q14 = shl32(q1_Q10, 4);
+                    if (rand_seed < 0) exc_Q14 = (i32)(0u - (u32)exc_Q14);
+                    const i32 LPC_exc_Q14 = s_addw(exc_Q14, shl32(LTP_pred_Q13, 1));
+                    const i32 xq_Q14 = s_addw(LPC_exc_Q14, shl32(LPC_pred_Q10, 4));
+                    {   // silk_SAT16(silk_RSHIFT_ROUND(silk_SMULWW(xq_Q14, Gain_Q10), 8)) in 64 bits
+                        i64 t = ((i64)xq_Q14 * Gain_Q10) >> 16;
+                        t = ((t >> 7) + 1) >> 1;
+                        o_xq[u] = (u32)(i32)(t > 32767 ? 32767 : (t < -32768 ? -32768 : t)) & 0xffffu;
+                    }
+                    nw[u] = xq_Q14;
+                    sLF_AR_shp_Q14 = s_subw(xq_Q14, shl32(n_AR_Q12, 2));
+                    shp_prev = s_subw(sLF_AR_shp_Q14, shl32(n_LF_Q12, 2));
+                    o_shp[u] = shp_prev;
+                    o_ltp[u] = shl32(LPC_exc_Q14, 1);
+                    rand_seed = (i32)((u32)rand_seed + (u32)pulse);
+                    pt[4] = pt[3]; pt[3] = pt[2]; pt[2] = pt[1]; pt[1] = pt[0]; pt[0] = pg.v[u];
+                    st[2] = st[1]; st[1] = st[0]; st[0] = sg.v[u];
+                }
+                sLTP_shp_buf_idx += 4;
+                sLTP_buf_idx += 4;
+                pred_lag += 4;
+                shp_lag += 4;
+                if (i0 + 4 < subfr_length) {                                                // the next group's inputs, ahead of this group's stores
+                    xg = *reinterpret_cast<const Q4 *>(&x_Q3[i0 + 4]);
+                    if (voiced) pg = *reinterpret_cast<const Q4 *>(&sLTP_Q15[pred_lag + 1]);
+                    if (lag > 0) sg = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[shp_lag + 1]);
+                }
+                *reinterpret_cast<u32 *>(&pulses[k * subfr_length + i0]) = o_pl[0] | (o_pl[1] << 8) | (o_pl[2] << 16) | (o_pl[3] << 24);
+                {
+                    struct __attribute__((packed, aligned(4))) Q2 { i32 v[2]; } xv;
+                    xv.v[0] = (i32)(o_xq[0] | (o_xq[1] << 16)); xv.v[1] = (i32)(o_xq[2] | (o_xq[3] << 16));
+                    *reinterpret_cast<Q2 *>(&pxq[i0]) = xv;
+                    Q4 v;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v.v[u] = nw[u];
+                    *reinterpret_cast<Q4 *>(&NSQ.sLPC_Q14[32 + i0]) = v;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v.v[u] = o_shp[u];
+                    *reinterpret_cast<Q4 *>(&NSQ.sLTP_shp_Q14[shp_idx0]) = v;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) v.v[u] = o_ltp[u];
+                    *reinterpret_cast<Q4 *>(&sLTP_Q15[ltp_idx0]) = v;
+                }
+                // the histories move by the four samples at once: [lpc_old (older 16) | lp (newer 16, newest first)], the delay line up to its order
+#pragma unroll
+                for (int j = 0; j < 16; j++) lpc_old[j] = j < 12 ? lpc_old[j + 4] : lp[27 - j];
+#pragma unroll
+                for (int j = 15; j >= 4; j--) lp[j] = lp[j - 4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) lp[j] = nw[3 - j];
+#pragma unroll
+                for (int j = 15; j >= 0; j--) {
+                    const i32 moved = j < 4 ? sv[3 - j] : ar[j - 4];
+                    ar[j] = j < shapingLPCOrder ? moved : ar[j];
+                }
+            }
+            continue;                                         // next subframe
         }
         const bool ahead = lag >= 8;
         i32 xn = x_Q3[0];

@@ -188,7 +188,18 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx; i += 4) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
             }
             if (adj != (i32)1 << 16) {
-                for (int i = shp_idx - ltp_mem + k; i < shp_idx; i += 4) NSQ.sLTP_shp_Q14[i] = s_smulww(adj, NSQ.sLTP_shp_Q14[i]);
+                {
+                    // every lane of the quad takes four consecutive values per access (16 bytes; the record is 4-byte aligned)
+                    struct __attribute__((packed, aligned(4))) Q4 { i32 v[4]; };
+                    const int i0 = shp_idx - ltp_mem, body = ltp_mem & ~15;
+                    for (int i = i0 + 4 * k; i < i0 + body; i += 16) {
+                        Q4 q = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[i]);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) q.v[u] = s_smulww(adj, q.v[u]);
+                        *reinterpret_cast<Q4 *>(&NSQ.sLTP_shp_Q14[i]) = q;
+                    }
+                    for (int i = i0 + body + k; i < shp_idx; i += 4) NSQ.sLTP_shp_Q14[i] = s_smulww(adj, NSQ.sLTP_shp_Q14[i]);
+                }
                 if (voiced && rewhite == 0)
                     for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx - delay; i += 4) sLTP_Q15[i] = s_smulww(adj, sLTP_Q15[i]);
                 lf_ar = s_smulww(adj, lf_ar);
