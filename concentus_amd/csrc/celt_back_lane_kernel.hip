@@ -64,7 +64,9 @@ void celt_back_lane16_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states
 extern "C" int opusgpu_lane_frames(void)
 {
     // measured on MI355X at 65 536 frames: back kernel 5.91 ms (64) / 5.53 ms (32) / 9.87 ms (16: 218 VGPRs allow two
-    // wavefronts per SIMD, so four quarter-filled ones take two rounds). Read per call so tests can compare the mappings.
+    // wavefronts per SIMD, so four quarter-filled ones take two rounds). Round 3, without the private working set (3.36 ms at 32):
+    // three wavefronts of 22 / 21 / 21 frames at 168 VGPRs 5.14 ms, four of 16 at 128 VGPRs 4.50 ms -- narrower wavefronts run
+    // chains that are hardly shorter, and there are more of them to issue. Read per call so tests can compare the mappings.
     const char *e = getenv("OPUSGPU_LANE_FRAMES");
     const int v = e ? atoi(e) : 32;
     return (v == 16 || v == 32 || v == 64) ? v : 32;
