@@ -282,8 +282,8 @@ def _pool_run(work, n):
     return run
 
 
-def cpu_baseline_silk_encoder(complexity=7):
-    """The reference's own opus_encode() as a 16 kHz mono VOIP constant-bitrate SILK encoder (32 kb/s, 20 ms frames) on synthetic
+def cpu_baseline_silk_encoder(complexity=7, vbr=0):
+    """The reference's own opus_encode() as a 16 kHz mono VOIP SILK encoder (32 kb/s, 20 ms frames; constant bitrate unless vbr) on synthetic
     speech, one encoder per host thread (oracle/ref_driver.c refdrv_silk_encode_loop) -- the whole encoder, i.e. silk_encode_frame_FIX
     plus what surrounds it (input filters, resampler, VAD, packet assembly). kind "reference"."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -301,16 +301,16 @@ def cpu_baseline_silk_encoder(complexity=7):
         loops, t = 1, 0.0
         while True:
             t0 = time.perf_counter()
-            assert drv.refdrv_silk_encode_loop(_p(pcm), nfr, 320, 16000, 32000, 0, complexity, loops, threads) > 0
+            assert drv.refdrv_silk_encode_loop(_p(pcm), nfr, 320, 16000, 32000, vbr, complexity, loops, threads) > 0
             t = time.perf_counter() - t0
             if t > 3.0 or loops >= 64:
                 break
             loops *= 2
         rates.append(nfr * loops * threads / t)
     return {"value": round(rates[1], 1), "unit": "frames/s", "cores": cores, "kind": "reference", "cpu": cpu_model(),
-            "sample": "opus-fix opus_encode() as a 16 kHz mono VOIP CBR 32 kb/s SILK encoder (complexity %d) over 1 000 frames of synthetic speech, "
+            "sample": "opus-fix opus_encode() as a 16 kHz mono VOIP %s 32 kb/s SILK encoder (complexity %d) over 1 000 frames of synthetic speech, "
                       "repeated >= 3 s, one encoder per thread at 1 and %d threads; the WHOLE encoder (input filters, VAD, packet assembly included); "
-                      "1 thread: %.0f frames/s" % (complexity, cores, rates[0])}
+                      "1 thread: %.0f frames/s" % ("VBR" if vbr else "CBR", complexity, cores, rates[0])}
 
 
 def cpu_baseline_silk(bi, ni, st0):
@@ -833,7 +833,7 @@ def main(argv=None):
         elapsed = time.perf_counter() - t0
         barrier()
         kms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-        kname = "silk_find_pred_coefs_kernel"
+        kname = "silk_nsq_del_dec_kernel"           # the longest of the step's kernels; avg_launch_ms below is the WHOLE step (extra["note"])
         kbytes = F * (1408 + 324 + 4380 + 1116 + 1328)  # per frame: pitch buffer in, pulses + Seed out, the carried states and the coder rewritten
         limiter = "latency / VALU issue (seven lane-per-frame kernels of serial fixed-point recurrences; whole step timed, kernel = the longest)"
         metric = "SILK 16kHz mono 20ms frames/sec (analysis chain + silk_NSQ_del_dec + entropy coding, pitch buffer -> range-coder bytes)"
@@ -853,10 +853,17 @@ def main(argv=None):
             b_ = cpu_baseline_silk_dd(np.ascontiguousarray(rec["c_q_in"][:m_cpu]), np.ascontiguousarray(rec["c_q_state_in"][:m_cpu]))
             c_ = cpu_baseline_silk_bits(np.ascontiguousarray(rec["c_bits_in"][:m_cpu]), np.ascontiguousarray(rec["c_ec_in"][:m_cpu]))
             v = 1.0 / (1.0 / a_["value"] + 1.0 / b_["value"] + 1.0 / c_["value"])
-            return {"value": round(v, 1), "unit": "frames/s", "cores": a_["cores"], "kind": "port", "cpu": a_["cpu"],
+            port = {"value": round(v, 1), "unit": "frames/s", "cores": a_["cores"], "kind": "port", "cpu": a_["cpu"],
                     "sample": "analysis: " + a_["sample"] + "; quantiser: " + b_["sample"] + "; entropy coding: " + c_["sample"]
                               + "; combined as 1 / (1/a + 1/b + 1/c)"
                               + ("; ONE pass per frame (the loop's further quantiser + coder passes are not in this baseline)" if cbr else "")}
+            # the baseline proper: the unmodified reference encoder at the same settings (it also does what surrounds the frame
+            # function); the host build of the kernel sources stays beside it as "port"
+            ref = cpu_baseline_silk_encoder(7, 0 if cbr else 1)
+            if ref.get("value"):
+                ref["port"] = port
+                return ref
+            return port
         if cbr:
             passes = rec["c_frame_args"].view(np.int32)[:, 3]
             workload += ("; CBR: after every pass one rate-control step, the frames over / under budget quantised + coded again from their "
@@ -1394,8 +1401,12 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": workload, "frames_per_gpu": F, "channels": 2,
-                       "sharding": "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0"},
+            "config": {"workload": workload, "frames_per_gpu": F,
+                       # the SILK workloads are 16 kHz mono records / frames; mdct / celt / decode / mixed carry 48 kHz stereo
+                       "channels": 1 if a.workload.startswith("silk") else 2,
+                       "sharding": ("records block-partitioned across ranks, no data-path collective, nothing gathered (the outputs stay on their rank)"
+                                    if a.workload.startswith("silk") or a.workload in ("mdct", "decode") else
+                                    "frames block-partitioned across ranks, no data-path collective; packets gathered to rank 0")},
             **({"rehearsal": True} if (host_gather or one_device) else {}),
             # transport evidence for a multi-GPU record: which torch.distributed backend ran ("nccl" = RCCL), how many ranks
             # it saw, and every rank's own rate over the timed region (units/s from that rank's clock)
