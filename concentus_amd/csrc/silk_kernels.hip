@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64) void silk_burg_kernel(const opusgpu_burg_in *__
 }
 
 // ---- silk_NSQ: one lane per record ---------------------------------------------------------------------
-// ws: per-record scratch in HBM for the two re-whitening buffers: int32 sLTP_Q15[640] then int16 sLTP[640].
+// ws: per-record scratch in HBM: the scaled re-whitened prediction buffer int32 sLTP_Q15[640] (the int16 sLTP[640] behind it is
+// unused since the re-whitening writes its outputs scaled; it stays in the workspace's size).
 struct NsqScratch { i32 sLTP_Q15[640]; i16 sLTP[640]; };
 
 __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__restrict__ recs, opusgpu_nsq_state *__restrict__ states,
@@ -89,7 +90,6 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
         return;
     }
     i32 *sLTP_Q15 = ws[r].sLTP_Q15;
-    i16 *sLTP = ws[r].sLTP;
     const int nb_subfr = in.nb_subfr, subfr_length = in.subfr_length, frame_length = in.frame_length;
     const int ltp_mem_length = in.ltp_mem_length, predictLPCOrder = in.predictLPCOrder, shapingLPCOrder = in.shapingLPCOrder;
     const int signalType = in.signalType;
@@ -122,10 +122,14 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
             lag = in.pitchL[k];
             if ((k & (3 - (LSF_interpolation_flag << 1))) == 0) {
                 const int start_idx = ltp_mem_length - lag - predictLPCOrder - 5 / 2;
-                // silk_LPC_analysis_filter (celt_fir form): out = SAT16(in + PSHR32(-sum B[m] in[ix-1-m], 12))
+                // silk_LPC_analysis_filter (celt_fir form): out = SAT16(in + PSHR32(-sum B[m] in[ix-1-m], 12)), fused with the scaling
+                // silk_nsq_scale_states applies to exactly these lag + 2 outputs (NSQ.c:445-456: sLTP_Q15[i] = SMULWB(inv_gain_Q31,
+                // sLTP[i])): the 16-bit sLTP buffer in between is never written or read, four results leave per 16-byte store
                 const i16 *inp = &NSQ.xq[start_idx + k * subfr_length];
-                i16 *outp = &sLTP[start_idx];
+                i32 *outq = &sLTP_Q15[start_idx];
                 const int len = ltp_mem_length - start_idx;
+                i32 ig_Q31 = s_inverse32_varq(in.Gains_Q16[k] > 1 ? in.Gains_Q16[k] : 1, 47);
+                if (k == 0) ig_Q31 = shl32(s_smulwb(ig_Q31, in.LTP_scale_Q14), 2);
                 // the predictLPCOrder previous input samples travel in a register window: every sample of xq is read once
                 i32 nA[16], w[16];
 #pragma unroll
@@ -133,57 +137,78 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
                     nA[m] = m < predictLPCOrder ? (i32)(i16)(-A_Q12[m]) : 0;
                     w[m] = m < predictLPCOrder ? (i32)inp[predictLPCOrder - 1 - m] : 0;
                 }
-                for (int ix = predictLPCOrder; ix < len; ix++) {
+                struct __attribute__((packed, aligned(2))) H4 { i16 v[4]; };
+                struct __attribute__((packed, aligned(4))) W4 { i32 v[4]; };
+                int ix = predictLPCOrder;
+                for (; ix + 4 <= len; ix += 4) {
+                    const H4 xi4 = *reinterpret_cast<const H4 *>(&inp[ix]);
+                    W4 o;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        i32 sum = 0;
+#pragma unroll
+                        for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
+                        const i32 xi = (i32)xi4.v[u];
+                        i32 v = xi + pshr32(sum, 12);
+                        v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+                        o.v[u] = s_smulwb(ig_Q31, v);
+#pragma unroll
+                        for (int m = 15; m > 0; m--) w[m] = w[m - 1];
+                        w[0] = xi;
+                    }
+                    *reinterpret_cast<W4 *>(&outq[ix]) = o;
+                }
+                for (; ix < len; ix++) {
                     i32 sum = 0;
 #pragma unroll
                     for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
                     const i32 xi = (i32)inp[ix];
                     i32 v = xi + pshr32(sum, 12);
-                    outp[ix] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
+                    v = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+                    outq[ix] = s_smulwb(ig_Q31, v);
 #pragma unroll
                     for (int m = 15; m > 0; m--) w[m] = w[m - 1];
                     w[0] = xi;
                 }
-                for (int j = 0; j < predictLPCOrder; j++) outp[j] = 0;
                 rewhite_flag = 1;
                 sLTP_buf_idx = ltp_mem_length;
             }
         }
         // ---- silk_nsq_scale_states (NSQ.c:423-496) ----
         const i32 gain = in.Gains_Q16[k];
-        i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
+        const i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
         const i32 gain_adj_Q16 = gain != prev_gain_Q16 ? s_div32_varq(prev_gain_Q16, gain, 16) : (i32)1 << 16;
         const i32 inv_gain_Q23 = s_rshift_round(inv_gain_Q31, 8);
         prev_gain_Q16 = gain;
         {
             const int lg = in.pitchL[k];
-            if (rewhite_flag) {
-                if (k == 0) inv_gain_Q31 = shl32(s_smulwb(inv_gain_Q31, in.LTP_scale_Q14), 2);
-#pragma unroll 4
-                for (int i = sLTP_buf_idx - lg - 5 / 2; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
-            }
+            // (rewhite_flag: sLTP_Q15[idx - lag - 2 .. idx) was scaled where it was produced, above)
             if (gain_adj_Q16 != (i32)1 << 16) {
-                // four values per access (the record is 4-byte aligned): a lane's access to its own record costs a cache line per
-                // instruction whatever its width
+                // Four values per access (the record is 4-byte aligned), and the loads of eight accesses in flight before the first
+                // store: written as load - scale - store per element the loop is one exposed memory round trip per trip.
                 struct __attribute__((packed, aligned(4))) Q4 { i32 v[4]; };
-                int i = sLTP_shp_buf_idx - ltp_mem_length;
-                for (; i + 4 <= sLTP_shp_buf_idx; i += 4) {
-                    Q4 q = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[i]);
+                auto scale_run = [&](i32 *a, int i, const int end) {
+                    for (; i + 32 <= end; i += 32) {
+                        Q4 q[8];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) q.v[u] = s_smulww(gain_adj_Q16, q.v[u]);
-                    *reinterpret_cast<Q4 *>(&NSQ.sLTP_shp_Q14[i]) = q;
-                }
-                for (; i < sLTP_shp_buf_idx; i++) NSQ.sLTP_shp_Q14[i] = s_smulww(gain_adj_Q16, NSQ.sLTP_shp_Q14[i]);
-                if (voiced && rewhite_flag == 0) {
-                    i = sLTP_buf_idx - lg - 5 / 2;
-                    for (; i + 4 <= sLTP_buf_idx; i += 4) {
-                        Q4 q = *reinterpret_cast<const Q4 *>(&sLTP_Q15[i]);
+                        for (int c = 0; c < 8; c++) q[c] = *reinterpret_cast<const Q4 *>(&a[i + 4 * c]);
+#pragma unroll
+                        for (int c = 0; c < 8; c++) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) q[c].v[u] = s_smulww(gain_adj_Q16, q[c].v[u]);
+                            *reinterpret_cast<Q4 *>(&a[i + 4 * c]) = q[c];
+                        }
+                    }
+                    for (; i + 4 <= end; i += 4) {
+                        Q4 q = *reinterpret_cast<const Q4 *>(&a[i]);
 #pragma unroll
                         for (int u = 0; u < 4; u++) q.v[u] = s_smulww(gain_adj_Q16, q.v[u]);
-                        *reinterpret_cast<Q4 *>(&sLTP_Q15[i]) = q;
+                        *reinterpret_cast<Q4 *>(&a[i]) = q;
                     }
-                    for (; i < sLTP_buf_idx; i++) sLTP_Q15[i] = s_smulww(gain_adj_Q16, sLTP_Q15[i]);
-                }
+                    for (; i < end; i++) a[i] = s_smulww(gain_adj_Q16, a[i]);
+                };
+                scale_run(NSQ.sLTP_shp_Q14, sLTP_shp_buf_idx - ltp_mem_length, sLTP_shp_buf_idx);
+                if (voiced && rewhite_flag == 0) scale_run(sLTP_Q15, sLTP_buf_idx - lg - 5 / 2, sLTP_buf_idx);
                 sLF_AR_shp_Q14 = s_smulww(gain_adj_Q16, sLF_AR_shp_Q14);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
@@ -576,12 +601,21 @@ __global__ __launch_bounds__(64) void silk_nsq_kernel(const opusgpu_nsq_in *__re
     // aligned (4 380 bytes), so the copy moves 16 bytes at a time through a 4-byte-aligned vector type.
     if ((ltp_mem_length & 7) == 0 && (frame_length & 1) == 0) {
         struct __attribute__((packed, aligned(4))) V16 { i32 x, y, z, w; };
-        V16 *dq = reinterpret_cast<V16 *>(NSQ.xq);
-        const V16 *sq = reinterpret_cast<const V16 *>(NSQ.xq + frame_length);
-        for (int i = 0; i < ltp_mem_length / 8; i++) { const V16 v = sq[i]; dq[i] = v; }
-        V16 *ds = reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14);
-        const V16 *ss = reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length);
-        for (int i = 0; i < ltp_mem_length / 4; i++) { const V16 v = ss[i]; ds[i] = v; }
+        // eight 16-byte pieces are loaded before the first of them is stored (one round trip per eight instead of per piece); a piece
+        // is stored below everything a later batch loads (the source runs frame_length elements ahead of the destination)
+        auto move_run = [&](V16 *d, const V16 *sc, const int n) {
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+                V16 v[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) v[c] = sc[i + c];
+#pragma unroll
+                for (int c = 0; c < 8; c++) d[i + c] = v[c];
+            }
+            for (; i < n; i++) { const V16 v = sc[i]; d[i] = v; }
+        };
+        move_run(reinterpret_cast<V16 *>(NSQ.xq), reinterpret_cast<const V16 *>(NSQ.xq + frame_length), ltp_mem_length / 8);
+        move_run(reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14), reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length), ltp_mem_length / 4);
     } else {
         for (int i = 0; i < ltp_mem_length; i++) NSQ.xq[i] = NSQ.xq[i + frame_length];
         for (int i = 0; i < ltp_mem_length; i++) NSQ.sLTP_shp_Q14[i] = NSQ.sLTP_shp_Q14[i + frame_length];
