@@ -15,7 +15,7 @@
 //     Pred / Shape (40 KB per wavefront), with one level of indirection: a path's entry for ring slot t lies in the column of
 //     the path that WROTE it, and every path carries a 64-bit map (2 bits per slot) saying which column that is;
 //   * per record, in HBM: the NSQ state (xq, sLTP_shp_Q14: read at the pitch lag by all four lanes, written by the
-//     winner's lane) and the re-whitening scratch sLTP / sLTP_Q15 (workspace).
+//     winner's lane) and the scaled re-whitened prediction buffer sLTP_Q15 (workspace; its 16-bit sLTP half is unused).
 // The reference's survivor copy (memcpy of the struct tail, :583-584) becomes: registers through ds_bpermute -- the map among
 // them: copying it IS the copy of the 160 ring rows (a replaced path goes on reading its new parent's history where the
 // parent wrote it; all four paths write slot t in the same step, each into its own column, so no entry is overwritten while a
@@ -83,7 +83,6 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
         return;
     }
     i32 *sLTP_Q15 = ws[r].sLTP_Q15;
-    i16 *sLTP = ws[r].sLTP;
     const int nb_subfr = in.nb_subfr, L = in.subfr_length, frame_length = in.frame_length;
     const int ltp_mem = in.ltp_mem_length, pord = in.predictLPCOrder, sord = in.shapingLPCOrder;
     const int voiced = in.signalType == 2;
@@ -146,30 +145,52 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                 // re-whitening: silk_LPC_analysis_filter (celt_fir form), the output samples shared out over the quad
                 const int start_idx = ltp_mem - lag - pord - 5 / 2;
                 const i16 *inp = &NSQ.xq[start_idx + sf * L];
-                i16 *outp = &sLTP[start_idx];
                 const int len = ltp_mem - start_idx;
                 {
                     // every lane of the quad takes a contiguous quarter of the outputs; the pord previous input samples travel in a
-                    // register window, so each sample of xq is read once per lane that needs it
+                    // register window, so each sample of xq is read once per lane that needs it. The outputs leave scaled, as
+                    // silk_nsq_del_dec_scale_states scales exactly these lag + 2 values (:651-660: sLTP_Q15[i] = SMULWB(inv_gain_Q31,
+                    // sLTP[i])): the 16-bit buffer in between is never touched; four inputs per load, four results per store
                     const int chunk = (len - pord + 3) >> 2, i0 = pord + k * chunk, i1 = imin(len, i0 + chunk);
+                    i32 ig_Q31 = s_inverse32_varq(in.Gains_Q16[sf] > 1 ? in.Gains_Q16[sf] : 1, 47);
+                    if (sf == 0) ig_Q31 = shl32(s_smulwb(ig_Q31, in.LTP_scale_Q14), 2);
+                    i32 *outq = &sLTP_Q15[start_idx];
                     i32 nA[16], w[16];
 #pragma unroll
                     for (int m = 0; m < 16; m++) {
                         nA[m] = m < pord ? (i32)(i16)(-A_Q12[m]) : 0;
                         w[m] = (m < pord && i0 < i1) ? (i32)inp[i0 - 1 - m] : 0;
                     }
-                    for (int ix = i0; ix < i1; ix++) {
+                    struct __attribute__((packed, aligned(2))) H4 { i16 v[4]; };
+                    struct __attribute__((packed, aligned(4))) W4 { i32 v[4]; };
+                    int ix = i0;
+                    for (; ix + 4 <= i1; ix += 4) {
+                        const H4 xi4 = *reinterpret_cast<const H4 *>(&inp[ix]);
+                        W4 o;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            i32 sum = 0;
+#pragma unroll
+                            for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
+                            const i32 xi = (i32)xi4.v[u];
+                            o.v[u] = s_smulwb(ig_Q31, (i32)sat16(xi + pshr32(sum, 12)));
+#pragma unroll
+                            for (int m = 15; m > 0; m--) w[m] = w[m - 1];
+                            w[0] = xi;
+                        }
+                        *reinterpret_cast<W4 *>(&outq[ix]) = o;
+                    }
+                    for (; ix < i1; ix++) {
                         i32 sum = 0;
 #pragma unroll
                         for (int m = 0; m < 16; m++) sum = s_addw(sum, __mul24(nA[m], w[m]));
                         const i32 xi = (i32)inp[ix];
-                        outp[ix] = sat16(xi + pshr32(sum, 12));
+                        outq[ix] = s_smulwb(ig_Q31, (i32)sat16(xi + pshr32(sum, 12)));
 #pragma unroll
                         for (int m = 15; m > 0; m--) w[m] = w[m - 1];
                         w[0] = xi;
                     }
                 }
-                for (int j = k; j < pord; j += 4) outp[j] = 0;
                 ltp_idx = ltp_mem;
                 rewhite = 1;
                 quad_fence();
@@ -177,22 +198,31 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
         }
         // ---- silk_nsq_del_dec_scale_states (NSQ_del_dec.c:632-724) ----
         const i32 gain = in.Gains_Q16[sf];
-        i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
+        const i32 inv_gain_Q31 = s_inverse32_varq(gain > 1 ? gain : 1, 47);
         const i32 adj = gain != prev_gain_Q16 ? s_div32_varq(prev_gain_Q16, gain, 16) : (i32)1 << 16;
         const i32 inv_gain_Q23 = s_rshift_round(inv_gain_Q31, 8);
         prev_gain_Q16 = gain;
         {
             const int lg = in.pitchL[sf];
-            if (rewhite) {
-                if (sf == 0) inv_gain_Q31 = shl32(s_smulwb(inv_gain_Q31, in.LTP_scale_Q14), 2);
-                for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx; i += 4) sLTP_Q15[i] = s_smulwb(inv_gain_Q31, sLTP[i]);
-            }
+            // (rewhite: sLTP_Q15[idx - lag - 2 .. idx) was scaled where it was produced, above)
             if (adj != (i32)1 << 16) {
                 {
                     // every lane of the quad takes four consecutive values per access (16 bytes; the record is 4-byte aligned)
                     struct __attribute__((packed, aligned(4))) Q4 { i32 v[4]; };
                     const int i0 = shp_idx - ltp_mem, body = ltp_mem & ~15;
-                    for (int i = i0 + 4 * k; i < i0 + body; i += 16) {
+                    int i = i0 + 4 * k;
+                    for (; i + 48 < i0 + body; i += 64) {               // four accesses in flight before the first store
+                        Q4 q[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) q[c] = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[i + 16 * c]);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) q[c].v[u] = s_smulww(adj, q[c].v[u]);
+                            *reinterpret_cast<Q4 *>(&NSQ.sLTP_shp_Q14[i + 16 * c]) = q[c];
+                        }
+                    }
+                    for (; i < i0 + body; i += 16) {
                         Q4 q = *reinterpret_cast<const Q4 *>(&NSQ.sLTP_shp_Q14[i]);
 #pragma unroll
                         for (int u = 0; u < 4; u++) q.v[u] = s_smulww(adj, q.v[u]);
@@ -200,8 +230,18 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
                     }
                     for (int i = i0 + body + k; i < shp_idx; i += 4) NSQ.sLTP_shp_Q14[i] = s_smulww(adj, NSQ.sLTP_shp_Q14[i]);
                 }
-                if (voiced && rewhite == 0)
-                    for (int i = ltp_idx - lg - 5 / 2 + k; i < ltp_idx - delay; i += 4) sLTP_Q15[i] = s_smulww(adj, sLTP_Q15[i]);
+                if (voiced && rewhite == 0) {
+                    int i = ltp_idx - lg - 5 / 2 + k;
+                    const int end = ltp_idx - delay;
+                    for (; i + 12 < end; i += 16) {
+                        i32 q[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) q[c] = sLTP_Q15[i + 4 * c];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) sLTP_Q15[i + 4 * c] = s_smulww(adj, q[c]);
+                    }
+                    for (; i < end; i += 4) sLTP_Q15[i] = s_smulww(adj, sLTP_Q15[i]);
+                }
                 lf_ar = s_smulww(adj, lf_ar);
 #pragma unroll
                 for (int j = 0; j < 16; j++) { lp[j] = s_smulww(adj, lp[j]); ar[j] = s_smulww(adj, ar[j]); }
@@ -457,10 +497,20 @@ __global__ __launch_bounds__(64) void silk_nsq_del_dec_kernel(const opusgpu_nsq_
             struct __attribute__((packed, aligned(4))) V16 { i32 x, y, z, w; };
             V16 *dq = reinterpret_cast<V16 *>(NSQ.xq);
             const V16 *sq = reinterpret_cast<const V16 *>(NSQ.xq + frame_length);
-            for (int c = k; c < ltp_mem / 8; c += 4) { const V16 v = sq[c]; dq[c] = v; }
-            V16 *ds = reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14);
-            const V16 *ss = reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length);
-            for (int c = k; c < ltp_mem / 4; c += 4) { const V16 v = ss[c]; ds[c] = v; }
+            // four pieces per lane are loaded before the first is stored: a stored piece lies below everything a later batch loads
+            auto move_run = [&](V16 *d, const V16 *sc, const int n) {
+                int c = k;
+                for (; c + 12 < n; c += 16) {
+                    V16 v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = sc[c + 4 * j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) d[c + 4 * j] = v[j];
+                }
+                for (; c < n; c += 4) { const V16 v = sc[c]; d[c] = v; }
+            };
+            move_run(dq, sq, ltp_mem / 8);
+            move_run(reinterpret_cast<V16 *>(NSQ.sLTP_shp_Q14), reinterpret_cast<const V16 *>(NSQ.sLTP_shp_Q14 + frame_length), ltp_mem / 4);
         } else {
             for (int m = k; m < ltp_mem; m += 4) {
                 const i16 a = NSQ.xq[m + frame_length];
