@@ -59,9 +59,8 @@ CA_DEV void silk_prefilter_dev(PrefilterState &P, const PrefilterCtrl &c, XG x, 
         int LTP_shp_buf_idx = P.sLTP_shp_buf_idx;
         i32 sLF_AR_shp_Q12 = P.sLF_AR_shp_Q12, sLF_MA_shp_Q12 = P.sLF_MA_shp_Q12;
         i32 prev_res_Q2 = P.sHarmHP_Q2;
-        for (int n = 0; n < L; n++) {
-            // silk_warped_LPC_analysis_filter_FIX_c (:58-100), one sample
-            const i32 in = x[k * L + n];
+        // one sample: silk_warped_LPC_analysis_filter_FIX_c (:58-100), the harmonic high-pass, silk_prefilt_FIX; returns xw_Q3
+        auto sample = [&](const i32 in) -> i32 {
             i32 tmp2 = s_smlawb(P.sAR_shp[0], P.sAR_shp[1], lambda_Q16);
             P.sAR_shp[0] = shl32(in, 14);
             i32 tmp1 = s_smlawb(P.sAR_shp[1], s_subw(P.sAR_shp[2], tmp2), lambda_Q16);
@@ -102,8 +101,21 @@ CA_DEV void silk_prefilter_dev(PrefilterState &P, const PrefilterCtrl &c, XG x, 
             LTP_shp_buf_idx = (LTP_shp_buf_idx - 1) & LTP_MASK;
             const i32 v = s_rshift_round(sLF_MA_shp_Q12, 12);
             ltp[LTP_shp_buf_idx] = (i16)(v > 32767 ? 32767 : (v < -32768 ? -32768 : v));
-            xw_Q3[k * L + n] = s_rshift_round(s_subw(sLF_MA_shp_Q12, n_LTP_Q12), 9);
+            return s_rshift_round(s_subw(sLF_MA_shp_Q12, n_LTP_Q12), 9);
+        };
+        // Four samples per group: one 8-byte load of the input, issued AHEAD of the previous group's 16-byte store (loads queue
+        // behind stores: a load and a store per sample would be an exposed memory round trip per sample)
+        int n = 0;
+        struct In4 { i16 v[4]; } in4;
+        struct Out4 { i32 v[4]; } out4;
+        if (L >= 4) __builtin_memcpy(&in4, &x[k * L], sizeof(in4));
+        for (; n + 4 <= L; n += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) out4.v[u] = sample((i32)in4.v[u]);
+            if (n + 8 <= L) __builtin_memcpy(&in4, &x[k * L + n + 4], sizeof(in4));
+            __builtin_memcpy(&xw_Q3[k * L + n], &out4, sizeof(out4));
         }
+        for (; n < L; n++) xw_Q3[k * L + n] = sample((i32)x[k * L + n]);
         P.sHarmHP_Q2 = prev_res_Q2;
         P.sLF_AR_shp_Q12 = sLF_AR_shp_Q12;
         P.sLF_MA_shp_Q12 = sLF_MA_shp_Q12;

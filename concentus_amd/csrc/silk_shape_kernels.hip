@@ -111,14 +111,20 @@ __global__ __launch_bounds__(64) void silk_prefilter_kernel(const opusgpu_prefil
     PrefiltRing ltp;
     ltp.col = ltp_s + threadIdx.x;
     ltp.s = &rp;
-    for (int a = 0; a < PF_RING; a += 8) {                     // slot a <- the entry a behind the newest, eight per access where the 512-ring does not wrap
-        const int p0 = (rp.cur + a) & LTP_MASK;
-        i32 v[8];
-        if (p0 <= LTP_BUF_LENGTH - 8) pe_load8(v, (const i16 *)st.sLTP_shp + p0);
-        else
-            for (int u = 0; u < 8; u++) v[u] = st.sLTP_shp[(p0 + u) & LTP_MASK];
+    static_assert(PF_RING % 32 == 0, "whole batches");
+    for (int a = 0; a < PF_RING; a += 32) {                    // slot a <- the entry a behind the newest, eight per access where the 512-ring does not
+        i32 v[4][8];                                           // wrap; four accesses in flight (a load per trip would be an exposed round trip per trip)
 #pragma unroll
-        for (int u = 0; u < 8; u++) ltp.col[(a + u) * 64] = (i16)v[u];
+        for (int c = 0; c < 4; c++) {
+            const int p0 = (rp.cur + a + 8 * c) & LTP_MASK;
+            if (p0 <= LTP_BUF_LENGTH - 8) pe_load8(v[c], (const i16 *)st.sLTP_shp + p0);
+            else
+                for (int u = 0; u < 8; u++) v[c][u] = st.sLTP_shp[(p0 + u) & LTP_MASK];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) ltp.col[(a + 8 * c + u) * 64] = (i16)v[c][u];
     }
     PrefilterState P;
     for (int k = 0; k <= MAX_SHAPE_LPC_ORDER; k++) P.sAR_shp[k] = st.sAR_shp[k];
