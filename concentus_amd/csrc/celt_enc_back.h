@@ -796,6 +796,7 @@ CA_DEV int stereo_itheta_wave(const x16_t *X, const x16_t *Y, int stereo, int N)
     i32 pm = 0, ps = 0;
 #if defined(CA_LANE_FRAME)
     if ((N & 7) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0) {
+#pragma unroll 4
         for (int i = 0; i < N; i += 8) {
             i32 xv[8], yv[8];
             ld_bins8(X + i, xv);
@@ -904,8 +905,27 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
                     X[j] = (i16)(mac16_16(mul16_16(a1, X[j]), a2, Y[j]) >> 14);
             } else {
 #if defined(CA_LANE_FRAME)
-                if (vec8)
-                    for (int j = 0; j < N; j += 8) {                                       // stereo_split (bands.c:362-373)
+                if (vec8) {
+                    // stereo_split (bands.c:362-373); two groups of eight bins per trip, all four loads ahead of the first store (loads
+                    // queue behind stores: a group per trip is an exposed memory round trip per eight bins)
+                    int j = 0;
+                    for (; j + 16 <= N; j += 16) {
+                        i32 xv[2][8], yv[2][8];
+#pragma unroll
+                        for (int g = 0; g < 2; g++) { ld_bins8(X + j + 8 * g, xv[g]); ld_bins8(Y + j + 8 * g, yv[g]); }
+#pragma unroll
+                        for (int g = 0; g < 2; g++) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                const i32 l = mul16_16(23170, xv[g][u]), r = mul16_16(23170, yv[g][u]);
+                                xv[g][u] = (i16)(add32(l, r) >> 15);
+                                yv[g][u] = (i16)(sub32(r, l) >> 15);
+                            }
+                            st_bins8(X + j + 8 * g, xv[g]);
+                            st_bins8(Y + j + 8 * g, yv[g]);
+                        }
+                    }
+                    for (; j < N; j += 8) {
                         i32 xv[8], yv[8];
                         ld_bins8(X + j, xv);
                         ld_bins8(Y + j, yv);
@@ -918,7 +938,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
                         st_bins8(X + j, xv);
                         st_bins8(Y + j, yv);
                     }
-                else
+                } else
 #endif
                 CA_UNROLL_LANE
                 for (int j = lane(); j < N; j += LANES) {                                  // stereo_split (bands.c:362-373)
@@ -1257,6 +1277,7 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
     CA_STAMP_F(F, 26);
     {
         CA_AS_LDS i16 *q = S;
+#pragma unroll 4
         for (int k = 0; k < N; k += 8, q += 8 * LDS_COL) {
             const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
             q[0 * LDS_COL] = (i16)v.x; q[1 * LDS_COL] = (i16)(v.x >> 16); q[2 * LDS_COL] = (i16)v.y; q[3 * LDS_COL] = (i16)(v.y >> 16);

@@ -66,6 +66,7 @@ CA_DEV i32 alloc_trim_offset(int j, int alloc_trim)                             
 // one more haar level; here the same buffer takes that level first and the band is then fetched again.
 CA_DEV void tf_stage_band(const x16_t *Xb, Col tmp, int N)
 {
+#pragma unroll 4                                   // (several loads in flight: one per trip is an exposed round trip per trip)
     for (int j = 0; j < N; j += 8) {
         i32 v[8];
         ld_bins8(Xb + j, v);

@@ -95,6 +95,7 @@ CA_DEV int tf_band_metric(const x16_t *Xb, PT tmp, PT1 tmp_1, int N, int narrow,
 {
     const int LM = LM3;
 #if defined(CA_LANE_FRAME)
+#pragma unroll 4
     for (int j = 0; j < N; j += 8) {
         i32 v[8];
         ld_bins8(Xb + j, v);
@@ -364,6 +365,7 @@ CA_DEVFN int spreading_decision_wave(L &F, FrameCtx &fc, int update_hf)
             const x16_t *x = X + M * CLT_eband5ms[i] + c * FRAME;
             i32 t = 0;                                                            // three 10-bit counters
 #if defined(CA_LANE_FRAME)
+#pragma unroll 4
             for (int j = 0; j < N; j += 8) {
                 i32 v[8];
                 ld_bins8(x + j, v);
@@ -526,6 +528,7 @@ CA_DEVFN int stereo_analysis_wave(L &F)
     i32 pLR = 0, pMS = 0;
     const int jend = CLT_eband5ms[13] << LM3;
 #if defined(CA_LANE_FRAME)
+#pragma unroll 4
     for (int j = 0; j < jend; j += 8) {
         i32 lv[8], rv[8];
         ld_bins8(X + j, lv);
@@ -578,6 +581,7 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
 #if defined(CA_LANE_FRAME)
+#pragma unroll 4
             for (int j = 0; j < n; j += 8) {
                 i32 lv[8], rv[8];
                 ld_bins8(X + j0 + j, lv);
@@ -598,6 +602,7 @@ CA_DEVFN int alloc_trim_analysis_wave(L &F, FrameCtx &fc, i32 tf_estimate, int i
             const int j0 = CLT_eband5ms[i] << LM, n = (CLT_eband5ms[i + 1] - CLT_eband5ms[i]) << LM;
             i32 p = 0;
 #if defined(CA_LANE_FRAME)
+#pragma unroll 4
             for (int j = 0; j < n; j += 8) {
                 i32 lv[8], rv[8];
                 ld_bins8(X + j0 + j, lv);
