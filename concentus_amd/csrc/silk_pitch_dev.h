@@ -117,6 +117,7 @@ CA_DEV void pe_xcorr_sliding(TA tgt, XA sig, int b0, int nlags, F sink)
 #pragma unroll
     for (int i = 0; i < PE_BLK; i++) { t[i] = (i32)tgt[i]; b[i] = (i32)sig[b0 + i]; }
     i32 leaving = (i32)sig[b0 + PE_BLK];
+#pragma unroll 2
     for (int j = 0;; j++) {
         i32 cc = 0;
 #pragma unroll
@@ -152,6 +153,7 @@ CA_DEV void pe_calc_corr_energy_st3(i32 *corr /*[4][PE_SCRATCH_SIZE]*/, i32 *nrg
         i32 energy = pe_inner_prod(frame + b0, frame + b0, sf_length);
         scratch_e[0] = energy;
         const int lag_diff = lag_high - lag_low + 1;
+#pragma unroll 4
         for (int i = 1; i < lag_diff; i++) {
             const i32 a = frame[b0 + sf_length - i], b = frame[b0 - i];
             energy -= __mul24(a, a);

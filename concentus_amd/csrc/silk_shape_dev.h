@@ -98,6 +98,7 @@ CA_DEV int silk_autocorr_dev(i32 *ac, XA x, XS xs, int n, int correlationCount)
     const int lag = imin(n, correlationCount) - 1;
     i32 ac0 = 1 + (n << 7);
     if (n & 1) { const i32 v = x[0]; ac0 += __mul24(v, v) >> 9; }
+#pragma unroll 4
     for (int i = n & 1; i < n; i += 2) {
         const i32 a = x[i], b = x[i + 1];
         ac0 += __mul24(a, a) >> 9;
@@ -106,9 +107,11 @@ CA_DEV int silk_autocorr_dev(i32 *ac, XA x, XS xs, int n, int correlationCount)
     int shift = (31 - s_clz32(ac0)) - 30 + 10;          // celt_ilog2(ac0) - 30 + 10
     shift = shift / 2;
     if (shift > 0) {
+#pragma unroll 8
         for (int i = 0; i < n; i++) xs[i] = (i16)(((i32)x[i] + ((i32)1 << (shift - 1))) >> shift);
     } else {
         shift = 0;
+#pragma unroll 8
         for (int i = 0; i < n; i++) xs[i] = (i16)(i32)x[i];
     }
     {
@@ -118,6 +121,7 @@ CA_DEV int silk_autocorr_dev(i32 *ac, XA x, XS xs, int n, int correlationCount)
         i32 acc[MAXLAG], w[MAXLAG];
 #pragma unroll
         for (int k = 0; k < MAXLAG; k++) { acc[k] = 0; w[k] = 0; }
+#pragma unroll 4
         for (int j = 0; j < n; j++) {
             const i32 xj = (i32)xs[j];
 #pragma unroll
