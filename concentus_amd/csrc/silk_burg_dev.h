@@ -78,6 +78,7 @@ CA_DEV void silk_burg_modified_dev(XA x, XE e, const i32 minInvGain_Q30, const i
             i32 w[16];
 #pragma unroll
             for (n = 0; n < 16; n++) w[n] = 0;
+#pragma unroll 4
             for (k = 0; k < subfr_length; k++) {
                 const i32 xk = xp[k];
                 C0_64 += __mul24(xk, xk);

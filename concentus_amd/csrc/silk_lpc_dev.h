@@ -297,18 +297,9 @@ CA_DEV void lpc_residual_energy(XA x, const i16 *B, int d, int first, int len, i
     i32 nrg = 0;
     int shft = 0, i;
     const int n1 = len - 1;
+    // one loop for sum_sqr_shift.c's two (before / after the first overflow): with shft = 0 the second form is the first
+#pragma unroll 4
     for (i = 0; i < n1; i += 2) {
-        const i32 a = res(first + i), b = res(first + i + 1);
-        nrg = (i32)((u32)nrg + (u32)__mul24(a, a));
-        nrg = (i32)((u32)nrg + (u32)__mul24(b, b));
-        if (nrg < 0) {
-            nrg = (i32)((u32)nrg >> 2);
-            shft = 2;
-            i += 2;
-            break;
-        }
-    }
-    for (; i < n1; i += 2) {
         const i32 a = res(first + i), b = res(first + i + 1);
         i32 t = __mul24(a, a);
         t = (i32)((u32)t + (u32)__mul24(b, b));

@@ -433,6 +433,7 @@ CA_DEV void silk_LTP_analysis_filter_dev(OUT out, XA x, const i16 *LTPCoef_Q14, 
         const i32 B0 = LTPCoef_Q14[k * LTP_ORDER], B1 = LTPCoef_Q14[k * LTP_ORDER + 1], B2 = LTPCoef_Q14[k * LTP_ORDER + 2],
                   B3 = LTPCoef_Q14[k * LTP_ORDER + 3], B4 = LTPCoef_Q14[k * LTP_ORDER + 4];
         const int n = subfr_length + pre_length;
+#pragma unroll 4
         for (int i = 0; i < n; i++) {
             i32 LTP_est = __mul24((i32)x_lag[i + 2], B0);
             LTP_est = s_addw(LTP_est, __mul24((i32)x_lag[i + 1], B1));
