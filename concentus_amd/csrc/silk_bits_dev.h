@@ -137,14 +137,19 @@ CA_DEV void silk_encode_pulses_dev(RangeEnc &ec, int signalType, int quantOffset
 {
     const int iter = frame_length >> 4;
     int sum_pulses[MAX_SHELL_BLOCKS], nRshifts[MAX_SHELL_BLOCKS];
-    for (int i = 0; i < iter; i++) {                                                         // a shell block per 16-byte access
-        struct B16 { i8 b[SHELL_FRAME]; } blk;
+    (void)absq;
+    // |q| of a shell block, down-shifted: one 16-byte access of the pulses per block and pass (the passes below re-derive what the
+    // reference keeps in abs_pulses[]: a block's magnitudes are needed shifted by its final nRshifts only)
+    struct B16 { i8 b[SHELL_FRAME]; };
+    auto block_abs = [&](int i, int rshift, u8 *a16) {
+        B16 blk;
         __builtin_memcpy(&blk, &pulses[i * SHELL_FRAME], sizeof(blk));
 #pragma unroll
-        for (int k = 0; k < SHELL_FRAME; k++) { const int q = blk.b[k]; absq[i * SHELL_FRAME + k] = (u8)(q < 0 ? -q : q); }
-    }
+        for (int k = 0; k < SHELL_FRAME; k++) { const int q = blk.b[k]; a16[k] = (u8)((q < 0 ? -q : q) >> rshift); }
+    };
     for (int i = 0; i < iter; i++) {
-        u8 *ap = absq + i * SHELL_FRAME;
+        u8 ap[SHELL_FRAME];
+        block_abs(i, 0, ap);
         nRshifts[i] = 0;
         while (1) {
             int a16[16], comb[8];
@@ -182,13 +187,20 @@ CA_DEV void silk_encode_pulses_dev(RangeEnc &ec, int signalType, int quantOffset
     }
     // shell encoding (:172-179)
     for (int i = 0; i < iter; i++)
-        if (sum_pulses[i] > 0) silk_shell_encoder_dev(ec, absq + i * SHELL_FRAME);
+        if (sum_pulses[i] > 0) {
+            u8 ap[SHELL_FRAME];
+            block_abs(i, nRshifts[i], ap);
+            silk_shell_encoder_dev(ec, ap);
+        }
     // LSB encoding (:181-199)
     for (int i = 0; i < iter; i++) {
         if (nRshifts[i] > 0) {
             const int nLS = nRshifts[i] - 1;
+            B16 blk;
+            __builtin_memcpy(&blk, &pulses[i * SHELL_FRAME], sizeof(blk));
+#pragma unroll
             for (int k = 0; k < SHELL_FRAME; k++) {
-                const int q = (i8)pulses[i * SHELL_FRAME + k];
+                const int q = blk.b[k];
                 const i32 abs_q = (i8)(q < 0 ? -q : q);
                 for (int j = nLS; j > 0; j--) ec_enc_icdf(ec, (abs_q >> j) & 1, SILK_lsb_iCDF, 8);
                 ec_enc_icdf(ec, abs_q & 1, SILK_lsb_iCDF, 8);
@@ -205,8 +217,11 @@ CA_DEV void silk_encode_pulses_dev(RangeEnc &ec, int signalType, int quantOffset
             const int p = sum_pulses[i];
             if (p > 0) {
                 icdf[0] = icdf_ptr[imin(p & 0x1F, 6)];
+                B16 blk;
+                __builtin_memcpy(&blk, &pulses[i * SHELL_FRAME], sizeof(blk));
+#pragma unroll
                 for (int j = 0; j < SHELL_FRAME; j++) {
-                    const int q = (i8)pulses[i * SHELL_FRAME + j];
+                    const int q = blk.b[j];
                     if (q != 0) ec_enc_icdf(ec, (q >> 15) + 1, icdf, 8);                    // silk_enc_map
                 }
             }
