@@ -597,8 +597,13 @@ CA_DEV void lowband_prepare(D &F, LowbandPrep &lp)
     if (lp.need_copy) {
         i16 *__restrict__ d = lp.scratch;
         const i16 *__restrict__ sQ = lp.src;
+        if ((lp.N & 7) == 0 && ((((uintptr_t)d) | ((uintptr_t)sQ)) & 15) == 0) {              // 16 bytes per access, four in flight
+#pragma unroll 4
+            for (int j = 0; j < lp.N; j += 8) *reinterpret_cast<int4 *>(d + j) = *reinterpret_cast<const int4 *>(sQ + j);
+        } else {
 #pragma unroll 8
-        for (int j = 0; j < lp.N; j++) d[j] = sQ[j];
+            for (int j = 0; j < lp.N; j++) d[j] = sQ[j];
+        }
         lowband = lp.scratch;
     }
     int B = lp.B, N_B = lp.N_B, tf_change = lp.tf_change;
@@ -710,18 +715,28 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
         }
         B <<= recombine;
         const i32 n = (i16)celt_sqrt(shl32(N0, 22));
+        // (lowband_out = the folding source norm[] in private memory, 16-byte aligned like the band: eight values per store too)
+        const bool lo16 = lowband_out && ((uintptr_t)lowband_out & 15) == 0;
         for (int k = 0; k < N0; k += 8) {
-            u32 h[8];
+            u32 h[8], g[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const i32 v = T[k + u];
                 h[u] = (u32)v & 0xffffu;
-                if (lowband_out) lowband_out[k + u] = (i16)mul16_16_q15(n, v);
+                g[u] = (u32)(i32)(i16)mul16_16_q15(n, v) & 0xffffu;
             }
             int4 w;
             w.x = (i32)(h[0] | (h[1] << 16)); w.y = (i32)(h[2] | (h[3] << 16));
             w.z = (i32)(h[4] | (h[5] << 16)); w.w = (i32)(h[6] | (h[7] << 16));
             *reinterpret_cast<int4 *>(X + k) = w;
+            if (lo16) {
+                w.x = (i32)(g[0] | (g[1] << 16)); w.y = (i32)(g[2] | (g[3] << 16));
+                w.z = (i32)(g[4] | (g[5] << 16)); w.w = (i32)(g[6] | (g[7] << 16));
+                *reinterpret_cast<int4 *>(lowband_out + k) = w;
+            } else if (lowband_out) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) lowband_out[k + u] = (i16)g[u];
+            }
         }
         cm &= (1u << B) - 1;
         CA_STAMP_F(F, 9);
@@ -756,8 +771,80 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     return cm;
 }
 
+#if defined(CA_LANE_FRAME)
+// eight bins of this stream's X (a row of opusgpu_celt_dec_state in HBM, 16-byte aligned) per access: celt_enc_mid.h ld_bins8 / st_bins8
+CA_DEV void dec_ld8(const i16 *p, i32 v[8]) { ld_bins8((const x16_t *)p, v); }
+CA_DEV void dec_st8(i16 *p, const i32 v[8]) { st_bins8((x16_t *)p, v); }
+#endif
+
 CA_DEV void stereo_merge_dec(i16 *X, i16 *Y, i32 mid, int N)                                    // bands.c:375-427
 {
+#if defined(CA_LANE_FRAME)
+    // Lane build: X / Y are this stream's rows in HBM, so every access costs the wavefront a cache line per lane whatever its
+    // width, and a load per trip is an exposed memory round trip per trip: eight bins per access, several accesses in flight,
+    // a group's loads ahead of its stores. (The sums wrap, so their order is free.)
+    if ((N & 7) == 0 && ((((uintptr_t)X) | ((uintptr_t)Y)) & 15) == 0) {
+        i32 xp = 0, side = 0;
+#pragma unroll 4
+        for (int j = 0; j < N; j += 8) {
+            i32 xv[8], yv[8];
+            dec_ld8(X + j, xv);
+            dec_ld8(Y + j, yv);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { xp = mac16_16(xp, yv[u], xv[u]); side = mac16_16(side, yv[u], yv[u]); }
+        }
+        xp = mul16_32_q15(mid, xp);
+        const i32 mid2 = (i16)(mid >> 1);
+        const i32 El = sub32(add32(mul16_16(mid2, mid2), side), shl32(xp, 1));
+        const i32 Er = add32(add32(mul16_16(mid2, mid2), side), shl32(xp, 1));
+        if (Er < 161061 || El < 161061) {                                                      // QCONST32(6e-4f, 28)
+#pragma unroll 4
+            for (int j = 0; j < N; j += 8) {
+                i32 xv[8];
+                dec_ld8(X + j, xv);
+                dec_st8(Y + j, xv);
+            }
+            return;
+        }
+        int kl = celt_ilog2(El) >> 1, kr = celt_ilog2(Er) >> 1;
+        i32 t = vshr32(El, (kl - 7) << 1);
+        const i32 lgain = celt_rsqrt_norm(t);
+        t = vshr32(Er, (kr - 7) << 1);
+        const i32 rgain = celt_rsqrt_norm(t);
+        if (kl < 7) kl = 7;
+        if (kr < 7) kr = 7;
+        auto merge8 = [&](i32 *xv, i32 *yv) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const i32 l = (i16)mul16_16_p15(mid, xv[u]);
+                const i32 r = yv[u];
+                xv[u] = (i16)pshr32(mul16_16(lgain, sub16(l, r)), kl + 1);
+                yv[u] = (i16)pshr32(mul16_16(rgain, add16(l, r)), kr + 1);
+            }
+        };
+        int j = 0;
+        for (; j + 16 <= N; j += 16) {
+            i32 xv[2][8], yv[2][8];
+#pragma unroll
+            for (int g = 0; g < 2; g++) { dec_ld8(X + j + 8 * g, xv[g]); dec_ld8(Y + j + 8 * g, yv[g]); }
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                merge8(xv[g], yv[g]);
+                dec_st8(X + j + 8 * g, xv[g]);
+                dec_st8(Y + j + 8 * g, yv[g]);
+            }
+        }
+        for (; j < N; j += 8) {
+            i32 xv[8], yv[8];
+            dec_ld8(X + j, xv);
+            dec_ld8(Y + j, yv);
+            merge8(xv, yv);
+            dec_st8(X + j, xv);
+            dec_st8(Y + j, yv);
+        }
+        return;
+    }
+#endif
     i32 xp = 0, side = 0;
     for (int j = 0; j < N; j++) { xp = mac16_16(xp, Y[j], X[j]); side = mac16_16(side, Y[j], Y[j]); }
     xp = mul16_32_q15(mid, xp);
@@ -842,8 +929,21 @@ CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 
         }
     }
     if (N != 2) stereo_merge_dec(X, Y, mid, N);
-    if (inv)
+    if (inv) {
+#if defined(CA_LANE_FRAME)
+        if ((N & 7) == 0 && (((uintptr_t)Y) & 15) == 0) {
+#pragma unroll 2
+            for (int j = 0; j < N; j += 8) {
+                i32 yv[8];
+                dec_ld8(Y + j, yv);
+#pragma unroll
+                for (int u = 0; u < 8; u++) yv[u] = (i16)(-yv[u]);
+                dec_st8(Y + j, yv);
+            }
+        } else
+#endif
         for (int j = 0; j < N; j++) Y[j] = (i16)(-Y[j]);
+    }
     return cm;
 }
 
