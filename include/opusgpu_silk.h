@@ -288,7 +288,9 @@ int opusgpu_silk_noise_shape_analysis_batch(const opusgpu_noise_shape_in *d_in, 
  * Replaces silk_prefilter_FIX(psEnc, psEncCtrl, xw_Q3, x) (opus-fix/silk/fixed/prefilter_FIX.c:102-184, called from
  * silk_encode_frame_FIX right before the noise-shaping quantiser): warped short-term analysis filter, harmonic high-pass,
  * tilt / low-frequency / harmonic shaping. The state record has the layout of silk_prefilter_state_FIX (structs_FIX.h:53-62)
- * and is updated in place; the output is xw_Q3[frame_length], the x_Q3 argument of silk_NSQ / silk_NSQ_del_dec. */
+ * and is updated in place; the output is xw_Q3[frame_length], the x_Q3 argument of silk_NSQ / silk_NSQ_del_dec.
+ * Records whose pitch lags (pitchL[], lagPrev) are 1 or above 316 are rejected (status OPUSGPU_BAD_ARG, state untouched): the
+ * kernel keeps the newest 320 entries of the harmonic-shaping ring per frame; the encoder's lags are 0 or 32 .. 288. */
 typedef struct opusgpu_prefilter_state {
     int16_t sLTP_shp[512];
     int32_t sAR_shp[17];
