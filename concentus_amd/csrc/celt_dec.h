@@ -20,13 +20,17 @@ enum { DEC_BUF = 2048, DEC_MEM = DEC_BUF + OVL };           // DECODE_BUFFER_SIZ
 
 // per-packet working set (host memory in the emulation, private/global memory on the GPU)
 struct __attribute__((aligned(16))) DecWork {
-    i16 *X;                        // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
+    // Both rows live in the stream's state record in HBM and are typed as such (wave.h x16_t: global address space in the lane
+    // build): every pointer into X / norm -- band, lowband, lowband_out, lowband scratch -- is then a GLOBAL pointer and the band
+    // functions issue global_load / global_store. With norm[] in this (private) struct the same functions were handed pointers into
+    // either space, i.e. generic ones: 3 200 FLAT instructions in the kernel, each waiting on both memory counters.
+    x16_t *X;                      // -> decoded normalised bands X[c*960 + j] (opusgpu_celt_dec_state::mid_X)
+    x16_t *norm;                   // -> folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel (::mid_norm)
 #if defined(CA_LANE_FRAME)
     // (address space in the pointer type, wave.h: a generic pointer reloaded from this private struct makes every access FLAT)
     CA_AS_LDS i32 *lds_pvq32;      // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
     CA_AS_LDS i16 *lds_pvq16;      // -> ... of the 16-bit scratch (LANE_SCRATCH_N bins: (de)interleave, band staging)
 #endif
-    i16 norm[2 * 624];             // folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel
     i32 iy[176];
     i16 tmp[176];
     i32 offsets[NB], cap[NB], pulses[NB], fine_quant[NB], fine_priority[NB], tf_res[NB];
@@ -131,10 +135,10 @@ CA_DEV void tf_decode_dec(int isTransient, i32 *tf_res, RangeDec &dec)          
 }
 
 // ---- PVQ decode ----------------------------------------------------------------------------------------
-CA_DEV void exp_rotation1_ref(i16 *X, int len, int stride, i32 c, i32 s)                        // vq.c:43-68
+CA_DEV void exp_rotation1_ref(x16_t *X, int len, int stride, i32 c, i32 s)                        // vq.c:43-68
 {
     const i32 ms = (i16)neg32(s);
-    i16 *p = X;
+    x16_t *p = X;
     for (int i = 0; i < len - stride; i++) {
         i32 x1 = p[0], x2 = p[stride];
         p[stride] = (i16)pshr32(mac16_16(mul16_16(c, x2), s, x1), 15);
@@ -236,7 +240,7 @@ CA_DEV i32 cwrsi_dec(int n, int k, u32 i, PY y)
     return yy;
 }
 
-CA_DEV void renormalise_vector_dec(i16 *X, int N, i32 gain)                                     // vq.c:349-374
+CA_DEV void renormalise_vector_dec(x16_t *X, int N, i32 gain)                                     // vq.c:349-374
 {
     i32 E = 1;
 #pragma unroll 8
@@ -255,10 +259,10 @@ CA_DEV void renormalise_vector_dec(i16 *X, int N, i32 gain)                     
 }
 
 template <class D, class PI>
-CA_DEV unsigned alg_unquant_body(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy);
+CA_DEV unsigned alg_unquant_body(D &F, x16_t *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy);
 
 template <class D>
-CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain)   // vq.c:329-346
+CA_DEV unsigned alg_unquant_dec(D &F, x16_t *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain)   // vq.c:329-346
 {
 #if defined(CA_LANE_FRAME)
     // the pulse vector of a leaf of up to 48 bins lives in this lane's LDS column, of a larger one in private memory: two
@@ -271,7 +275,7 @@ CA_DEV unsigned alg_unquant_dec(D &F, i16 *X, int N, int K, int spread, int B, R
 }
 
 template <class D, class PI>
-CA_DEV unsigned alg_unquant_body(D &F, i16 *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy)
+CA_DEV unsigned alg_unquant_body(D &F, x16_t *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain, PI iy)
 {
     CA_STAMP_F(F, 8);
     u32 V = pvq_u(N, K) + pvq_u(N, K + 1);
@@ -297,10 +301,10 @@ CA_DEV unsigned alg_unquant_body(D &F, i16 *X, int N, int K, int spread, int B, 
                     u32 h[8];
 #pragma unroll
                     for (int u = 0; u < 8; u++) h[u] = (u32)(i32)T[i + u] & 0xffffu;
-                    int4 w;
+                    v4i w;
                     w.x = (i32)(h[0] | (h[1] << 16)); w.y = (i32)(h[2] | (h[3] << 16));
                     w.z = (i32)(h[4] | (h[5] << 16)); w.w = (i32)(h[6] | (h[7] << 16));
-                    *reinterpret_cast<int4 *>(X + i) = w;
+                    *reinterpret_cast<CA_AS_GLB v4i *>(X + i) = w;
                 }
             } else {
 #pragma unroll 8
@@ -392,11 +396,11 @@ CA_DEV DecSplit compute_theta_dec(RangeDec &dec, DecBandCtx &ctx, int N, int *b,
 // over the band, and at ordinary rates no partition folds, so the passes are recorded here and only run when the
 // first partition asks for the data (the result is the same: the source is read-only until then).
 struct LowbandPrep {
-    i16 *src;          // norm + effective_lowband (nullptr: nothing to fold from)
-    i16 *scratch;      // where the transformed copy goes (nullptr: transform in place, last band)
+    x16_t *src;          // norm + effective_lowband (nullptr: nothing to fold from)
+    x16_t *scratch;      // where the transformed copy goes (nullptr: transform in place, last band)
     int N, B, N_B, tf_change, recombine, longBlocks, need_copy;
     int ready;
-    i16 *ptr;          // valid once ready
+    x16_t *ptr;          // valid once ready
 };
 template <class D> CA_DEV void lowband_prepare(D &F, LowbandPrep &lp);
 
@@ -404,10 +408,10 @@ template <class D> CA_DEV void lowband_prepare(D &F, LowbandPrep &lp);
 // is parked on a small stack (as in the encoder), each node carrying its own lowband, gain, fill and the
 // shift its collapse mask enters the parent's mask with.
 template <class D>
-CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int N, int b, int B, LowbandPrep &lp,
+CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, int N, int b, int B, LowbandPrep &lp,
                                     int LM, i32 gain, int fill)
 {
-    struct Parked { i16 *X; int lowband; int b, N, B, LM, first_bits, allow, fill, shift; i32 remaining, gain; };
+    struct Parked { x16_t *X; int lowband; int b, N, B, LM, first_bits, allow, fill, shift; i32 remaining, gain; };
     Parked st[5];
     int sp = 0, shift = 0;
     int lowband = lp.src ? 0 : -1;                  // offset into the (lazily prepared) folding source, -1: none
@@ -416,7 +420,7 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
         while (LM != -1 && N > 2 && b > pulse_cache_max(ctx.i, LM) + 12) {
             const int B0 = B;
             N >>= 1;
-            i16 *Y = X + N;
+            x16_t *Y = X + N;
             LM -= 1;
             if (B == 1) fill = (fill & 1) | (fill << 1);
             B = (B + 1) >> 1;
@@ -473,8 +477,8 @@ CA_DEV unsigned quant_partition_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X
                     cm = cm_mask;
                 } else {
                     if (!lp.ready) lowband_prepare(F, lp);
-                    i16 *__restrict__ xo = X;
-                    const i16 *__restrict__ lb = lp.ptr + lowband;
+                    x16_t *__restrict__ xo = X;
+                    const x16_t *__restrict__ lb = lp.ptr + lowband;
 #pragma unroll 8
                     for (int j = 0; j < N; j++) {
                         ctx.seed = celt_lcg_rand(ctx.seed);
@@ -523,10 +527,10 @@ CA_DEV void haar1_ref(P X, int N0, int stride)                                  
 }
 
 template <class PT>
-CA_DEV void deinterleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard);
+CA_DEV void deinterleave_hadamard_ref_via(x16_t *X, PT tmp, int N0, int stride, int hadamard);
 
 template <class D>
-CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)
+CA_DEV void deinterleave_hadamard_ref(D &F, x16_t *X, int N0, int stride, int hadamard)
 {
 #if defined(CA_LANE_FRAME)
     if (N0 * stride <= 96) deinterleave_hadamard_ref_via(X, lds_col(F.lds_pvq16), N0, stride, hadamard);
@@ -537,12 +541,12 @@ CA_DEV void deinterleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hada
 }
 
 template <class PT>
-CA_DEV void deinterleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard)
+CA_DEV void deinterleave_hadamard_ref_via(x16_t *X, PT tmp, int N0, int stride, int hadamard)
 {
     const int N = N0 * stride;
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
-        const i16 *__restrict__ x = X;
+        const x16_t *__restrict__ x = X;
         for (int i = 0; i < stride; i++) {
             const int d = hadamard ? ordery[i] : i;
 #pragma unroll 4
@@ -550,17 +554,17 @@ CA_DEV void deinterleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, in
         }
     }
     {
-        i16 *__restrict__ x = X;
+        x16_t *__restrict__ x = X;
 #pragma unroll 8
         for (int k = 0; k < N; k++) x[k] = tmp[k];
     }
 }
 
 template <class PT>
-CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard);
+CA_DEV void interleave_hadamard_ref_via(x16_t *X, PT tmp, int N0, int stride, int hadamard);
 
 template <class D>
-CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadamard)
+CA_DEV void interleave_hadamard_ref(D &F, x16_t *X, int N0, int stride, int hadamard)
 {
 #if defined(CA_LANE_FRAME)
     if (N0 * stride <= 96) interleave_hadamard_ref_via(X, lds_col(F.lds_pvq16), N0, stride, hadamard);
@@ -571,12 +575,12 @@ CA_DEV void interleave_hadamard_ref(D &F, i16 *X, int N0, int stride, int hadama
 }
 
 template <class PT>
-CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int hadamard)
+CA_DEV void interleave_hadamard_ref_via(x16_t *X, PT tmp, int N0, int stride, int hadamard)
 {
     const int N = N0 * stride;
     const u8 *ordery = CLT_ordery_table + stride - 2;
     {
-        const i16 *__restrict__ x = X;
+        const x16_t *__restrict__ x = X;
         for (int i = 0; i < stride; i++) {
             const int d = hadamard ? ordery[i] : i;
 #pragma unroll 4
@@ -584,7 +588,7 @@ CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int 
         }
     }
     {
-        i16 *__restrict__ x = X;
+        x16_t *__restrict__ x = X;
 #pragma unroll 8
         for (int k = 0; k < N; k++) x[k] = tmp[k];
     }
@@ -593,14 +597,17 @@ CA_DEV void interleave_hadamard_ref_via(i16 *X, PT tmp, int N0, int stride, int 
 template <class D>
 CA_DEV void lowband_prepare(D &F, LowbandPrep &lp)
 {
-    i16 *lowband = lp.src;
+    x16_t *lowband = lp.src;
     if (lp.need_copy) {
-        i16 *__restrict__ d = lp.scratch;
-        const i16 *__restrict__ sQ = lp.src;
+        x16_t *__restrict__ d = lp.scratch;
+        const x16_t *__restrict__ sQ = lp.src;
+#if defined(CA_LANE_FRAME)
         if ((lp.N & 7) == 0 && ((((uintptr_t)d) | ((uintptr_t)sQ)) & 15) == 0) {              // 16 bytes per access, four in flight
 #pragma unroll 4
-            for (int j = 0; j < lp.N; j += 8) *reinterpret_cast<int4 *>(d + j) = *reinterpret_cast<const int4 *>(sQ + j);
-        } else {
+            for (int j = 0; j < lp.N; j += 8) *reinterpret_cast<CA_AS_GLB v4i *>(d + j) = *reinterpret_cast<const CA_AS_GLB v4i *>(sQ + j);
+        } else
+#endif
+        {
 #pragma unroll 8
             for (int j = 0; j < lp.N; j++) d[j] = sQ[j];
         }
@@ -622,9 +629,9 @@ CA_DEV void lowband_prepare(D &F, LowbandPrep &lp)
 }
 
 // quant_band_n1 (bands.c:819-862), encode = 0
-CA_DEV unsigned quant_band_n1_dec(RangeDec &dec, DecBandCtx &ctx, i16 *X, i16 *Y, i16 *lowband_out)
+CA_DEV unsigned quant_band_n1_dec(RangeDec &dec, DecBandCtx &ctx, x16_t *X, x16_t *Y, x16_t *lowband_out)
 {
-    i16 *x = X;
+    x16_t *x = X;
     for (int c = 0; c < (Y ? 2 : 1); c++) {
         int sign = 0;
         if (ctx.remaining_bits >= 1 << BITRES) {
@@ -640,8 +647,8 @@ CA_DEV unsigned quant_band_n1_dec(RangeDec &dec, DecBandCtx &ctx, i16 *X, i16 *Y
 
 // quant_band (bands.c:1044-1174), encode = 0
 template <class D>
-CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int N, int b, int B, i16 *lowband, int LM,
-                               i16 *lowband_out, i32 gain, i16 *lowband_scratch, int fill)
+CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, int N, int b, int B, x16_t *lowband, int LM,
+                               x16_t *lowband_out, i32 gain, x16_t *lowband_scratch, int fill)
 {
     const int N0 = N;
     int N_B = (int)((u32)N / (u32)B);
@@ -687,7 +694,7 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
             int d = 0, j = 0, i = 0;
             if (stride > 1 && longBlocks) { while (ordery[i] != 0) i++; }
             for (int k = 0; k < N0; k += 8) {
-                const int4 w = *reinterpret_cast<const int4 *>(X + k);
+                const v4i w = *reinterpret_cast<const CA_AS_GLB v4i *>(X + k);
                 const i32 v[8] = {(i16)w.x, w.x >> 16, (i16)w.y, w.y >> 16, (i16)w.z, w.z >> 16, (i16)w.w, w.w >> 16};
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -725,14 +732,14 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
                 h[u] = (u32)v & 0xffffu;
                 g[u] = (u32)(i32)(i16)mul16_16_q15(n, v) & 0xffffu;
             }
-            int4 w;
+            v4i w;
             w.x = (i32)(h[0] | (h[1] << 16)); w.y = (i32)(h[2] | (h[3] << 16));
             w.z = (i32)(h[4] | (h[5] << 16)); w.w = (i32)(h[6] | (h[7] << 16));
-            *reinterpret_cast<int4 *>(X + k) = w;
+            *reinterpret_cast<CA_AS_GLB v4i *>(X + k) = w;
             if (lo16) {
                 w.x = (i32)(g[0] | (g[1] << 16)); w.y = (i32)(g[2] | (g[3] << 16));
                 w.z = (i32)(g[4] | (g[5] << 16)); w.w = (i32)(g[6] | (g[7] << 16));
-                *reinterpret_cast<int4 *>(lowband_out + k) = w;
+                *reinterpret_cast<CA_AS_GLB v4i *>(lowband_out + k) = w;
             } else if (lowband_out) {
 #pragma unroll
                 for (int u = 0; u < 8; u++) lowband_out[k + u] = (i16)g[u];
@@ -760,8 +767,8 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
     if (lowband_out) {
         i32 n = (i16)celt_sqrt(shl32(N0, 22));
         {
-            i16 *__restrict__ d = lowband_out;
-            const i16 *__restrict__ sQ = X;
+            x16_t *__restrict__ d = lowband_out;
+            const x16_t *__restrict__ sQ = X;
 #pragma unroll 8
             for (int j = 0; j < N0; j++) d[j] = (i16)mul16_16_q15(n, sQ[j]);
         }
@@ -773,11 +780,11 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, int
 
 #if defined(CA_LANE_FRAME)
 // eight bins of this stream's X (a row of opusgpu_celt_dec_state in HBM, 16-byte aligned) per access: celt_enc_mid.h ld_bins8 / st_bins8
-CA_DEV void dec_ld8(const i16 *p, i32 v[8]) { ld_bins8((const x16_t *)p, v); }
-CA_DEV void dec_st8(i16 *p, const i32 v[8]) { st_bins8((x16_t *)p, v); }
+CA_DEV void dec_ld8(const x16_t *p, i32 v[8]) { ld_bins8(p, v); }
+CA_DEV void dec_st8(x16_t *p, const i32 v[8]) { st_bins8(p, v); }
 #endif
 
-CA_DEV void stereo_merge_dec(i16 *X, i16 *Y, i32 mid, int N)                                    // bands.c:375-427
+CA_DEV void stereo_merge_dec(x16_t *X, x16_t *Y, i32 mid, int N)                                    // bands.c:375-427
 {
 #if defined(CA_LANE_FRAME)
     // Lane build: X / Y are this stream's rows in HBM, so every access costs the wavefront a cache line per lane whatever its
@@ -879,8 +886,8 @@ CA_DEV void stereo_merge_dec(i16 *X, i16 *Y, i32 mid, int N)                    
 
 // quant_band_stereo (bands.c:1176-1335), encode = 0
 template <class D>
-CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 *X, i16 *Y, int N, int b, int B,
-                                      i16 *lowband, int LM, i16 *lowband_out, i16 *lowband_scratch, int fill)
+CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, x16_t *Y, int N, int b, int B,
+                                      x16_t *lowband, int LM, x16_t *lowband_out, x16_t *lowband_scratch, int fill)
 {
     if (N == 1) return quant_band_n1_dec(dec, ctx, X, Y, lowband_out);
     const int orig_fill = fill;
@@ -894,7 +901,7 @@ CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 
         mbits -= sbits;
         const int c = itheta > 8192;
         ctx.remaining_bits -= sc.qalloc + sbits;
-        i16 *x2 = c ? Y : X, *y2 = c ? X : Y;
+        x16_t *x2 = c ? Y : X, *y2 = c ? X : Y;
         int sign = 0;
         if (sbits) sign = (int)ec_dec_bits(dec, 1);
         sign = 1 - 2 * sign;
@@ -920,9 +927,9 @@ CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, i16 
             cm = quant_band_dec(F, dec, ctx, X, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, fill);
             rebalance = mbits - (rebalance - ctx.remaining_bits);
             if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            cm |= quant_band_dec(F, dec, ctx, Y, N, sbits, B, (i16 *)nullptr, LM, (i16 *)nullptr, side, (i16 *)nullptr, fill >> B);
+            cm |= quant_band_dec(F, dec, ctx, Y, N, sbits, B, (x16_t *)nullptr, LM, (x16_t *)nullptr, side, (x16_t *)nullptr, fill >> B);
         } else {
-            cm = quant_band_dec(F, dec, ctx, Y, N, sbits, B, (i16 *)nullptr, LM, (i16 *)nullptr, side, (i16 *)nullptr, fill >> B);
+            cm = quant_band_dec(F, dec, ctx, Y, N, sbits, B, (x16_t *)nullptr, LM, (x16_t *)nullptr, side, (x16_t *)nullptr, fill >> B);
             rebalance = sbits - (rebalance - ctx.remaining_bits);
             if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
             cm |= quant_band_dec(F, dec, ctx, X, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, fill);
@@ -955,9 +962,9 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
     const int LM = LM3, M = M8, C = 2;
     const int B = shortBlocks ? M : 1;
     const i16 *eB = CLT_eband5ms;
-    i16 *X_ = F.X, *Y_ = F.X + FRAME;
-    i16 *norm = F.norm, *norm2 = F.norm + M * eB[NB - 1];
-    i16 *lowband_scratch = X_ + M * eB[NB - 1];
+    x16_t *X_ = F.X, *Y_ = F.X + FRAME;
+    x16_t *norm = F.norm, *norm2 = F.norm + M * eB[NB - 1];
+    x16_t *lowband_scratch = X_ + M * eB[NB - 1];
     int lowband_offset = 0, update_lowband = 1;
     DecBandCtx ctx;
     ctx.intensity = intensity;
@@ -966,7 +973,7 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
     for (int i = 0; i < NB; i++) {
         ctx.i = i;
         const int last = i == NB - 1;
-        i16 *X = X_ + M * eB[i], *Y = Y_ + M * eB[i];
+        x16_t *X = X_ + M * eB[i], *Y = Y_ + M * eB[i];
         const int N = M * eB[i + 1] - M * eB[i];
         i32 tell = (i32)ec_tell_frac(dec);
         if (i != 0) balance -= tell;
@@ -1004,13 +1011,13 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
             for (int j = 0; j < M * eB[i]; j++) norm[j] = (i16)(((i32)norm[j] + norm2[j]) >> 1);
         }
         if (dual_stereo) {
-            x_cm = quant_band_dec(F, dec, ctx, X, N, b / 2, B, effective_lowband != -1 ? norm + effective_lowband : (i16 *)nullptr, LM,
-                                  last ? (i16 *)nullptr : norm + M * eB[i], 32767, lowband_scratch, (int)x_cm);
-            y_cm = quant_band_dec(F, dec, ctx, Y, N, b / 2, B, effective_lowband != -1 ? norm2 + effective_lowband : (i16 *)nullptr, LM,
-                                  last ? (i16 *)nullptr : norm2 + M * eB[i], 32767, lowband_scratch, (int)y_cm);
+            x_cm = quant_band_dec(F, dec, ctx, X, N, b / 2, B, effective_lowband != -1 ? norm + effective_lowband : (x16_t *)nullptr, LM,
+                                  last ? (x16_t *)nullptr : norm + M * eB[i], 32767, lowband_scratch, (int)x_cm);
+            y_cm = quant_band_dec(F, dec, ctx, Y, N, b / 2, B, effective_lowband != -1 ? norm2 + effective_lowband : (x16_t *)nullptr, LM,
+                                  last ? (x16_t *)nullptr : norm2 + M * eB[i], 32767, lowband_scratch, (int)y_cm);
         } else {
-            x_cm = quant_band_stereo_dec(F, dec, ctx, X, Y, N, b, B, effective_lowband != -1 ? norm + effective_lowband : (i16 *)nullptr, LM,
-                                         last ? (i16 *)nullptr : norm + M * eB[i], lowband_scratch, (int)(x_cm | y_cm));
+            x_cm = quant_band_stereo_dec(F, dec, ctx, X, Y, N, b, B, effective_lowband != -1 ? norm + effective_lowband : (x16_t *)nullptr, LM,
+                                         last ? (x16_t *)nullptr : norm + M * eB[i], lowband_scratch, (int)(x_cm | y_cm));
             y_cm = x_cm;
         }
         F.collapse_masks[i * C + 0] = (u8)x_cm;
@@ -1053,7 +1060,7 @@ CA_DEV void anti_collapse_dec(D &F, const i16 *logE, const i16 *prev1logE, const
             r = (i16)mul16_16_q14(23170, imin(23169, r));                                      // LM == 3
             r = (i16)(imin(thresh, r) >> 1);
             r = (i16)(mul16_16_q15(sqrt_1, r) >> shift);
-            i16 *X = F.X + c * FRAME + (CLT_eband5ms[i] << LM);
+            x16_t *X = F.X + c * FRAME + (CLT_eband5ms[i] << LM);
             int renormalize = 0;
             for (int k = 0; k < 1 << LM; k++) {
                 if (!(F.collapse_masks[i * C + c] & 1 << k)) {
@@ -1145,7 +1152,8 @@ CA_DEV DecResult celt_decode_front(D &F, opusgpu_celt_dec_state *st, const u8 *d
     res.samples = OPUSGPU_INVALID_PACKET;
     res.final_range = 0;
     st->mid_valid = 0;
-    F.X = st->mid_X;
+    F.X = (x16_t *)st->mid_X;
+    F.norm = (x16_t *)st->mid_norm;
     const int C = 2, N = FRAME, LM = LM3, M = M8;
     if (len < 2) { res.samples = len < 1 ? OPUSGPU_BAD_ARG : OPUSGPU_UNIMPLEMENTED; return res; }   // len == 1: PLC/DTX, not implemented
     // TOC (src/opus_decoder.c, opus_packet_parse_impl): CELT-only (0x80), fullband (3 << 5), 20 ms (3 << 3), stereo (4), code 0

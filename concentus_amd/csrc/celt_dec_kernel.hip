@@ -76,7 +76,8 @@ __global__ __launch_bounds__(64) void quant_all_bands_dec_hook_kernel(opusgpu_qa
     DecWork F;
     F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32);
     F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16);
-    F.X = rec->X;
+    F.X = (x16_t *)rec->X;
+    F.norm = (x16_t *)rec->norm;
     F.diag = nullptr;
     for (int k = 0; k < NB; k++) { F.pulses[k] = rec->pulses[k]; F.tf_res[k] = rec->tf_res[k]; }
     for (int k = 0; k < 2 * NB; k++) F.collapse_masks[k] = 0;

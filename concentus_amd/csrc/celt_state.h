@@ -75,6 +75,7 @@ typedef struct opusgpu_celt_dec_state {
     /* hand-off between the kernels of one opusgpu_decode_batch call (not stream state): the decoded normalised
      * bands, what the synthesis and post-filter kernels need to know about the frame, and the per-stream result */
     int16_t mid_X[2 * OPUSGPU_CELT_FRAME];
+    int16_t mid_norm[2 * 624];                             /* the frame's folding source (bands.c norm / norm2): working storage of the lane kernel */
     int32_t mid_valid, mid_isTransient, mid_silence;
     int32_t mid_pf_period_old, mid_pf_period, mid_pf_period_new;
     int32_t mid_pf_gain_old, mid_pf_gain, mid_pf_gain_new;

@@ -37,6 +37,7 @@ static inline int opusgpu_copy(void *dst, const void *src, size_t bytes, hipMemc
 // bytes; out: X (both channels), collapse_masks, seed, the decoder's fields.
 struct opusgpu_qab_dec_record {
     int16_t X[2 * 960];
+    int16_t norm[2 * 624];             // working storage (the folding source), not an output
     int32_t pulses[21], tf_res[21];
     int32_t shortBlocks, spread, dual_stereo, intensity, total_bits, balance, codedBands;
     uint32_t seed;
