@@ -650,6 +650,7 @@ template <class D>
 CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, int N, int b, int B, x16_t *lowband, int LM,
                                x16_t *lowband_out, i32 gain, x16_t *lowband_scratch, int fill)
 {
+    CA_STAMP_F(F, 16);
     const int N0 = N;
     int N_B = (int)((u32)N / (u32)B);
     int B0 = B, time_divide = 0, recombine = 0;
@@ -891,7 +892,9 @@ CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_
 {
     if (N == 1) return quant_band_n1_dec(dec, ctx, X, Y, lowband_out);
     const int orig_fill = fill;
+    CA_STAMP_F(F, 12);
     DecSplit sc = compute_theta_dec(dec, ctx, N, &b, B, B, LM, 1, &fill);
+    CA_STAMP_F(F, 13);
     const int inv = sc.inv, itheta = sc.itheta;
     const i32 mid = sc.imid, side = sc.iside;
     unsigned cm;
@@ -935,7 +938,9 @@ CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_
             cm |= quant_band_dec(F, dec, ctx, X, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, fill);
         }
     }
+    CA_STAMP_F(F, 17);
     if (N != 2) stereo_merge_dec(X, Y, mid, N);
+    CA_STAMP_F(F, 18);
     if (inv) {
 #if defined(CA_LANE_FRAME)
         if ((N & 7) == 0 && (((uintptr_t)Y) & 15) == 0) {
@@ -971,6 +976,7 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
     ctx.spread = spread;
     ctx.seed = *seed;
     for (int i = 0; i < NB; i++) {
+        CA_STAMP_F(F, 14);
         ctx.i = i;
         const int last = i == NB - 1;
         x16_t *X = X_ + M * eB[i], *Y = Y_ + M * eB[i];
@@ -1006,6 +1012,7 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
         } else {
             x_cm = y_cm = (1u << B) - 1;
         }
+        CA_STAMP_F(F, 15);
         if (dual_stereo && i == intensity) {
             dual_stereo = 0;
             for (int j = 0; j < M * eB[i]; j++) norm[j] = (i16)(((i32)norm[j] + norm2[j]) >> 1);

@@ -57,8 +57,10 @@ static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 namespace ca { struct StageClock { unsigned long long *acc; unsigned long long last; }; }
 #define CA_STAMP_DECL ca::StageClock *stage_clock
 #define CA_STAMP_F(F, k) do { ca::StageClock *stage_clock = (ca::StageClock *)(F).diag; CA_STAMP(k); } while (0)
-#define CA_STAMP(k) do { if (stage_clock && stage_clock->acc) { unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-        __builtin_amdgcn_s_waitcnt(0xC07F); stage_clock->acc[k] += _t - stage_clock->last; stage_clock->last = __builtin_amdgcn_s_memtime(); } } while (0)
+// (sched_barrier: the instruction scheduler may otherwise move a stage's arithmetic across the clock reads, and the shares lie)
+#define CA_STAMP(k) do { if (stage_clock && stage_clock->acc) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_s_waitcnt(0xC07F); stage_clock->acc[k] += _t - stage_clock->last; stage_clock->last = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 namespace ca { struct StageClock; }
 #define CA_STAMP(k) do {} while (0)

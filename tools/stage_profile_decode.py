@@ -12,7 +12,8 @@ import concentus_amd as ca
 
 NAMES = {0: "header", 1: "coarse_energy", 2: "tf+dynalloc+allocation+fine", 3: "pvq:ec_dec_uint", 4: "pvq:cwrsi", 5: "pvq:normalise",
          6: "pvq:rotation", 7: "band:setup(lowband haar/deinterleave)", 8: "partition walk + theta + fill", 9: "band:resynthesis",
-         10: "quant_all_bands rest", 11: "finalise + anti-collapse + state"}
+         10: "quant_all_bands rest", 11: "finalise + anti-collapse + state", 12: "dual/stereo dispatch", 13: "stereo theta",
+         14: "after band (masks, balance)", 15: "band head (tell, b, fold masks)", 16: "call -> quant_band entry", 17: "stereo: between the two quant_bands / before merge", 18: "stereo_merge"}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 pcm = torch.from_numpy(np.random.default_rng(3).integers(-8192, 8192, size=(n, 960, 2), dtype=np.int16)).cuda()
 pk, ln, _ = ca.encode_independent(pcm)
