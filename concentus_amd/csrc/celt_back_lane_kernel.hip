@@ -14,8 +14,8 @@
 
 namespace ca {
 
-// A = frames per wavefront. A == 64 fills every lane; A == 32 / 16 leave the upper lanes of each wavefront idle and
-// put 2 / 4 wavefronts into the 64-frame workgroup instead (same LDS footprint, [element][64] slots shared by the
+// A = frames per wavefront. A == 64 fills every lane; A == 32 leaves the upper lanes of each wavefront idle and
+// puts 2 wavefronts into the 64-frame workgroup instead (same LDS footprint, [element][64] slots shared by the
 // workgroup's waves): the back phase is bound by the latency of one frame's serial chain and by the divergence of the
 // lanes' partition walks, so at a fixed batch size half-filled waves, two per SIMD, hide each other's latency and
 // diverge less than one full wave per SIMD.
@@ -38,50 +38,33 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_c
     out_rng[n] = r.final_range;
 }
 
-// A = 16 with the register budget of four wavefronts per SIMD (128 VGPRs): the 64-frame workgroup is then four quarter-filled
-// wavefronts and all four workgroups a CU's LDS admits are resident at once (16 wavefronts per CU).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void celt_back_lane16_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out, int out_stride,
-                             int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
-{
-    fill_lds_tables();
-    const int l = threadIdx.x & 63;
-    if (l >= 16) return;
-    const int slot = (threadIdx.x >> 6) * 16 + l;
-    const int n = blockIdx.x * 64 + slot;
-    if (n >= nframes) return;
-    BackLds F;
-    F.col = (CA_AS_LDS i16 *)(g_lds_scratch + slot);
-    opusgpu_celt_state *st = states ? states + n : nullptr;
-    FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
-    out_len[n] = r.bytes;
-    out_rng[n] = r.final_range;
-}
-
 }  // namespace ca
 
-// frames per wavefront of the lane kernels: OPUSGPU_LANE_FRAMES = 64 | 32 | 16 (default below)
-extern "C" int opusgpu_lane_frames(void)
+// frames per wavefront of the lane kernels: OPUSGPU_LANE_FRAMES = 64 | 32 overrides the per-kernel default
+extern "C" int opusgpu_lane_frames(int dflt)
 {
-    // measured on MI355X at 65 536 frames: back kernel 5.91 ms (64) / 5.53 ms (32) / 9.87 ms (16: 218 VGPRs allow two
-    // wavefronts per SIMD, so four quarter-filled ones take two rounds). Round 3, without the private working set (3.36 ms at 32):
-    // three wavefronts of 22 / 21 / 21 frames at 168 VGPRs 5.14 ms, four of 16 at 128 VGPRs 4.50 ms -- narrower wavefronts run
-    // chains that are hardly shorter, and there are more of them to issue. Read per call so tests can compare the mappings.
+    // measured on MI355X at 65 536 frames. Round 2 (4.3 KB of private working set per frame): back kernel 5.91 ms (64) / 5.53 ms
+    // (32) / 9.87 ms (16). Round 3, working set in the LDS column: 3.24 ms (64) / 3.31 ms (32); narrower wavefronts (three of
+    // 21-22 frames at 168 VGPRs: 5.14 ms, four of 16 at 128 VGPRs: 4.50 ms) run chains that are hardly shorter, and there are
+    // more of them to issue -- their kernels are gone. Read per call so tests can compare the mappings.
     const char *e = getenv("OPUSGPU_LANE_FRAMES");
-    const int v = e ? atoi(e) : 32;
-    return (v == 16 || v == 32 || v == 64) ? v : 32;
+    const int v = e ? atoi(e) : dflt;
+    return (v == 32 || v == 64) ? v : dflt;
 }
+
+// default of the encoder's back kernel: one full wavefront per SIMD. Its vector-ALU instruction count is that of a half-filled
+// one (645 k against 605 k per wavefront: the divergence of the partition walks saturates), so a SIMD issues half as many,
+// and what the second wavefront hid is hidden by loads issued ahead in the kernel's own instruction stream.
+enum { BACK_LANE_FRAMES_DEFAULT = 64 };
 
 extern "C" void opusgpu_launch_back_lane(const opusgpu_celt_config *cfg, void *states, const void *mid, unsigned char *out,
                                          int out_stride, int32_t *out_len, uint32_t *out_rng, int n, hipStream_t s)
 {
-    const int a = opusgpu_lane_frames();
+    const int a = opusgpu_lane_frames(BACK_LANE_FRAMES_DEFAULT);
     const dim3 grid((n + 63) / 64), block(64 * (64 / a));
 #define CA_LAUNCH(A) hipLaunchKernelGGL(ca::celt_back_lane_kernel<A>, grid, block, 0, s, *cfg, (opusgpu_celt_state *)states, \
                                         (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n)
     if (a == 32) CA_LAUNCH(32);
-    else if (a == 16 && getenv("OPUSGPU_LANE16_OCC4")) hipLaunchKernelGGL(ca::celt_back_lane16_kernel, grid, block, 0, s, *cfg, (opusgpu_celt_state *)states, (ca::FrameMid *)mid, out, out_stride, out_len, out_rng, n);
-    else if (a == 16) CA_LAUNCH(16);
     else CA_LAUNCH(64);
 #undef CA_LAUNCH
 }

@@ -629,7 +629,16 @@ CA_DEVFN FrameResult celt_encode_back(L &F, const opusgpu_celt_config &cfg, cons
             F.oldLogE2[k] = mid->oldLogE2[k];
         }
 #endif
+#if defined(CA_LANE_FRAME)
+        {   // (two 16-byte loads in flight, not 32 byte loads each waited for)
+            const v4i h0 = reinterpret_cast<const v4i *>(mid->packet_head)[0], h1 = reinterpret_cast<const v4i *>(mid->packet_head)[1];
+            const u32 w[8] = { (u32)h0.x, (u32)h0.y, (u32)h0.z, (u32)h0.w, (u32)h1.x, (u32)h1.y, (u32)h1.z, (u32)h1.w };
+#pragma unroll
+            for (int k = 0; k < 32; k++) F.packet[1 + k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+        }
+#else
         for (int k = lane(); k < 32; k += LANES) F.packet[1 + k] = mid->packet_head[k];
+#endif
     }
     i32 tell;
     wave_sync();

@@ -1176,6 +1176,7 @@ CA_DEV void quant_band_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
         }
         x16_t *X = Xband + xoff;
         // leaf: the basic no-split case (bands.c:983-1039)
+        CA_STAMP_F(F, 24);
         int q = bits2pulses(ctx.i, LM, b);
         CA_COUNT(q ? "node.leaf" : "node.leaf_q0", N);
         int curr_bits = pulses2bits(ctx.i, LM, q);
@@ -1263,6 +1264,27 @@ CA_DEVFN SplitCtx split_theta_lane(L &F, RangeEnc &ec, BandCtx &ctx, CA_AS_LDS c
 // half into the other and then have the free half for the leaf copy; the two widest bands (144 / 176 bins) lie across
 // both halves, de-interleave through their own rows in HBM and keep 64 slots for leaves of up to 32 bins. A leaf that
 // does not fit (an unsplit wide band: few pulses over many bins) is searched in private memory by the generic body.
+// N bins (a multiple of eight) of this lane's row of X into its column, eight 16-byte loads issued before the first of
+// them is waited for: N is uniform (a band's width), so the guards are scalar branches. (A loop of load - eight column
+// stores per chunk, unrolled or not, was compiled as one exposed memory round trip per chunk: the staging of the 42
+// band-channels of a frame cost 240 of them, 6 % of the kernel.)
+CA_DEV void stage_band_lane(const x16_t *Xband, CA_AS_LDS i16 *q, int N)
+{
+    for (int k = 0; k < N; k += 64, q += 64 * LDS_COL) {
+        v4i v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k + 8 * u < N) v[u] = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k + 8 * u);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (k + 8 * u < N) {
+                CA_AS_LDS i16 *c = q + 8 * u * LDS_COL;
+                c[0 * LDS_COL] = (i16)v[u].x; c[1 * LDS_COL] = (i16)(v[u].x >> 16); c[2 * LDS_COL] = (i16)v[u].y; c[3 * LDS_COL] = (i16)(v[u].y >> 16);
+                c[4 * LDS_COL] = (i16)v[u].z; c[5 * LDS_COL] = (i16)(v[u].z >> 16); c[6 * LDS_COL] = (i16)v[u].w; c[7 * LDS_COL] = (i16)(v[u].w >> 16);
+            }
+    }
+}
+
 template <class L>
 CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM)
 {
@@ -1275,15 +1297,7 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
     if (N == 1) { quant_band_n1_wave(ec, ctx, Xband, nullptr); return; }
     int recombine = tf_change > 0 ? tf_change : 0;
     CA_STAMP_F(F, 26);
-    {
-        CA_AS_LDS i16 *q = S;
-#pragma unroll 4
-        for (int k = 0; k < N; k += 8, q += 8 * LDS_COL) {
-            const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
-            q[0 * LDS_COL] = (i16)v.x; q[1 * LDS_COL] = (i16)(v.x >> 16); q[2 * LDS_COL] = (i16)v.y; q[3 * LDS_COL] = (i16)(v.y >> 16);
-            q[4 * LDS_COL] = (i16)v.z; q[5 * LDS_COL] = (i16)(v.z >> 16); q[6 * LDS_COL] = (i16)v.w; q[7 * LDS_COL] = (i16)(v.w >> 16);
-        }
-    }
+    stage_band_lane(Xband, S, N);
     for (int k = 0; k < recombine; k++) haar1_wave(lds_col(S), N >> k, 1 << k);
     CA_STAMP_F(F, 27);
     B >>= recombine;
@@ -1331,12 +1345,7 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
         if (narrow) {
             cur = S + LANE_HALF * LDS_COL;
         } else {
-            CA_AS_LDS i16 *q = S;
-            for (int k = 0; k < N; k += 8, q += 8 * LDS_COL) {
-                const v4i v = *reinterpret_cast<const CA_AS_GLB v4i *>(Xband + k);
-                q[0 * LDS_COL] = (i16)v.x; q[1 * LDS_COL] = (i16)(v.x >> 16); q[2 * LDS_COL] = (i16)v.y; q[3 * LDS_COL] = (i16)(v.y >> 16);
-                q[4 * LDS_COL] = (i16)v.z; q[5 * LDS_COL] = (i16)(v.z >> 16); q[6 * LDS_COL] = (i16)v.w; q[7 * LDS_COL] = (i16)(v.w >> 16);
-            }
+            stage_band_lane(Xband, S, N);
         }
     }
     CA_STAMP_F(F, 21);
@@ -1394,6 +1403,7 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
         }
         if (q != 0) {
             const int K = get_pulses(q);
+            CA_STAMP_F(F, 25);
             CA_AS_LDS const i16 *src = cur + xoff * LDS_COL;
             if (N <= leaf_max) {
                 CA_AS_LDS i16 *dst = leaf;
@@ -1445,6 +1455,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
     ctx.intensity = intensity;
     ctx.spread = spread;
     for (int i = 0; i < NB; i++) {
+        CA_STAMP_F(F, 29);
         ctx.i = i;
         x16_t *X = X_ + M * CLT_eband5ms[i];
         x16_t *Y = Y_ ? Y_ + M * CLT_eband5ms[i] : nullptr;
@@ -1463,6 +1474,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
         ctx.tf_change = frame_tf_change(F, i);
         if (dual_stereo && i == intensity) dual_stereo = 0;
 
+        CA_STAMP_F(F, 23);
         // plan the jobs
         int njobs = 0, rebal = 0, allow2 = 0;
         x16_t *jx0 = X, *jx1 = Y;

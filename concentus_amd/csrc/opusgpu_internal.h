@@ -9,8 +9,8 @@ extern "C" int opusgpu_check_launch(void);
 // optional per-kernel timing (see opusgpu_kernel_timing_enable); slot -1 = timing off
 extern "C" int opusgpu_timing_begin(int kernel, hipStream_t s);
 extern "C" void opusgpu_timing_end(int slot, hipStream_t s);
-// frames (streams) per wavefront of the lane-per-frame kernels: 64, 32 or 16 (OPUSGPU_LANE_FRAMES)
-extern "C" int opusgpu_lane_frames(void);
+// frames (streams) per wavefront of the lane-per-frame kernels: 64 or 32 (OPUSGPU_LANE_FRAMES overrides the kernel's default)
+extern "C" int opusgpu_lane_frames(int dflt);
 // device counter of SILK records whose header failed the bounds checks (silk_validate.h); nullptr = allocation failed
 extern "C" int *opusgpu_bad_record_counter(void);
 extern "C" int opusgpu_private_bad_counter_begin(void);

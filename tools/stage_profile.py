@@ -15,7 +15,7 @@ NAMES = ["load+dc_reject+rate", "silence", "preemph", "prefilter(pitch)", "trans
          "tf_analysis", "coarse_energy", "tf_enc+spread+dynalloc+trim", "vbr", "allocation", "fine_energy", "PVQ",
          "finalise", "done+store",
          "pvq:theta", "pvq:exp_rotation", "pvq:presearch", "pvq:greedy", "pvq:encode_pulses", "pvq:band_setup", "pvq:other",
-         "pitch:downsample", "pitch:search", "pitch:remove_doubling", "pitch:decimate4", "pitch:xcorr_coarse", "pitch:best_coarse", "pitch:xcorr_fine", "front:mdct", "front:band_energies"]
+         "pitch:downsample | lane: band head", "pitch:search | lane: after pop / descend rest", "pitch:remove_doubling | lane: leaf bits2pulses", "pitch:decimate4 | lane: stage entry", "pitch:xcorr_coarse | lane: X -> column + recombine", "pitch:best_coarse | lane: time-divide haar", "pitch:xcorr_fine | lane: band tail + reconvergence", "front:mdct", "front:band_energies"]
 NS = 32
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
