@@ -310,7 +310,9 @@ CA_DEV void exp_rotation1_chains(P X, int len, int nblocks, int stride, i32 c, i
             int i = r;
             if (LANES == 1) {
                 // four look-ahead loads before the first store of the group (they never alias: the stores
-                // trail the loads by `stride`)
+                // trail the loads by `stride`). (Software pipelines -- the NEXT group loaded before this one is computed, here
+                // and in the greedy search of alg_quant_lane -- were slower at 64 frames per wavefront, 3.21 -> 3.26 / 3.29 ms: the
+                // compiler already waits per element, lgkmcnt(n), and the copies of the look-ahead registers cost more.)
                 for (; i + 3 * stride < len - stride; i += 4 * stride) {
                     i32 v[4];
 #pragma unroll
@@ -843,15 +845,31 @@ CA_DEV int compute_qn(int N, int b, int offset, int pulse_cap, int stereo)      
     return (qn + 1) >> 1 << 1;
 }
 
-struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc; };
+struct SplitCtx { int inv, imid, iside, delta, itheta, qalloc, staged; };   // staged (lane build): the child coded first is already in the column
+
+// imid, iside and delta of a quantised angle (bands.c:789-811)
+CA_DEV void theta_params(int itheta, int N, int *imid, int *iside, int *delta)
+{
+    if (itheta == 0) { *imid = 32767; *iside = 0; *delta = -16384; }
+    else if (itheta == 16384) { *imid = 0; *iside = 32767; *delta = 16384; }
+    else {
+        *imid = bitexact_cos((i16)itheta);
+        *iside = bitexact_cos((i16)(16384 - itheta));
+        *delta = frac_mul16((N - 1) << 7, bitexact_log2tan(*iside, *imid));
+    }
+}
 
 // compute_theta (bands.c:645-817), encode = 1
 template <class L>
 CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X, x16_t *Y, int N, int *b, int B,
-                                     int B0, int LM, int stereo)
+                                     int B0, int LM, int stereo, int stage_first = 0)
 {
     (void)B;
+    (void)stage_first;
     SplitCtx sc;
+    sc.staged = 0;
+    int imid = 0, iside = 0, delta = 0;
+    bool have_params = false;
     const int i = ctx.i;
     int inv = 0;
     CA_STAMP_F(F, 22);
@@ -907,7 +925,21 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
 #if defined(CA_LANE_FRAME)
                 if (vec8) {
                     // stereo_split (bands.c:362-373); two groups of eight bins per trip, all four loads ahead of the first store (loads
-                    // queue behind stores: a group per trip is an exposed memory round trip per eight bins)
+                    // queue behind stores: a group per trip is an exposed memory round trip per eight bins).
+                    // The child that is coded first (quant_band_stereo orders them by their budgets, bands.c:1268-1275: the
+                    // arithmetic below is the caller's) goes straight into this lane's column, where quant_band_lane works on
+                    // it, and not back to its row: written there it would be read again at once, behind its own stores.
+                    bool to_col = false, mid_first = true;
+                    if (stage_first) {
+                        theta_params(itheta, N, &imid, &iside, &delta);
+                        have_params = true;
+                        const i32 b1 = *b - (int)((i32)ec_tell_frac(ec) - tell);
+                        const i32 mbits = imax(0, imin(b1, (b1 - delta) / 2));
+                        mid_first = mbits >= b1 - mbits;
+                        to_col = true;
+                        sc.staged = 1;
+                    }
+                    CA_AS_LDS i16 *const col = F.col;
                     int j = 0;
                     for (; j + 16 <= N; j += 16) {
                         i32 xv[2][8], yv[2][8];
@@ -921,8 +953,13 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
                                 xv[g][u] = (i16)(add32(l, r) >> 15);
                                 yv[g][u] = (i16)(sub32(r, l) >> 15);
                             }
-                            st_bins8(X + j + 8 * g, xv[g]);
-                            st_bins8(Y + j + 8 * g, yv[g]);
+                            if (to_col) {
+                                CA_AS_LDS i16 *c = col + (j + 8 * g) * LDS_COL;
+#pragma unroll
+                                for (int u = 0; u < 8; u++) c[u * LDS_COL] = (i16)(mid_first ? xv[g][u] : yv[g][u]);
+                            }
+                            if (!(to_col && mid_first)) st_bins8(X + j + 8 * g, xv[g]);
+                            if (!(to_col && !mid_first)) st_bins8(Y + j + 8 * g, yv[g]);
                         }
                     }
                     for (; j < N; j += 8) {
@@ -935,8 +972,13 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
                             xv[u] = (i16)(add32(l, r) >> 15);
                             yv[u] = (i16)(sub32(r, l) >> 15);
                         }
-                        st_bins8(X + j, xv);
-                        st_bins8(Y + j, yv);
+                        if (to_col) {
+                            CA_AS_LDS i16 *c = col + j * LDS_COL;
+#pragma unroll
+                            for (int u = 0; u < 8; u++) c[u * LDS_COL] = (i16)(mid_first ? xv[u] : yv[u]);
+                        }
+                        if (!(to_col && mid_first)) st_bins8(X + j, xv);
+                        if (!(to_col && !mid_first)) st_bins8(Y + j, yv);
                     }
                 } else
 #endif
@@ -972,14 +1014,7 @@ CA_DEVFN SplitCtx compute_theta_wave(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *X,
     }
     int qalloc = (int)((i32)ec_tell_frac(ec) - tell);
     *b -= qalloc;
-    int imid, iside, delta;
-    if (itheta == 0) { imid = 32767; iside = 0; delta = -16384; }
-    else if (itheta == 16384) { imid = 0; iside = 32767; delta = 16384; }
-    else {
-        imid = bitexact_cos((i16)itheta);
-        iside = bitexact_cos((i16)(16384 - itheta));
-        delta = frac_mul16((N - 1) << 7, bitexact_log2tan(iside, imid));
-    }
+    if (!have_params) theta_params(itheta, N, &imid, &iside, &delta);
     CA_STAMP_F(F, 16);
     sc.inv = inv; sc.imid = imid; sc.iside = iside; sc.delta = delta; sc.itheta = itheta; sc.qalloc = qalloc;
     return sc;
@@ -1286,7 +1321,7 @@ CA_DEV void stage_band_lane(const x16_t *Xband, CA_AS_LDS i16 *q, int N)
 }
 
 template <class L>
-CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM)
+CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int N, int b, int B, int LM, int staged = 0)
 {
     CA_STAMP_F(F, 22);
     CA_AS_LDS i16 *const S = F.col;                            // slot 0 of this lane's column
@@ -1297,7 +1332,7 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
     if (N == 1) { quant_band_n1_wave(ec, ctx, Xband, nullptr); return; }
     int recombine = tf_change > 0 ? tf_change : 0;
     CA_STAMP_F(F, 26);
-    stage_band_lane(Xband, S, N);
+    if (!staged) stage_band_lane(Xband, S, N);         // (staged: compute_theta_wave's stereo split left this child in the column)
     for (int k = 0; k < recombine; k++) haar1_wave(lds_col(S), N >> k, 1 << k);
     CA_STAMP_F(F, 27);
     B >>= recombine;
@@ -1476,7 +1511,8 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
 
         CA_STAMP_F(F, 23);
         // plan the jobs
-        int njobs = 0, rebal = 0, allow2 = 0;
+        int njobs = 0, rebal = 0, allow2 = 0, staged0 = 0;
+        (void)staged0;
         x16_t *jx0 = X, *jx1 = Y;
         int jb0 = b, jb1 = 0;
         if (dual_stereo) {
@@ -1485,7 +1521,12 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
             if (N == 1) {
                 quant_band_n1_wave(ec, ctx, X, Y);
             } else {
+#if defined(CA_LANE_FRAME)
+                SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B, LM, 1, 1);
+                staged0 = sc.staged;
+#else
                 SplitCtx sc = compute_theta_wave(F, ec, ctx, X, Y, N, &b, B, B, LM, 1);
+#endif
                 const int itheta = sc.itheta;
                 if (N == 2) {
                     int mbits = b, sbits = 0;
@@ -1520,7 +1561,7 @@ CA_DEV void quant_all_bands_wave(L &F, RangeEnc &ec, int C, int shortBlocks, int
                 if (rebalance > 3 << BITRES && allow2) jb += rebalance - (3 << BITRES);
             }
 #if defined(CA_LANE_FRAME)
-            quant_band_lane(F, ec, ctx, jx, N, jb, B, LM);
+            quant_band_lane(F, ec, ctx, jx, N, jb, B, LM, j == 0 && staged0);
 #else
             quant_band_wave(F, ec, ctx, jx, N, jb, B, LM);
 #endif
