@@ -37,14 +37,46 @@ CA_DEV void st_bins8(x16_t *p, const i32 v[8])
 }
 #endif
 
+// G butterflies of haar1, pair index p0 .. p0+G-1 of the flattened (j, i) space (stride = 1 << ls): all loads before the first store
+template <int G, class P>
+CA_DEV void haar1_group(P X, int p0, int ls, int stride)
+{
+    i32 a[G], b[G];
+    int ia[G];
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        const int p = p0 + u;
+        ia[u] = ((p >> ls) << (ls + 1)) + (p & (stride - 1));
+        a[u] = X[ia[u]];
+        b[u] = X[ia[u] + stride];
+    }
+#pragma unroll
+    for (int u = 0; u < G; u++) {
+        i32 t1 = mul16_16(23170, a[u]), t2 = mul16_16(23170, b[u]);
+        X[ia[u]] = (i16)pshr32(add32(t1, t2), 15);
+        X[ia[u] + stride] = (i16)pshr32(sub32(t1, t2), 15);
+    }
+}
+
 // haar1 on a vector in LDS (bands.c:581-594): N0 halved, `stride` interleaved sub-vectors; all pairs independent.
 template <class P>
 CA_DEV void haar1_wave(P X, int N0, int stride)
 {
     N0 >>= 1;
     if (LANES == 1) {
-        // one lane owns the frame: plain nested loops, four butterflies loaded before the first store (the
-        // compiler cannot prove the stores of one step clear of the loads of the next)
+        // one lane owns the frame. The N0 x stride butterflies are independent: walked as ONE index space in groups of eight
+        // (sixteen loads, then sixteen stores), whatever the stride -- nested (i, j) loops in groups of four left the short
+        // inner loops of the narrow bands (N0 = 2 at stride 2 of an 8-bin band) to a one-butterfly-per-round-trip tail.
+        const int npairs = N0 * stride;
+        if ((stride & (stride - 1)) == 0 && (npairs & 3) == 0) {
+            int ls = 0;
+            while ((1 << ls) < stride) ls++;
+            int p0 = 0;
+            for (; p0 + 8 <= npairs; p0 += 8) haar1_group<8>(X, p0, ls, stride);
+            if (p0 < npairs) haar1_group<4>(X, p0, ls, stride);
+            wave_sync();
+            return;
+        }
         for (int i = 0; i < stride; i++) {
             int j = 0;
             for (; j + 4 <= N0; j += 4) {
