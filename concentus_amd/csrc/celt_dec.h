@@ -504,6 +504,17 @@ template <class P>
 CA_DEV void haar1_ref(P X, int N0, int stride)                                                  // bands.c:580-594
 {
     N0 >>= 1;
+    {   // all butterflies are independent: one index space, eight per round trip (celt_enc_mid.h haar1_group)
+        const int npairs = N0 * stride;
+        if ((stride & (stride - 1)) == 0 && (npairs & 3) == 0) {
+            int ls = 0;
+            while ((1 << ls) < stride) ls++;
+            int p0 = 0;
+            for (; p0 + 8 <= npairs; p0 += 8) haar1_group<8>(X, p0, ls, stride);
+            if (p0 < npairs) haar1_group<4>(X, p0, ls, stride);
+            return;
+        }
+    }
     for (int i = 0; i < stride; i++) {
         int j = 0;
         for (; j + 4 <= N0; j += 4) {                // four butterflies loaded before the first store
@@ -694,17 +705,27 @@ CA_DEV unsigned quant_band_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, i
             const u8 *ordery = CLT_ordery_table + stride - 2;
             int d = 0, j = 0, i = 0;
             if (stride > 1 && longBlocks) { while (ordery[i] != 0) i++; }
-            for (int k = 0; k < N0; k += 8) {
-                const v4i w = *reinterpret_cast<const CA_AS_GLB v4i *>(X + k);
-                const i32 v[8] = {(i16)w.x, w.x >> 16, (i16)w.y, w.y >> 16, (i16)w.z, w.z >> 16, (i16)w.w, w.w >> 16};
+            // (the band's 16-byte loads eight at a time ahead of the scatter: one memory round trip per 64 bins, not per 8)
+            for (int k0 = 0; k0 < N0; k0 += 64) {
+                v4i wv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    T[j * stride + i] = (i16)v[u];
-                    if (++j == Ni) {
-                        j = 0;
-                        d++;
-                        i = d;
-                        if (stride > 1 && longBlocks && d < stride) { i = 0; while (ordery[i] != d) i++; }
+                for (int c = 0; c < 8; c++)
+                    if (k0 + 8 * c < N0) wv[c] = *reinterpret_cast<const CA_AS_GLB v4i *>(X + k0 + 8 * c);
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    if (k0 + 8 * c < N0) {
+                        const v4i w = wv[c];
+                        const i32 v[8] = {(i16)w.x, w.x >> 16, (i16)w.y, w.y >> 16, (i16)w.z, w.z >> 16, (i16)w.w, w.w >> 16};
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            T[j * stride + i] = (i16)v[u];
+                            if (++j == Ni) {
+                                j = 0;
+                                d++;
+                                i = d;
+                                if (stride > 1 && longBlocks && d < stride) { i = 0; while (ordery[i] != d) i++; }
+                            }
+                        }
                     }
                 }
             }

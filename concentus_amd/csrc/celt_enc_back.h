@@ -299,6 +299,47 @@ template <class P>
 CA_DEV void exp_rotation1_chains(P X, int len, int nblocks, int stride, i32 c, i32 s)
 {
     const i32 ms = (i16)neg32(s);
+    if (LANES == 1 && stride == 1 && (nblocks & 3) == 0 && len >= 2) {
+        // short blocks (B = 4 or 8 blocks of len = N / B bins, one chain each): four blocks in lockstep, so that a step is one
+        // round trip of four loads for four chains instead of one per chain (a block of a short-block band is 1-6 steps long:
+        // the look-ahead of the long-block path below never starts on it)
+        for (int b0 = 0; b0 < nblocks; b0 += 4) {
+            P x = X + b0 * len;
+            i32 x1[4], x2[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) x1[g] = x[g * len];
+            for (int i = 0; i < len - 1; i++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) x2[g] = x[g * len + i + 1];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const i32 n2 = (i16)pshr32(mac16_16(mul16_16(c, x2[g]), s, x1[g]), 15);
+                    x[g * len + i] = (i16)pshr32(mac16_16(mul16_16(c, x1[g]), ms, x2[g]), 15);
+                    x1[g] = n2;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; g++) x[g * len + len - 1] = (i16)x1[g];
+            if (len >= 3) {
+                // backward: i = len-3 .. 0; the value written to x[i] is the x2 of the next (lower) step
+#pragma unroll
+                for (int g = 0; g < 4; g++) x2[g] = x[g * len + len - 2];
+                for (int i = len - 3; i >= 0; i--) {
+#pragma unroll
+                    for (int g = 0; g < 4; g++) x1[g] = x[g * len + i];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        x[g * len + i + 1] = (i16)pshr32(mac16_16(mul16_16(c, x2[g]), s, x1[g]), 15);
+                        x2[g] = (i16)pshr32(mac16_16(mul16_16(c, x1[g]), ms, x2[g]), 15);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g++) x[g * len] = (i16)x2[g];
+            }
+        }
+        wave_sync();
+        return;
+    }
     CA_UNROLL_LANE
     for (int ch = lane(); ch < nblocks * stride; ch += LANES) {
         P x = X + (ch / stride) * len;
