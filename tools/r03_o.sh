@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03_o
 mkdir -p $O
 cd $R
-for a in 32 64; do
+for a in ${LANES_LIST:-32 64}; do
   export OPUSGPU_LANE_FRAMES=$a
   timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/enc_$a.json 2> $O/enc_$a.err || exit 1
   timeout -k 10 200 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload decode > $O/dec_$a.json 2> $O/dec_$a.err || exit 1
