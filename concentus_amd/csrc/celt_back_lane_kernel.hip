@@ -20,9 +20,8 @@ namespace ca {
 // lanes' partition walks, so at a fixed batch size half-filled waves, two per SIMD, hide each other's latency and
 // diverge less than one full wave per SIMD.
 template <int A>
-__global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states,
-                                                            FrameMid *mid, u8 *out, int out_stride,
-                                                            int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+__device__ __forceinline__ void back_lane_body(const opusgpu_celt_config &cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out,
+                                               int out_stride, int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
 {
     fill_lds_tables();
     const int l = threadIdx.x & 63;
@@ -36,6 +35,27 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_back_lane_kernel(opusgpu_c
     FrameResult r = celt_encode_back(F, cfg, mid + n, st, out + (size_t)n * out_stride);
     out_len[n] = r.bytes;
     out_rng[n] = r.final_range;
+}
+
+template <int A> __global__ void celt_back_lane_kernel(opusgpu_celt_config cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out,
+                                                       int out_stride, int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes);
+
+// one full wavefront per SIMD (the LDS columns of 4 x 64 frames fill a CU): the compiler is told so -- it may spend the whole
+// register file on keeping loads in flight instead of saving registers for wavefronts that cannot come
+template <>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void celt_back_lane_kernel<64>(opusgpu_celt_config cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out, int out_stride,
+                               int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+{
+    back_lane_body<64>(cfg, states, mid, out, out_stride, out_len, out_rng, nframes);
+}
+
+template <>
+__global__ __launch_bounds__(128)
+void celt_back_lane_kernel<32>(opusgpu_celt_config cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out, int out_stride,
+                               int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
+{
+    back_lane_body<32>(cfg, states, mid, out, out_stride, out_len, out_rng, nframes);
 }
 
 }  // namespace ca
