@@ -906,78 +906,28 @@ CA_DEV void stereo_merge_dec(x16_t *X, x16_t *Y, i32 mid, int N)                
     }
 }
 
-// quant_band_stereo (bands.c:1176-1335), encode = 0
-template <class D>
-CA_DEV unsigned quant_band_stereo_dec(D &F, RangeDec &dec, DecBandCtx &ctx, x16_t *X, x16_t *Y, int N, int b, int B,
-                                      x16_t *lowband, int LM, x16_t *lowband_out, x16_t *lowband_scratch, int fill)
+// quant_band_stereo (bands.c:1176-1335), encode = 0, is folded into quant_all_bands_dec below: a band is up to two
+// quant_band jobs (left / right of a dual-stereo band, or mid / side in the order of their budgets) that go through ONE call
+// site. quant_band_dec with everything it inlines (partition walk, pulse decoding, folding, resynthesis) is most of the
+// kernel's code; written as the reference writes it -- two calls for dual stereo, four for the two orders of mid / side, one
+// for two-bin bands -- it was inlined seven times, and a wavefront whose streams disagree on dual stereo or on the order of
+// mid and side ran the copies one after the other.
+CA_DEV void negate_band_dec(x16_t *Y, int N)
 {
-    if (N == 1) return quant_band_n1_dec(dec, ctx, X, Y, lowband_out);
-    const int orig_fill = fill;
-    CA_STAMP_F(F, 12);
-    DecSplit sc = compute_theta_dec(dec, ctx, N, &b, B, B, LM, 1, &fill);
-    CA_STAMP_F(F, 13);
-    const int inv = sc.inv, itheta = sc.itheta;
-    const i32 mid = sc.imid, side = sc.iside;
-    unsigned cm;
-    if (N == 2) {
-        int mbits = b, sbits = 0;
-        if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
-        mbits -= sbits;
-        const int c = itheta > 8192;
-        ctx.remaining_bits -= sc.qalloc + sbits;
-        x16_t *x2 = c ? Y : X, *y2 = c ? X : Y;
-        int sign = 0;
-        if (sbits) sign = (int)ec_dec_bits(dec, 1);
-        sign = 1 - 2 * sign;
-        cm = quant_band_dec(F, dec, ctx, x2, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, orig_fill);
-        y2[0] = (i16)(-sign * x2[1]);
-        y2[1] = (i16)(sign * x2[0]);
-        X[0] = (i16)mul16_16_q15(mid, X[0]);
-        X[1] = (i16)mul16_16_q15(mid, X[1]);
-        Y[0] = (i16)mul16_16_q15(side, Y[0]);
-        Y[1] = (i16)mul16_16_q15(side, Y[1]);
-        i32 t = X[0];
-        X[0] = (i16)sub16(t, Y[0]);
-        Y[0] = (i16)add16(t, Y[0]);
-        t = X[1];
-        X[1] = (i16)sub16(t, Y[1]);
-        Y[1] = (i16)add16(t, Y[1]);
-    } else {
-        int mbits = imax(0, imin(b, (b - sc.delta) / 2));
-        int sbits = b - mbits;
-        ctx.remaining_bits -= sc.qalloc;
-        i32 rebalance = ctx.remaining_bits;
-        if (mbits >= sbits) {
-            cm = quant_band_dec(F, dec, ctx, X, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, fill);
-            rebalance = mbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 0) sbits += rebalance - (3 << BITRES);
-            cm |= quant_band_dec(F, dec, ctx, Y, N, sbits, B, (x16_t *)nullptr, LM, (x16_t *)nullptr, side, (x16_t *)nullptr, fill >> B);
-        } else {
-            cm = quant_band_dec(F, dec, ctx, Y, N, sbits, B, (x16_t *)nullptr, LM, (x16_t *)nullptr, side, (x16_t *)nullptr, fill >> B);
-            rebalance = sbits - (rebalance - ctx.remaining_bits);
-            if (rebalance > 3 << BITRES && itheta != 16384) mbits += rebalance - (3 << BITRES);
-            cm |= quant_band_dec(F, dec, ctx, X, N, mbits, B, lowband, LM, lowband_out, 32767, lowband_scratch, fill);
-        }
-    }
-    CA_STAMP_F(F, 17);
-    if (N != 2) stereo_merge_dec(X, Y, mid, N);
-    CA_STAMP_F(F, 18);
-    if (inv) {
 #if defined(CA_LANE_FRAME)
-        if ((N & 7) == 0 && (((uintptr_t)Y) & 15) == 0) {
+    if ((N & 7) == 0 && (((uintptr_t)Y) & 15) == 0) {
 #pragma unroll 2
-            for (int j = 0; j < N; j += 8) {
-                i32 yv[8];
-                dec_ld8(Y + j, yv);
+        for (int j = 0; j < N; j += 8) {
+            i32 yv[8];
+            dec_ld8(Y + j, yv);
 #pragma unroll
-                for (int u = 0; u < 8; u++) yv[u] = (i16)(-yv[u]);
-                dec_st8(Y + j, yv);
-            }
-        } else
-#endif
-        for (int j = 0; j < N; j++) Y[j] = (i16)(-Y[j]);
+            for (int u = 0; u < 8; u++) yv[u] = (i16)(-yv[u]);
+            dec_st8(Y + j, yv);
+        }
+        return;
     }
-    return cm;
+#endif
+    for (int j = 0; j < N; j++) Y[j] = (i16)(-Y[j]);
 }
 
 // quant_all_bands (bands.c:1337-1502), encode = 0, start 0, end 21, LM 3, C = 2
@@ -1038,15 +988,100 @@ CA_DEV void quant_all_bands_dec(D &F, RangeDec &dec, int shortBlocks, int spread
             dual_stereo = 0;
             for (int j = 0; j < M * eB[i]; j++) norm[j] = (i16)(((i32)norm[j] + norm2[j]) >> 1);
         }
-        if (dual_stereo) {
-            x_cm = quant_band_dec(F, dec, ctx, X, N, b / 2, B, effective_lowband != -1 ? norm + effective_lowband : (x16_t *)nullptr, LM,
-                                  last ? (x16_t *)nullptr : norm + M * eB[i], 32767, lowband_scratch, (int)x_cm);
-            y_cm = quant_band_dec(F, dec, ctx, Y, N, b / 2, B, effective_lowband != -1 ? norm2 + effective_lowband : (x16_t *)nullptr, LM,
-                                  last ? (x16_t *)nullptr : norm2 + M * eB[i], 32767, lowband_scratch, (int)y_cm);
-        } else {
-            x_cm = quant_band_stereo_dec(F, dec, ctx, X, Y, N, b, B, effective_lowband != -1 ? norm + effective_lowband : (x16_t *)nullptr, LM,
-                                         last ? (x16_t *)nullptr : norm + M * eB[i], lowband_scratch, (int)(x_cm | y_cm));
-            y_cm = x_cm;
+        x16_t *const lb = effective_lowband != -1 ? norm + effective_lowband : (x16_t *)nullptr;
+        x16_t *const lb2 = effective_lowband != -1 ? norm2 + effective_lowband : (x16_t *)nullptr;
+        x16_t *const lo_out = last ? (x16_t *)nullptr : norm + M * eB[i];
+        x16_t *const lo_out2 = last ? (x16_t *)nullptr : norm2 + M * eB[i];
+        // plan the band's jobs (bands.c:1176-1335 for the stereo cases)
+        enum { DUAL = 0, STEREO = 1, STEREO_N2 = 2, DONE = 3 };
+        int kind = DUAL, njobs = 2, rebal = 0, allow2 = 0, inv = 0, sign = 1, n2_swap = 0;
+        i32 mid = 0, side = 0;
+        x16_t *jx0 = X, *jx1 = Y, *jl0 = lb, *jl1 = lb2, *jo0 = lo_out, *jo1 = lo_out2, *js0 = lowband_scratch, *js1 = lowband_scratch;
+        int jb0 = b / 2, jb1 = b / 2, jf0 = (int)x_cm, jf1 = (int)y_cm;
+        i32 jg0 = 32767, jg1 = 32767;
+        if (!dual_stereo) {
+            if (N == 1) {
+                x_cm = y_cm = quant_band_n1_dec(dec, ctx, X, Y, lo_out);
+                kind = DONE;
+                njobs = 0;
+            } else {
+                int fill = (int)(x_cm | y_cm);
+                const int orig_fill = fill;
+                int bs = b;                          // (quant_band_stereo's own copy: the band's b decides update_lowband below)
+                CA_STAMP_F(F, 12);
+                DecSplit sc = compute_theta_dec(dec, ctx, N, &bs, B, B, LM, 1, &fill);
+                CA_STAMP_F(F, 13);
+                inv = sc.inv;
+                mid = sc.imid;
+                side = sc.iside;
+                const int itheta = sc.itheta;
+                if (N == 2) {
+                    int mbits = bs, sbits = 0;
+                    if (itheta != 0 && itheta != 16384) sbits = 1 << BITRES;
+                    mbits -= sbits;
+                    n2_swap = itheta > 8192;
+                    ctx.remaining_bits -= sc.qalloc + sbits;
+                    if (sbits) sign = 1 - 2 * (int)ec_dec_bits(dec, 1);
+                    kind = STEREO_N2;
+                    njobs = 1;
+                    jx0 = n2_swap ? Y : X; jb0 = mbits; jl0 = lb; jo0 = lo_out; jg0 = 32767; js0 = lowband_scratch; jf0 = orig_fill;
+                } else {
+                    const int mbits = imax(0, imin(bs, (bs - sc.delta) / 2));
+                    const int sbits = bs - mbits;
+                    ctx.remaining_bits -= sc.qalloc;
+                    kind = STEREO;
+                    njobs = 2;
+                    rebal = 1;
+                    if (mbits >= sbits) {
+                        jx0 = X; jb0 = mbits; jl0 = lb; jo0 = lo_out; jg0 = 32767; js0 = lowband_scratch; jf0 = fill;
+                        jx1 = Y; jb1 = sbits; jl1 = nullptr; jo1 = nullptr; jg1 = side; js1 = nullptr; jf1 = fill >> B;
+                        allow2 = itheta != 0;
+                    } else {
+                        jx0 = Y; jb0 = sbits; jl0 = nullptr; jo0 = nullptr; jg0 = side; js0 = nullptr; jf0 = fill >> B;
+                        jx1 = X; jb1 = mbits; jl1 = lb; jo1 = lo_out; jg1 = 32767; js1 = lowband_scratch; jf1 = fill;
+                        allow2 = itheta != 16384;
+                    }
+                }
+            }
+        }
+        // ... and run them through one call site
+        const i32 rebalance0 = ctx.remaining_bits;
+        unsigned cm0 = 0, cm1 = 0;
+        for (int j = 0; j < njobs; j++) {
+            int jb = j ? jb1 : jb0;
+            if (j == 1 && rebal) {
+                const i32 rebalance = jb0 - (rebalance0 - ctx.remaining_bits);
+                if (rebalance > 3 << BITRES && allow2) jb += rebalance - (3 << BITRES);
+            }
+            const unsigned c = quant_band_dec(F, dec, ctx, j ? jx1 : jx0, N, jb, B, j ? jl1 : jl0, LM, j ? jo1 : jo0, j ? jg1 : jg0,
+                                              j ? js1 : js0, j ? jf1 : jf0);
+            if (j) cm1 = c; else cm0 = c;
+        }
+        if (kind == DUAL) {
+            x_cm = cm0;
+            y_cm = cm1;
+        } else if (kind == STEREO) {
+            CA_STAMP_F(F, 17);
+            stereo_merge_dec(X, Y, mid, N);
+            CA_STAMP_F(F, 18);
+            if (inv) negate_band_dec(Y, N);
+            x_cm = y_cm = cm0 | cm1;
+        } else if (kind == STEREO_N2) {
+            x16_t *x2 = n2_swap ? Y : X, *y2 = n2_swap ? X : Y;
+            y2[0] = (i16)(-sign * x2[1]);
+            y2[1] = (i16)(sign * x2[0]);
+            X[0] = (i16)mul16_16_q15(mid, X[0]);
+            X[1] = (i16)mul16_16_q15(mid, X[1]);
+            Y[0] = (i16)mul16_16_q15(side, Y[0]);
+            Y[1] = (i16)mul16_16_q15(side, Y[1]);
+            i32 t = X[0];
+            X[0] = (i16)sub16(t, Y[0]);
+            Y[0] = (i16)add16(t, Y[0]);
+            t = X[1];
+            X[1] = (i16)sub16(t, Y[1]);
+            Y[1] = (i16)add16(t, Y[1]);
+            if (inv) negate_band_dec(Y, N);
+            x_cm = y_cm = cm0;
         }
         F.collapse_masks[i * C + 0] = (u8)x_cm;
         F.collapse_masks[i * C + C - 1] = (u8)y_cm;
