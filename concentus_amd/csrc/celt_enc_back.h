@@ -1491,8 +1491,30 @@ CA_DEV void quant_band_lane(L &F, RangeEnc &ec, BandCtx &ctx, x16_t *Xband, int 
                     for (int u = 0; u < 8; u++) dst[u * LDS_COL] = (i16)v[u];
                 }
                 alg_quant_lane(F, ec, leaf, cnt, N, K, ctx.spread, B);
+            } else if (Nband <= LANE_HALF) {
+                // an unsplit band of 64 or 96 bins: searched where it lies (its bins are dead once they are coded: resynth == 0),
+                // the pulse counts in the band's other buffer. (Through the generic body below, whose search state is in HBM, a
+                // handful of such leaves per wavefront cost every lane of it ~25 k cycles each.)
+                CA_COUNT("lane.wide_leaf_inplace", N);
+                alg_quant_lane(F, ec, const_cast<CA_AS_LDS i16 *>(src), (CA_AS_LDS u16 *)(cur == S ? S + LANE_HALF * LDS_COL : S), N, K,
+                               ctx.spread, B);
+            } else if (N <= 48) {
+                // 36 / 44 bins, a quarter of one of the two widest bands: in place as well, the pulse counts in slots 184..231
+                // (the narrow leaves' copy and count slots, 176..239, are idle); the quantiser zeroes the slots up to the next
+                // multiple of eight past the leaf, which are the first bins of the next partition: kept aside and put back
+                CA_COUNT("lane.wide_leaf_inplace", N);
+                CA_AS_LDS i16 *const x = const_cast<CA_AS_LDS i16 *>(src);
+                CA_AS_LDS i16 *const tail = x + (N & ~7) * LDS_COL;
+                i32 keep[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) keep[u] = tail[u * LDS_COL];
+                alg_quant_lane(F, ec, x, (CA_AS_LDS u16 *)(S + 184 * LDS_COL), N, K, ctx.spread, B);
+                const int r0 = N & 7;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (u >= r0) tail[u * LDS_COL] = (i16)keep[u];
             } else {
-                // a leaf wider than the column's leaf slots (an unsplit wide band: a handful of pulses over 64..176 bins; N is a
+                // a leaf wider than the column's leaf slots (72 .. 176 bins of the two widest bands: a handful of pulses; N is a
                 // multiple of eight): searched in place in the band buffer by the generic body, its search state (2*iy, |x|, iy:
                 // 3 N 16-bit values) in bins of X this frame has already coded -- bands below this one are dead in both channels
                 // (resynth == 0) and the first band with such a leaf starts at bin 320 of a channel
