@@ -44,12 +44,59 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_decode_lane_kernel(opusgpu
     rng[k] = r.final_range;
 }
 
+// celt_decode_post_channel (celt_dec.h) for the lane pair (2k, 2k+1) = the two channels of stream k. The post-filter is the
+// same code; the de-emphasis (celt_decoder.c:183-285) runs in blocks of 32 samples -- eight 16-byte loads issued together, the
+// recurrence over them, then the stores -- and the two lanes exchange their outputs (DPP) so that each writes interleaved
+// stereo 16 bytes at a time: a load, the recurrence step and a 2-byte store per sample was one exposed memory round trip per
+// sample (loads queue behind stores), 960 per channel and most of this kernel's 0.70 ms.
+__device__ __forceinline__ void celt_decode_post_pair(opusgpu_celt_dec_state *st, int c, i16 *pcm)
+{
+    if (!st->mid_valid) return;
+    const int N = FRAME;
+    i32 *out_syn = st->decode_mem[c] + DEC_BUF - N;
+    comb_filter_inplace_dec(out_syn, st->mid_pf_period_old, st->mid_pf_period, 120, st->mid_pf_gain_old, st->mid_pf_gain,
+                            st->mid_pf_tapset_old, st->mid_pf_tapset);
+    comb_filter_inplace_dec(out_syn + 120, st->mid_pf_period, st->mid_pf_period_new, N - 120, st->mid_pf_gain, st->mid_pf_gain_new,
+                            st->mid_pf_tapset, st->mid_pf_tapset_new);
+    i32 m = st->preemph_memD[c];
+    const int4 *src = reinterpret_cast<const int4 *>(out_syn);
+    for (int j0 = 0; j0 < N; j0 += 32) {
+        int4 in[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) in[q] = src[(j0 >> 2) + q];
+        int4 res[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const i32 w[8] = {in[2 * g].x, in[2 * g].y, in[2 * g].z, in[2 * g].w, in[2 * g + 1].x, in[2 * g + 1].y, in[2 * g + 1].z, in[2 * g + 1].w};
+            u32 v[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const i32 t = add32(w[k], m);
+                m = mul16_32_q15(27853, t);
+                i32 x = pshr32(t, 12);
+                x = imax(x, -32768);
+                x = imin(x, 32767);
+                v[k] = (u32)x & 0xffffu;
+                o[k] = (u32)__builtin_amdgcn_update_dpp(0, (int)v[k], 0xB1, 0xF, 0xF, false);     // quad_perm [1,0,3,2]: the other channel
+            }
+            // channel 0's lane writes the group's stereo pairs 0..3, channel 1's lane pairs 4..7
+            u32 pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) pr[i] = c ? (o[4 + i] | (v[4 + i] << 16)) : (v[i] | (o[i] << 16));
+            res[g] = make_int4((int)pr[0], (int)pr[1], (int)pr[2], (int)pr[3]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) *reinterpret_cast<int4 *>(pcm + 2 * (j0 + 8 * g + 4 * c)) = res[g];
+    }
+    st->preemph_memD[c] = m;
+}
+
 __global__ __launch_bounds__(256) void celt_decode_post_kernel(opusgpu_celt_dec_state *states, i16 *__restrict__ pcm, int n)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int k = t >> 1, c = t & 1;
     if (k >= n) return;
-    celt_decode_post_channel(states + k, c, pcm + (size_t)k * FRAME * 2);
+    celt_decode_post_pair(states + k, c, pcm + (size_t)k * FRAME * 2);
 }
 
 // fresh decoder state (opus_decoder_create + OPUS_RESET_STATE, celt_decoder.c:1177-1190)
@@ -123,6 +170,7 @@ extern "C" int opusgpu_decode_batch(void *d_states, const unsigned char *d_packe
     if (n_streams < 0) return OPUSGPU_BAD_ARG;
     if (n_streams == 0) return OPUSGPU_OK;
     if (!d_states || !d_packets || !d_len || !d_pcm || !d_ret || !d_rng || packet_stride <= 0) return OPUSGPU_BAD_ARG;
+    if (((uintptr_t)d_pcm & 15) != 0) return OPUSGPU_BAD_ARG;         // the post kernel stores 16 bytes at a time
     hipStream_t s = (hipStream_t)stream;
     int slot = opusgpu_timing_begin(OPUSGPU_KERNEL_DEC_LANE, s);
     {

@@ -155,7 +155,8 @@ int opusgpu_encode_batch(const opusgpu_celt_config *cfg, void *d_states, const i
  *   d_states   device, n x opusgpu_celt_dec_state_size() bytes, initialised once with
  *              opusgpu_celt_dec_state_init (== opus_decoder_create(48000, 2)); advanced by one frame per call.
  *   d_packets  device, packet i at d_packets + i * packet_stride, d_len[i] bytes (as opus_decode's data, len).
- *   d_pcm      device, int16 [n][960][2] interleaved (as opus_decode's pcm with frame_size 960).
+ *   d_pcm      device, int16 [n][960][2] interleaved (as opus_decode's pcm with frame_size 960), 16-byte aligned
+ *              (it is written 16 bytes at a time; OPUSGPU_BAD_ARG otherwise).
  *   d_ret      device, int32 [n]: 960, or a negative OPUSGPU_* code for that stream (opus_decode's return value):
  *              OPUSGPU_UNIMPLEMENTED for other TOCs and for 1-byte packets (loss concealment / DTX).
  *   d_rng      device, uint32 [n]: OPUS_GET_FINAL_RANGE after the packet (equals the encoder's).
