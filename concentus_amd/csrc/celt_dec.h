@@ -28,7 +28,7 @@ struct __attribute__((aligned(16))) DecWork {
     x16_t *norm;                   // -> folding source: norm / norm2 (bands.c:1369-1372), M*eBands[20] = 624 per channel (::mid_norm)
 #if defined(CA_LANE_FRAME)
     // (address space in the pointer type, wave.h: a generic pointer reloaded from this private struct makes every access FLAT)
-    CA_AS_LDS i32 *lds_pvq32;      // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], 48 bins)
+    CA_AS_LDS i16 *lds_iy16;       // -> this lane's column of the workgroup's LDS pulse vector ([element][lane], LANE_IY16_N bins)
     CA_AS_LDS i16 *lds_pvq16;      // -> ... of the 16-bit scratch (LANE_SCRATCH_N bins: (de)interleave, band staging)
 #endif
     i32 iy[176];
@@ -265,9 +265,10 @@ template <class D>
 CA_DEV unsigned alg_unquant_dec(D &F, x16_t *X, int N, int K, int spread, int B, RangeDec &dec, i32 gain)   // vq.c:329-346
 {
 #if defined(CA_LANE_FRAME)
-    // the pulse vector of a leaf of up to 48 bins lives in this lane's LDS column, of a larger one in private memory: two
-    // instantiations, each with the address space in its accessor type
-    if (N <= 48) return alg_unquant_body(F, X, N, K, spread, B, dec, gain, lds_col(F.lds_pvq32));
+    // the pulse vector of a leaf of up to 64 bins lives in this lane's LDS column, of a larger one in private memory: two
+    // instantiations, each with the address space in its accessor type (and each run by the whole wavefront when its lanes
+    // disagree: 16-bit counts so that the unsplit 64-bin band takes the first one too)
+    if (N <= LANE_IY16_N) return alg_unquant_body(F, X, N, K, spread, B, dec, gain, lds_col(F.lds_iy16));
     return alg_unquant_body(F, X, N, K, spread, B, dec, gain, priv((i32 *)F.iy));
 #else
     return alg_unquant_body(F, X, N, K, spread, B, dec, gain, (i32 *)F.iy);

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void celt_decode_lane_diag_kernel(opusgpu_celt_
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= n) return;
     DecWork F;
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + threadIdx.x);
+    F.lds_iy16 = (CA_AS_LDS i16 *)(g_lds_iy16 + threadIdx.x);
     F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + threadIdx.x);
     unsigned long long acc[NSTAGES];
     for (int i = 0; i < NSTAGES; i++) acc[i] = 0;

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64 * (64 / A)) void celt_decode_lane_kernel(opusgpu
     const int k = blockIdx.x * 64 + slot;
     if (k >= n) return;
     DecWork F;
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + slot);
+    F.lds_iy16 = (CA_AS_LDS i16 *)(g_lds_iy16 + slot);
     F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + slot);
     const int ln = len[k];
     if (ln > packet_stride) {
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void quant_all_bands_dec_hook_kernel(opusgpu_qa
     fill_lds_tables();
     if (threadIdx.x != 0) return;
     DecWork F;
-    F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32);
+    F.lds_iy16 = (CA_AS_LDS i16 *)(g_lds_iy16);
     F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16);
     F.X = (x16_t *)rec->X;
     F.norm = (x16_t *)rec->norm;

@@ -41,25 +41,23 @@ struct LdsTables {
 #define CA_SHARED __shared__
 #endif
 CA_SHARED LdsTables g_lds_tables;
-// Per-lane scratch of the 64 frames of the workgroup, [element][lane] (30 KB in one block). Every lane owns ONE column,
-// and the two wavefronts of a workgroup (OPUSGPU_LANE_FRAMES=32) run independently, so an array may only ever be
-// addressed with the element size its region is laid out for -- a 16-bit view of the 32-bit region would land in other
-// lanes' columns:
-//   16-bit slots   0.. 95  PVQ search state y and |x| (48 each)          g_lds_pvq16
-//   16-bit slots  96..143  the leaf's copy of X (48)                     g_lds_xs
-//   then 48 32-bit slots   PVQ search state iy                           g_lds_pvq32
-// Stages that run while the PVQ search is idle (band re-arrangement, TF analysis) use the 16-bit part as one array of up
-// to LANE_SCRATCH_N bins through g_lds_pvq16.
+// Per-lane scratch of the 64 frames of the workgroup, [element][lane] (30 KB in one block), 16-bit slots throughout. Every lane
+// owns ONE column, and the two wavefronts of a workgroup (OPUSGPU_LANE_FRAMES=32) run independently, so the block may only
+// ever be addressed with ONE element size -- a 32-bit view of a region would land in other lanes' columns. The decoder's
+// lane kernel (celt_dec.h) lays it out as
+//   slots   0..175  band scratch: a leaf while it is scaled and un-rotated, a band during resynthesis / (de)interleave
+//                   (LANE_SCRATCH_N: the widest band, 176 bins, fits since round 3 -- at 144 the last band of every
+//                   transient frame was re-arranged in place in HBM, two bytes per access)       g_lds_pvq16
+//   slots 176..239  the pulse vector iy of a leaf of up to LANE_IY16_N = 64 bins (16-bit: |iy| <= K < 2^15)   g_lds_iy16
 // The encoder's back kernel (celt_back_lane_kernel.hip) defines CA_LANE_SLOTS 264 and lays the column out itself
-// (celt_enc_front.h LS_*, celt_enc_lane.h M_*): 16-bit slots throughout.
-enum { LANE_SCRATCH_N = 144 };
+// (celt_enc_front.h LS_*, celt_enc_lane.h M_*).
+enum { LANE_SCRATCH_N = 176, LANE_IY16_N = 64 };
 #if !defined(CA_LANE_SLOTS)
-#define CA_LANE_SLOTS (LANE_SCRATCH_N + 2 * 48)
+#define CA_LANE_SLOTS (LANE_SCRATCH_N + LANE_IY16_N)
 #endif
 CA_SHARED __attribute__((aligned(16))) int16_t g_lds_scratch[CA_LANE_SLOTS * 64];
 #define g_lds_pvq16 (ca::g_lds_scratch)
-#define g_lds_xs (ca::g_lds_scratch + 96 * 64)
-#define g_lds_pvq32 (reinterpret_cast<int32_t *>(ca::g_lds_scratch + LANE_SCRATCH_N * 64))
+#define g_lds_iy16 (ca::g_lds_scratch + ca::LANE_SCRATCH_N * 64)
 #if defined(CA_HOST_EMU)
 static inline void fill_lds_tables()
 {

@@ -87,13 +87,13 @@ extern "C" int emu_lane_celt_decode_frames(const unsigned char *packets, int str
         lds_poison();
         DecWork F;
         memset(&F, 0xAB, sizeof(F));
-        F.lds_pvq32 = (CA_AS_LDS i32 *)(g_lds_pvq32 + g_slot);
+        F.lds_iy16 = (CA_AS_LDS i16 *)(g_lds_iy16 + g_slot);
         F.lds_pvq16 = (CA_AS_LDS i16 *)(g_lds_pvq16 + g_slot);
         memset(L, 0xAB, sizeof(SynthLds));
         DecResult r = celt_decode_frame(F, *L, st, packets + (size_t)n * stride, len[n], pcm + (size_t)n * 960 * 2);
         ret[n] = r.samples;
         rng[n] = r.final_range;
-        clean &= lds_neighbours_untouched(LANE_SCRATCH_N);
+        clean &= lds_neighbours_untouched(LS_SLOTS);          // (the decoder's part of the image is 16-bit slots throughout since round 3)
     }
     free(L);
     free(st);
