@@ -26,6 +26,34 @@ CA_DEV int get_pulses(int i) { return i < 8 ? i : (8 + (i & 7)) << ((i >> 3) - 1
 
 CA_DEV const u8 *pulse_cache(int band, int LM) { return CLT_cache_bits50 + CLT_cache_index50[(LM + 1) * NB + band]; }
 
+#if defined(CA_LANE_FRAME)
+// Lane build: every look-up is an LDS round trip on the critical path of a lone wavefront, so the chain is kept short -- the
+// row's last entry and length come from tables of their own (celt_lane_tables.h), and the row (non-decreasing, at most 40
+// entries long) is searched in two rounds of independent probes instead of six dependent bisection steps.
+CA_DEV int pulse_cache_max(int band, int LM) { return g_lds_tables.cache_max_[(LM + 1) * NB + band]; }
+
+CA_DEV int bits2pulses(int band, int LM, int bits)                                         // rate.h:51-77
+{
+    const u8 *cache = pulse_cache(band, LM);
+    const int mx = g_lds_tables.cache_len_[(LM + 1) * NB + band];
+    bits--;
+    // lo = the largest index whose entry is below `bits` (0: none) = what the reference's bisection ends on; probes 6, 12, .., 36,
+    // then the five entries after the last probe that was below
+    int v[6], c1 = 0;
+#pragma unroll
+    for (int t = 0; t < 6; t++) v[t] = cache[imin(6 * (t + 1), mx)];
+#pragma unroll
+    for (int t = 0; t < 6; t++) c1 += (6 * (t + 1) <= mx) & (v[t] < bits);
+    int w[5], c2 = 0;
+#pragma unroll
+    for (int u = 0; u < 5; u++) w[u] = cache[imin(6 * c1 + u + 1, mx)];
+#pragma unroll
+    for (int u = 0; u < 5; u++) c2 += (6 * c1 + u + 1 <= mx) & (w[u] < bits);
+    const int lo = 6 * c1 + c2, hi = lo < mx ? lo + 1 : mx;
+    if (bits - (lo == 0 ? -1 : (int)cache[lo]) <= (int)cache[hi] - bits) return lo;
+    return hi;
+}
+#else
 CA_DEV int pulse_cache_max(int band, int LM) { const u8 *cache = pulse_cache(band, LM); return cache[cache[0]]; }
 
 CA_DEV int bits2pulses(int band, int LM, int bits)                                         // rate.h:51-77
@@ -40,6 +68,7 @@ CA_DEV int bits2pulses(int band, int LM, int bits)                              
     if (bits - (lo == 0 ? -1 : (int)cache[lo]) <= (int)cache[hi] - bits) return lo;
     return hi;
 }
+#endif
 
 CA_DEV int pulses2bits(int band, int LM, int pulses)                                       // rate.h:79-85
 {

@@ -34,6 +34,10 @@ struct LdsTables {
 #define X(T, NAME, N) T NAME##_[N];
     CA_LDS_TABLES(X)
 #undef X
+    // derived per (LM + 1, band), built by fill_lds_tables: the length of the pulse-cache row (cache[0]) and its last entry
+    // (cache[cache[0]], rate.h's "maximum bits of an unsplit band") -- one look-up instead of two / three dependent ones
+    uint8_t cache_len_[105];
+    uint8_t cache_max_[105];
 };
 #if defined(CA_HOST_EMU)
 #define CA_SHARED static            // the lane build on a CPU (tests/emu/celt_lane_emu.cpp): the workgroup's LDS is a plain array
@@ -64,6 +68,11 @@ static inline void fill_lds_tables()
 #define X(T, NAME, N) for (int k = 0; k < N; k++) g_lds_tables.NAME##_[k] = NAME[k];
     CA_LDS_TABLES(X)
 #undef X
+    for (int k = 0; k < 105; k++) {
+        const int ix = CLT_cache_index50[k];
+        g_lds_tables.cache_len_[k] = ix >= 0 ? CLT_cache_bits50[ix] : 0;
+        g_lds_tables.cache_max_[k] = ix >= 0 ? CLT_cache_bits50[ix + CLT_cache_bits50[ix]] : 0;
+    }
 }
 #else
 __device__ __forceinline__ void fill_lds_tables()
@@ -71,6 +80,11 @@ __device__ __forceinline__ void fill_lds_tables()
 #define X(T, NAME, N) for (int k = threadIdx.x; k < N; k += blockDim.x) g_lds_tables.NAME##_[k] = NAME[k];
     CA_LDS_TABLES(X)
 #undef X
+    for (int k = threadIdx.x; k < 105; k += blockDim.x) {
+        const int ix = CLT_cache_index50[k];
+        g_lds_tables.cache_len_[k] = ix >= 0 ? CLT_cache_bits50[ix] : 0;
+        g_lds_tables.cache_max_[k] = ix >= 0 ? CLT_cache_bits50[ix + CLT_cache_bits50[ix]] : 0;
+    }
     __syncthreads();
 }
 #endif
