@@ -99,3 +99,22 @@ extern "C" int emu_lane_celt_decode_frames(const unsigned char *packets, int str
     free(st);
     return clean ? 0 : -1;
 }
+
+// the lane build's pulse-cache look-ups (celt_enc_back.h: two rounds of probes, row length / last entry from derived tables) and
+// the reference's bisection (rate.h:51-77) on the tables as they are, for tests/test_lane_emu_cpu.py
+extern "C" int emu_lane_bits2pulses(int band, int LM, int bits) { fill_lds_tables(); return bits2pulses(band, LM, bits); }
+extern "C" int emu_lane_pulse_cache_max(int band, int LM) { fill_lds_tables(); return pulse_cache_max(band, LM); }
+extern "C" int emu_lane_bits2pulses_bisect(int band, int LM, int bits)
+{
+    fill_lds_tables();
+    const u8 *cache = pulse_cache(band, LM);
+    int lo = 0, hi = cache[0];
+    bits--;
+    for (int i = 0; i < 6; i++) {
+        int mid = (lo + hi + 1) >> 1;
+        if ((int)cache[mid] >= bits) hi = mid; else lo = mid;
+    }
+    if (bits - (lo == 0 ? -1 : (int)cache[lo]) <= (int)cache[hi] - bits) return lo;
+    return hi;
+}
+extern "C" int emu_lane_pulse_cache_max_ref(int band, int LM) { fill_lds_tables(); const u8 *cache = pulse_cache(band, LM); return cache[cache[0]]; }

@@ -83,3 +83,18 @@ def test_rare_lane_paths_are_reached_and_match_the_reference():
         ec.assert_packets_equal(out, lens, r2, pk, ln, rg, "%s %d" % (kind, br))
     seen = {k: emu.emu_lane_count(k.encode()) for k in ("lane.wide_leaf", "lane.tf_extra_level", "lane.coarse_intra_restored")}
     assert all(v > 0 for v in seen.values()), seen
+
+
+def test_lane_build_pulse_cache_lookups_equal_the_reference_bisection():
+    """bits2pulses / the split threshold of the lane build (two rounds of independent probes, derived per-(LM, band) tables:
+    celt_enc_back.h, celt_lane_tables.h) against rate.h:51-77's bisection and cache[cache[0]] on the same tables: every band,
+    every LM the walk can reach (0..3; -1 for the bands wider than one bin), every budget the 16 383-clamped b can take that
+    changes the answer (entries are bytes: -3..300) plus the extremes."""
+    emu = emulib.lane_lib()
+    for LM in (-1, 0, 1, 2, 3):
+        for band in range(21):
+            if LM == -1 and band < 8:
+                continue                       # one-bin bands at LM -1: no cache row (index -1), never looked up (N > 2 guards)
+            assert emu.emu_lane_pulse_cache_max(band, LM) == emu.emu_lane_pulse_cache_max_ref(band, LM), (band, LM)
+            for bits in list(range(-3, 301)) + [1000, 16383, 16384]:
+                assert emu.emu_lane_bits2pulses(band, LM, bits) == emu.emu_lane_bits2pulses_bisect(band, LM, bits), (band, LM, bits)
