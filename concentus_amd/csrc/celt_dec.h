@@ -1354,8 +1354,26 @@ CA_DEV void celt_decode_synth(S &L, opusgpu_celt_dec_state *st)
     const int isTransient = uni(st->mid_isTransient), silence = uni(st->mid_silence);
     for (int c = 0; c < 2; c++) {
         i32 *mem = st->decode_mem[c];
-        // OPUS_MOVE(decode_mem, decode_mem + N, DECODE_BUFFER_SIZE - N + overlap/2): ascending blocks, each read
-        // before it is written (the source runs 960 ahead of the destination)
+        // OPUS_MOVE(decode_mem, decode_mem + N, DECODE_BUFFER_SIZE - N + overlap/2)
+        if (LANES == 64) {
+            // the whole move through registers, 16 bytes per lane and access: five loads, then five stores -- block by block
+            // (load, store, load, ...) every block's load queued behind the previous block's store, 18 exposed memory
+            // round trips per channel
+            enum { NQ = (DEC_BUF - FRAME + OVL / 2) / 4, NM = (NQ + 63) / 64 };
+            static_assert((DEC_BUF - FRAME + OVL / 2) % 4 == 0 && (FRAME % 4) == 0, "history move in 16-byte units");
+            typedef int hv4 __attribute__((vector_size(16)));          // (gcc builds the wave-per-frame emulation: no ext_vector_type)
+            const hv4 *src = reinterpret_cast<const hv4 *>(mem + N);
+            hv4 *dst = reinterpret_cast<hv4 *>(mem);
+            hv4 hv[NM];
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                if (lane() + 64 * m < NQ) hv[m] = src[lane() + 64 * m];
+            wave_sync();
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                if (lane() + 64 * m < NQ) dst[lane() + 64 * m] = hv[m];
+        } else
+        // ascending blocks, each read before it is written (the source runs 960 ahead of the destination)
         for (int k0 = 0; k0 < DEC_BUF - N + OVL / 2; k0 += LANES) {
             const int k = k0 + lane();
             i32 v = 0;
