@@ -16,9 +16,9 @@ namespace ca {
 
 // A = frames per wavefront. A == 64 fills every lane; A == 32 leaves the upper lanes of each wavefront idle and
 // puts 2 wavefronts into the 64-frame workgroup instead (same LDS footprint, [element][64] slots shared by the
-// workgroup's waves): the back phase is bound by the latency of one frame's serial chain and by the divergence of the
-// lanes' partition walks, so at a fixed batch size half-filled waves, two per SIMD, hide each other's latency and
-// diverge less than one full wave per SIMD.
+// workgroup's waves). While the per-frame working set was private memory (rounds 1-2) the half-filled waves, two per SIMD,
+// won: they hid each other's scratch latency. With the working set in the LDS column the full wave wins (the default, below):
+// its instruction count is hardly larger than a half-filled one's, so the SIMD issues half as much.
 template <int A>
 __device__ __forceinline__ void back_lane_body(const opusgpu_celt_config &cfg, opusgpu_celt_state *states, FrameMid *mid, u8 *out,
                                                int out_stride, int *__restrict__ out_len, u32 *__restrict__ out_rng, int nframes)
