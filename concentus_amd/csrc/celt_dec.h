@@ -43,6 +43,10 @@ struct __attribute__((aligned(16))) DecWork {
 struct __attribute__((aligned(16))) SynthLds {
     i32 freq[FRAME];
     int2 f2[480];
+    // denormalise_bands: per band gain / shift of the channel in hand, and the band of every group of eight bins (120 groups)
+    i16 dn_gain[NB];
+    i8 dn_shift[NB];
+    u8 dn_band8[FRAME / 8];
 };
 
 CA_DEV u32 celt_lcg_rand(u32 seed) { return 1664525u * seed + 1013904223u; }                   // bands.c:63
@@ -1144,26 +1148,68 @@ CA_DEV void anti_collapse_dec(D &F, const i16 *logE, const i16 *prev1logE, const
 }
 
 // denormalise_bands (bands.c:169-238) for one channel, start 0, end 21, downsample 1; lanes share a band's bins
-CA_DEV void denormalise_bands_dec(const i16 *X, i32 *freq, const i16 *bandLogE, int silence)
+// denormalise_bands (bands.c:169-239), start 0, end 21, M = 8, no downsampling. The reference walks the bands; a wavefront doing
+// that pays 21 dependent steps (the band's energy from HBM, then its 8-176 bins, a sixth of the lanes busy on the narrow bands).
+// Here the 21 gains are computed side by side (one lane per band), and the 960 bins are then walked 64 at a time with all of a
+// lane's loads issued together; a bin finds its band through a 120-entry table (bands start at multiples of eight bins).
+template <class S>
+CA_DEV void denormalise_bands_dec(S &L, const i16 *X, const i16 *bandLogE, int silence)
 {
-    const int M = M8, N = FRAME;
-    int end = NB, bound = M * CLT_eband5ms[NB];
-    if (silence) { bound = 0; end = 0; }
-    for (int i = 0; i < end; i++) {
-        const int j0 = M * CLT_eband5ms[i], j1 = M * CLT_eband5ms[i + 1];
+    const int N = FRAME;
+    i32 *freq = L.freq;
+    for (int i = lane(); i < NB; i += LANES) {
         i32 lg = add16(bandLogE[i], shl16(CLT_eMeans[i], 6));
         int shift = 16 - (lg >> 10);
         i32 g;
         if (shift > 31) { shift = 0; g = 0; }
         else g = celt_exp2_frac(lg & 1023);
-        if (shift < 0) {
-            if (shift < -2) { g = 32767; shift = -2; }
-            for (int j = j0 + lane(); j < j1; j += LANES) freq[j] = shl32(mul16_16(X[j], g), -shift);
-        } else {
-            for (int j = j0 + lane(); j < j1; j += LANES) freq[j] = mul16_16(X[j], g) >> shift;
+        if (shift < -2) { g = 32767; shift = -2; }
+        L.dn_gain[i] = (i16)g;
+        L.dn_shift[i] = (i8)shift;
+    }
+    for (int k = lane(); k < N / 8; k += LANES) {
+        int b = 0;
+#pragma unroll
+        for (int i = 1; i < NB; i++) b += k >= CLT_eband5ms[i];
+        L.dn_band8[k] = (u8)b;
+    }
+    wave_sync();
+    if (silence) {
+        for (int k = lane(); k < N; k += LANES) freq[k] = 0;
+        wave_sync();
+        return;
+    }
+    const int bound = M8 * CLT_eband5ms[NB];
+    if (LANES == 64) {
+        i32 xv[(FRAME + 63) / 64];
+#pragma unroll
+        for (int m = 0; m < (FRAME + 63) / 64; m++) xv[m] = lane() + 64 * m < bound ? (i32)X[lane() + 64 * m] : 0;
+#pragma unroll
+        for (int m = 0; m < (FRAME + 63) / 64; m++) {
+            const int j = lane() + 64 * m;
+            if (j < N) {
+                i32 v = 0;
+                if (j < bound) {
+                    const int b = L.dn_band8[j >> 3];
+                    const i32 g = L.dn_gain[b];
+                    const int shift = L.dn_shift[b];
+                    v = shift < 0 ? shl32(mul16_16(xv[m], g), -shift) : mul16_16(xv[m], g) >> shift;
+                }
+                freq[j] = v;
+            }
+        }
+    } else {
+        for (int j = lane(); j < N; j += LANES) {
+            i32 v = 0;
+            if (j < bound) {
+                const int b = L.dn_band8[j >> 3];
+                const i32 g = L.dn_gain[b];
+                const int shift = L.dn_shift[b];
+                v = shift < 0 ? shl32(mul16_16(X[j], g), -shift) : mul16_16(X[j], g) >> shift;
+            }
+            freq[j] = v;
         }
     }
-    for (int k = bound + lane(); k < N; k += LANES) freq[k] = 0;
     wave_sync();
 }
 
@@ -1383,7 +1429,7 @@ CA_DEV void celt_decode_synth(S &L, opusgpu_celt_dec_state *st)
         }
         wave_sync();
         i32 *out_syn = mem + DEC_BUF - N;
-        denormalise_bands_dec(st->mid_X + c * N, L.freq, st->oldBandE + c * NB, silence);
+        denormalise_bands_dec(L, st->mid_X + c * N, st->oldBandE + c * NB, silence);
         if (isTransient) {
             const MdctTab T = mdct_global_tab<3>();
             mdct_backward_wave<3, 8>(L.freq, 1, L.f2, out_syn, T, lane());
