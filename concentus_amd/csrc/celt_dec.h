@@ -1398,36 +1398,47 @@ CA_DEV void celt_decode_synth(S &L, opusgpu_celt_dec_state *st)
     if (!uni(st->mid_valid)) return;
     const int N = FRAME;
     const int isTransient = uni(st->mid_isTransient), silence = uni(st->mid_silence);
-    for (int c = 0; c < 2; c++) {
-        i32 *mem = st->decode_mem[c];
-        // OPUS_MOVE(decode_mem, decode_mem + N, DECODE_BUFFER_SIZE - N + overlap/2)
-        if (LANES == 64) {
-            // the whole move through registers, 16 bytes per lane and access: five loads, then five stores -- block by block
-            // (load, store, load, ...) every block's load queued behind the previous block's store, 18 exposed memory
-            // round trips per channel
-            enum { NQ = (DEC_BUF - FRAME + OVL / 2) / 4, NM = (NQ + 63) / 64 };
-            static_assert((DEC_BUF - FRAME + OVL / 2) % 4 == 0 && (FRAME % 4) == 0, "history move in 16-byte units");
-            typedef int hv4 __attribute__((vector_size(16)));          // (gcc builds the wave-per-frame emulation: no ext_vector_type)
-            const hv4 *src = reinterpret_cast<const hv4 *>(mem + N);
-            hv4 *dst = reinterpret_cast<hv4 *>(mem);
-            hv4 hv[NM];
+    // OPUS_MOVE(decode_mem, decode_mem + N, DECODE_BUFFER_SIZE - N + overlap/2) of both channels first
+    if (LANES == 64) {
+        // the whole move through registers, 16 bytes per lane and access: the ten loads of the two channels, then their ten
+        // stores -- block by block (load, store, load, ...) every block's load queued behind the previous block's store, 18
+        // exposed memory round trips per channel, and the second channel's behind the first one's synthesis stores
+        enum { NQ = (DEC_BUF - FRAME + OVL / 2) / 4, NM = (NQ + 63) / 64 };
+        static_assert((DEC_BUF - FRAME + OVL / 2) % 4 == 0 && (FRAME % 4) == 0, "history move in 16-byte units");
+        typedef int hv4 __attribute__((vector_size(16)));          // (gcc builds the wave-per-frame emulation: no ext_vector_type)
+        hv4 hv[2][NM];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const hv4 *src = reinterpret_cast<const hv4 *>(st->decode_mem[c] + N);
 #pragma unroll
             for (int m = 0; m < NM; m++)
-                if (lane() + 64 * m < NQ) hv[m] = src[lane() + 64 * m];
-            wave_sync();
-#pragma unroll
-            for (int m = 0; m < NM; m++)
-                if (lane() + 64 * m < NQ) dst[lane() + 64 * m] = hv[m];
-        } else
-        // ascending blocks, each read before it is written (the source runs 960 ahead of the destination)
-        for (int k0 = 0; k0 < DEC_BUF - N + OVL / 2; k0 += LANES) {
-            const int k = k0 + lane();
-            i32 v = 0;
-            if (k < DEC_BUF - N + OVL / 2) v = mem[k + N];
-            wave_sync();
-            if (k < DEC_BUF - N + OVL / 2) mem[k] = v;
+                if (lane() + 64 * m < NQ) hv[c][m] = src[lane() + 64 * m];
         }
         wave_sync();
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            hv4 *dst = reinterpret_cast<hv4 *>(st->decode_mem[c]);
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                if (lane() + 64 * m < NQ) dst[lane() + 64 * m] = hv[c][m];
+        }
+    } else {
+        // ascending blocks, each read before it is written (the source runs 960 ahead of the destination)
+        for (int c = 0; c < 2; c++) {
+            i32 *mem = st->decode_mem[c];
+            for (int k0 = 0; k0 < DEC_BUF - N + OVL / 2; k0 += LANES) {
+                const int k = k0 + lane();
+                i32 v = 0;
+                if (k < DEC_BUF - N + OVL / 2) v = mem[k + N];
+                wave_sync();
+                if (k < DEC_BUF - N + OVL / 2) mem[k] = v;
+            }
+            wave_sync();
+        }
+    }
+    wave_sync();
+    for (int c = 0; c < 2; c++) {
+        i32 *mem = st->decode_mem[c];
         i32 *out_syn = mem + DEC_BUF - N;
         denormalise_bands_dec(L, st->mid_X + c * N, st->oldBandE + c * NB, silence);
         if (isTransient) {
